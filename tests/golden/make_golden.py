@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by RUNNING THE REFERENCE on CPU.
+
+Runs only in the build container (the reference is not present on the GPU box); the .npz files it
+writes are committed and are the only thing that travels.  Nothing here is reference source: the
+script imports the reference package from a scratch build and records inputs/outputs.
+
+Recipe for the scratch build:
+    mkdir -p /tmp/refbuild && cd /tmp/refbuild
+    cp -r /root/reference/neural_admixture /root/reference/setup.py .
+    printf '__version__ = "0.0.0+scratch"\n__version_tuple__ = (0, 0, 0)\n' > neural_admixture/_version.py
+    python3 setup.py build_ext --inplace          # Cython utils/rsvd (.so), ~1 min
+    NADM_REF=/tmp/refbuild python3 /root/repo/tests/golden/make_golden.py
+
+Precision: the reference calls torch.set_float32_matmul_precision('medium') inside
+launch_training (model/neural_admixture.py:349), which selects bf16 matmuls on this AMX CPU.  Every
+trajectory is captured twice: "hi" (that call neutralised -> true fp32, the oracle target) and
+"med" (as-is, the reference's own noise floor; used to state tolerances, not as a target).
+"""
+import os
+import sys
+import math
+import contextlib
+
+import numpy as np
+import torch
+
+REF = os.environ.get("NADM_REF", "/tmp/refbuild")
+sys.path.insert(0, REF)
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+from neural_admixture.model.neural_admixture import Q_P, NeuralAdmixture  # noqa: E402
+from neural_admixture.src.utils_c import utils as ref_cy                  # noqa: E402
+from neural_admixture.src import utils as ref_utils                       # noqa: E402
+from neural_admixture.src.svd import RSVD                                 # noqa: E402
+
+_real_set_prec = torch.set_float32_matmul_precision
+
+
+@contextlib.contextmanager
+def precision(mode):
+    """mode 'hi': neutralise the reference's 'medium' request; 'med': leave it."""
+    if mode == "hi":
+        torch.set_float32_matmul_precision = lambda *_a, **_k: None
+        _real_set_prec("highest")
+    try:
+        yield
+    finally:
+        torch.set_float32_matmul_precision = _real_set_prec
+        _real_set_prec("highest")
+
+
+def synth(N, M, K, seed=1234, missing=0.01):
+    rng = np.random.default_rng(seed)
+    Fq = np.clip(0.5 * rng.beta(0.5, 0.5, size=(K, M)), 0.005, 0.5)
+    Qt = rng.dirichlet(0.2 * np.ones(K), size=N)
+    G = rng.binomial(2, Qt @ Fq).astype(np.uint8)
+    G[rng.random((N, M)) < missing] = 3
+    return G
+
+
+def pack_rule(G):
+    """pack2bit.cu:26-31 restated with explicit loops (independent of oracle.pack2bit)."""
+    N, M = G.shape
+    Mp = (M + 3) // 4
+    out = np.zeros((N, Mp), dtype=np.uint8)
+    for r in range(N):
+        for c in range(Mp):
+            b = 0
+            for i in range(4):
+                j = 4 * c + i
+                if j < M:
+                    b |= (int(G[r, j]) & 3) << (2 * i)
+            out[r, c] = b
+    return out
+
+
+def state_np(model):
+    return {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def flat_state(prefix, sd):
+    return {f"{prefix}{k.replace('.', '_')}": v for k, v in sd.items()}
+
+
+def grads_np(model):
+    return {n: p.grad.detach().numpy().copy() for n, p in model.named_parameters()}
+
+
+# ------------------------------------------------------------------------------------------
+def case_pack():
+    rng = np.random.default_rng(7)
+    G = rng.integers(0, 4, size=(5, 11), dtype=np.uint8)
+    G[0, :4] = [0, 1, 2, 3]
+    G2 = rng.integers(0, 256, size=(3, 9), dtype=np.uint8)   # high bits must be masked (&3)
+    np.savez_compressed(os.path.join(OUT, "pack_layout.npz"), G=G, packed=pack_rule(G),
+                        G_hibits=G2, packed_hibits=pack_rule(G2))
+
+
+def case_bce_elementwise():
+    """clamp_(r,0,1) -> BCELoss(sum) forward/backward on hand-picked pre-clamp values
+    (neural_admixture.py:97,288): pins the -100 log clamp, the 1e-12 denominator, and the
+    inclusive gradient mask on the PRE-clamp value without any GEMM rounding in the way."""
+    one = np.float32(1.0)
+    specials = np.asarray([0.0, 1.0, -0.0, -1e-3, 1.0 + 1e-3, np.nextafter(one, np.float32(2)), np.nextafter(one, np.float32(0)),
+                           1e-30, 1e-13, 1e-12, 1e-7, 0.5, 0.25, 0.999999, 2.0, -5.0, 1e-38], dtype=np.float32)
+    rng = np.random.default_rng(12)
+    r = np.concatenate([specials, rng.uniform(-0.1, 1.1, 200).astype(np.float32)])
+    rr = np.repeat(r, 3)
+    xx = np.tile(np.asarray([0.0, 0.5, 1.0], dtype=np.float32), len(r))
+    rt = torch.tensor(rr, requires_grad=True)
+    out = torch.clamp_(rt * 1.0, 0, 1)
+    per = torch.nn.functional.binary_cross_entropy(out, torch.tensor(xx), reduction="none")
+    per.sum().backward()
+    np.savez_compressed(os.path.join(OUT, "bce_elementwise.npz"), r_raw=rr, x=xx, loss=per.detach().numpy(), grad=rt.grad.numpy())
+
+
+def one_step_case(name, N, M, ks, Hd, C, seed, edge=False, steps=3, lr=2e-3):
+    G = synth(N, M, max(ks), seed=seed + 1, missing=0.03)
+    rng = np.random.default_rng(seed + 2)
+    V0 = (rng.standard_normal((M, C)) / math.sqrt(M)).astype(np.float32)
+    S = sum(ks)
+    P0 = rng.uniform(0.02, 0.98, size=(S, M)).astype(np.float32)
+    if edge:
+        # exact zeros: r is exactly 0 whatever the summation order (robust); near-one values keep
+        # r < 1.  All-ones rows are NOT used: there r = sum_k q_k = 1 +- 1ulp depends on the GEMM's
+        # summation order, so the reference's own result is not reproducible to rounding; the
+        # saturated elementwise semantics are pinned separately by case_bce_elementwise().
+        P0[:, :40] = 0.0
+        P0[:, 40:60] = rng.uniform(0.999, 1.0, size=(S, 20)).astype(np.float32)
+    out = dict(G=G, V0=V0, P0=P0, ks=np.asarray(ks), Hd=Hd, seed=seed, lr=lr)
+    with precision("hi"):
+        torch.manual_seed(seed)
+        model = Q_P(Hd, C, V=torch.tensor(V0), P=torch.tensor(P0), ks_list=list(ks))
+        out.update(flat_state("init_", state_np(model)))
+        opt = model.create_custom_adam(device=torch.device("cpu"), lr=lr)
+        loss_fn = torch.nn.BCELoss(reduction="sum")
+        Gt = torch.tensor(G)
+        for s in range(steps):
+            opt.zero_grad(set_to_none=True)
+            (recs, probs), X = model(Gt)
+            loss = sum(loss_fn(rec, X) for rec in recs)
+            loss.backward()
+            out[f"loss{s}"] = np.float64(loss.item())
+            if s == 0:
+                with torch.no_grad():
+                    Xf = Gt.float() / 2
+                    Xf = torch.where(Xf == 1.5, 0.0, Xf)
+                    out["Z0"] = (Xf @ model.V).numpy().copy()
+                for h, q in enumerate(probs):
+                    out[f"Q0_{h}"] = q.detach().numpy().copy()
+                out.update({f"grad0_{k.replace('.', '_')}": v for k, v in grads_np(model).items()})
+            opt.step()
+            model.restrict_P()
+            out.update(flat_state(f"after{s}_", state_np(model)))
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    print(name, "losses", [out[f"loss{s}"] for s in range(steps)])
+
+
+def run_reference_training(G, V_MC, P_SM, K, min_k, max_k, Hd, epochs, batch, lr, seed, mode):
+    """launch_training on CPU (num_gpus=0), recording each step's loss."""
+    N, M = G.shape
+    with precision(mode):
+        torch.manual_seed(seed)
+        na = NeuralAdmixture(K, epochs, batch, lr, torch.device("cpu"), seed, 0, True, None, min_k, max_k)
+        step_losses = []
+        orig = na._run_step
+
+        def wrapped(x):
+            loss = orig(x)
+            step_losses.append(float(loss.item()))
+            return loss
+        na._run_step = wrapped
+        Qs, Ps, model = na.launch_training(torch.tensor(P_SM.copy()), torch.tensor(G), Hd, V_MC.shape[1],
+                                           torch.tensor(V_MC.copy()), M, N, None)
+        sd = state_np(model)
+    return Qs, Ps, sd, np.asarray(step_losses)
+
+
+def case_demo():
+    """c1: bundled demo BED, K=3, batch 800 (> N: one step per epoch), 5 and 25 epochs."""
+    seed, K, Hd, C, lr = 42, 3, 1024, 8, 2e-3
+    ref_utils.set_seed(seed)
+    bed = "/root/reference/demo/data/demo_data.bed"
+    data, _, N, M = ref_utils.read_data(bed)
+    Vt = RSVD(data, N, M, C, seed)                                   # [C,M]
+    # GMM init exactly as train.py:49-63 does it
+    from sklearn.mixture import GaussianMixture
+    X_pca = (data.astype(np.float32) / 2 @ Vt.T).astype("float64")
+    gmm = GaussianMixture(n_components=K, n_init=5, init_params="k-means++", tol=1e-4,
+                          covariance_type="full", max_iter=100, random_state=seed).fit(X_pca)
+    P_SM = np.clip(gmm.means_ @ Vt, 5e-6, 1 - 5e-6).astype(np.float32)
+    V_MC = np.ascontiguousarray(Vt.T.astype(np.float32))
+    raw_bed = np.fromfile(bed, dtype=np.uint8)
+    out = dict(bed_bytes=raw_bed, N=N, M=M, G_packed=pack_rule(data), Vt=Vt.astype(np.float32), P_init=P_SM,
+               gmm_means=gmm.means_, seed=seed, K=K, Hd=Hd, lr=lr)
+    for mode in ("hi", "med"):
+        for ep in (5, 25):
+            Qs, Ps, sd, sl = run_reference_training(data, V_MC, P_SM, K, None, None, Hd, ep, 800, lr, seed, mode)
+            out[f"{mode}_e{ep}_Q"] = Qs[0]
+            out[f"{mode}_e{ep}_P"] = Ps[0]
+            out[f"{mode}_e{ep}_losses"] = sl
+            if ep == 5:
+                out[f"{mode}_e{ep}_V"] = sd["V"]
+                out.update(flat_state(f"{mode}_e5_sd_", {k: v for k, v in sd.items()
+                                                          if not k.startswith("decoders") and k != "V"}))
+                P64 = np.ascontiguousarray(Ps[0].astype(np.float64))
+                Q64 = np.ascontiguousarray(Qs[0].astype(np.float64))
+                out[f"{mode}_e5_loglik"] = np.float64(ref_cy.loglikelihood(data, P64, Q64, K))
+                out[f"{mode}_e5_fst"] = np.asarray([[NeuralAdmixture._hudsons_fst(torch.tensor(Ps[0][:, a]), torch.tensor(Ps[0][:, b_]))
+                                                     if b_ < a else 0.0 for b_ in range(K)] for a in range(K)])
+            print("demo", mode, ep, "loss0", sl[0], "lossN", sl[-1])
+    np.savez_compressed(os.path.join(OUT, "demo_k3.npz"), **out)
+
+
+def case_multibatch():
+    """c4-shaped miniature: N=1000, M=2048, K=8, b=400 (steps 400,400,200), 3 epochs."""
+    N, M, K, Hd, C, b, ep, seed, lr = 1000, 2048, 8, 1024, 8, 400, 3, 42, 2e-3
+    G = synth(N, M, K, seed=1234)
+    rng = np.random.default_rng(5)
+    V_MC = (rng.standard_normal((M, C)) / math.sqrt(M)).astype(np.float32)
+    P_SM = rng.uniform(0.05, 0.95, size=(K, M)).astype(np.float32)
+    out = dict(G_packed=pack_rule(G), N=N, M=M, K=K, Hd=Hd, b=b, epochs=ep, seed=seed, lr=lr, V0=V_MC, P0=P_SM)
+    g = torch.Generator().manual_seed(seed)
+    sampler = torch.utils.data.RandomSampler(range(N), generator=g)
+    out["orders"] = np.asarray([list(iter(sampler)) for _ in range(ep)], dtype=np.int64)
+    for mode in ("hi", "med"):
+        Qs, Ps, sd, sl = run_reference_training(G, V_MC, P_SM, K, None, None, Hd, ep, b, lr, seed, mode)
+        out[f"{mode}_Q"], out[f"{mode}_P"], out[f"{mode}_V"], out[f"{mode}_losses"] = Qs[0], Ps[0], sd["V"], sl
+        print("multibatch", mode, sl[:3], sl[-1])
+    np.savez_compressed(os.path.join(OUT, "multibatch_k8.npz"), **out)
+
+
+def case_multihead_run():
+    """c3-shaped miniature: ks=2..5, N=300, M=1531 (not a multiple of 4), b=128, 2 epochs."""
+    N, M, Hd, C, b, ep, seed, lr = 300, 1531, 256, 8, 128, 2, 7, 2e-3
+    mn, mx = 2, 5
+    ks = list(range(mn, mx + 1))
+    G = synth(N, M, 4, seed=99, missing=0.02)
+    rng = np.random.default_rng(6)
+    V_MC = (rng.standard_normal((M, C)) / math.sqrt(M)).astype(np.float32)
+    P_SM = rng.uniform(0.05, 0.95, size=(sum(ks), M)).astype(np.float32)
+    out = dict(G_packed=pack_rule(G), N=N, M=M, ks=np.asarray(ks), Hd=Hd, b=b, epochs=ep, seed=seed, lr=lr, V0=V_MC, P0=P_SM)
+    Qs, Ps, sd, sl = run_reference_training(G, V_MC, P_SM, None, mn, mx, Hd, ep, b, lr, seed, "hi")
+    for h in range(len(ks)):
+        out[f"hi_Q{h}"], out[f"hi_P{h}"] = Qs[h], Ps[h]
+    out["hi_V"], out["hi_losses"] = sd["V"], sl
+    print("multihead", sl[:2], sl[-1])
+    np.savez_compressed(os.path.join(OUT, "multihead_run.npz"), **out)
+
+
+def case_ddp(world=2):
+    """DDP emulation on CPU (NCCL cannot run here): one shared model, per-rank batches from
+    torch's DistributedSampler(shuffle=True, seed) with set_epoch never called (loaders.py:27),
+    per-rank batch = batch_size//world (neural_admixture.py:287), gradients averaged (DDP mean)."""
+    from torch.utils.data.distributed import DistributedSampler
+    N, M, K, Hd, C, batch, ep, seed, lr = 203, 1024, 4, 128, 8, 64, 2, 11, 2e-3
+    G = synth(N, M, K, seed=321)
+    rng = np.random.default_rng(8)
+    V_MC = (rng.standard_normal((M, C)) / math.sqrt(M)).astype(np.float32)
+    P_SM = rng.uniform(0.05, 0.95, size=(K, M)).astype(np.float32)
+    b_local = batch // world
+    with precision("hi"):
+        torch.manual_seed(seed)
+        model = Q_P(Hd, C, V=torch.tensor(V_MC.copy()), P=torch.tensor(P_SM.copy()), ks_list=[K])
+        opt = model.create_custom_adam(device=torch.device("cpu"), lr=lr)
+        loss_fn = torch.nn.BCELoss(reduction="sum")
+        Gt = torch.tensor(G)
+        samplers = [DistributedSampler(range(N), num_replicas=world, rank=r, shuffle=True, seed=seed) for r in range(world)]
+        rank_orders, losses0 = [], []
+        for e in range(ep):
+            idx = [list(iter(s)) for s in samplers]
+            if e == 0:
+                rank_orders = np.asarray(idx, dtype=np.int64)
+            nsteps = math.ceil(len(idx[0]) / b_local)
+            for s in range(nsteps):
+                acc = None
+                for r in range(world):
+                    bi = idx[r][s * b_local:(s + 1) * b_local]
+                    opt.zero_grad(set_to_none=True)
+                    (recs, _), X = model(Gt[bi])
+                    loss = sum(loss_fn(rec, X) for rec in recs)
+                    loss.backward()
+                    if r == 0:
+                        losses0.append(float(loss.item()))
+                    gr = [p.grad.detach().clone() for p in model.parameters()]
+                    acc = gr if acc is None else [a + g_ for a, g_ in zip(acc, gr)]
+                for p, a in zip(model.parameters(), acc):
+                    p.grad = a / world
+                opt.step()
+                model.restrict_P()
+        with torch.no_grad():
+            model.return_func = model._return_infer
+            probs, _ = model(Gt)
+        sd = state_np(model)
+    np.savez_compressed(os.path.join(OUT, f"ddp_w{world}.npz"), G_packed=pack_rule(G), N=N, M=M, K=K, Hd=Hd, batch=batch,
+                        epochs=ep, seed=seed, lr=lr, world=world, V0=V_MC, P0=P_SM, rank_orders=rank_orders,
+                        losses_rank0=np.asarray(losses0), Q=probs[0].numpy(), P=sd["decoders.decoders.0.weight"], V=sd["V"])
+    print("ddp", world, losses0[:2], losses0[-1])
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    case_pack()
+    case_bce_elementwise()
+    one_step_case("one_step_k3", 64, 509, [3], 64, 8, seed=3)
+    one_step_case("one_step_multihead", 64, 509, [2, 3, 4], 64, 8, seed=4)
+    one_step_case("one_step_k8_h1024", 48, 777, [8], 1024, 8, seed=5)
+    one_step_case("one_step_edge", 64, 509, [3], 64, 8, seed=6, edge=True)
+    case_multibatch()
+    case_multihead_run()
+    case_ddp(2)
+    case_demo()
+    print("done ->", OUT)

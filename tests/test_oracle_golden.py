@@ -1,0 +1,140 @@
+"""Pin the CPU oracle (oracle/nadm_oracle.py) against every golden fixture captured from the
+reference (tests/golden/make_golden.py).  Tolerances are fp32-rounding class: the fixtures are the
+reference forced to true-fp32 matmuls ("hi"); the "med" variants (the reference's own bf16 path)
+are only used to show how far the reference is from itself."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import nadm_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def mx(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+def rel(a, b):
+    return mx(a, b) / (float(np.abs(b).max()) + 1e-30)
+
+
+def test_pack_layout():
+    d = np.load(f"{G}/pack_layout.npz")
+    assert np.array_equal(O.pack2bit(d["G"]), d["packed"])
+    assert np.array_equal(O.pack2bit(d["G_hibits"]), d["packed_hibits"])       # &3 masking
+    assert np.array_equal(O.unpack2bit(d["packed"], d["G"].shape[1]), d["G"])
+    # empty / ragged
+    assert O.pack2bit(np.zeros((0, 5), np.uint8)).shape == (0, 2)
+    assert O.pack2bit(np.zeros((3, 0), np.uint8)).shape == (3, 0)
+
+
+def test_bce_elementwise_semantics():
+    """-100 log clamp, 1e-12 denominator, inclusive mask on the pre-clamp value."""
+    d = np.load(f"{G}/bce_elementwise.npz")
+    r_raw, x = d["r_raw"], d["x"]
+    R = np.clip(r_raw, np.float32(0), np.float32(1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        loss = -(x * np.maximum(np.log(R), O.LOG_CLAMP) + (1 - x) * np.maximum(np.log1p(-R), O.LOG_CLAMP))
+        grad = (R - x) / np.maximum((1 - R) * R, O.BCE_EPS)
+    grad[(r_raw < 0) | (r_raw > 1)] = 0
+    assert np.allclose(loss, d["loss"], rtol=2e-6, atol=1e-30)
+    assert np.allclose(grad, d["grad"], rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("name", ["one_step_k3", "one_step_multihead", "one_step_k8_h1024", "one_step_edge"])
+def test_one_step(name):
+    d = np.load(f"{G}/{name}.npz")
+    ks = [int(k) for k in d["ks"]]
+    p = O.make_params(int(d["seed"]), d["V0"], d["P0"], int(d["Hd"]), ks)
+    # initial weights: same torch RNG stream as the reference's module construction
+    assert mx(p.W1, d["init_common_encoder_0_weight"]) == 0
+    assert mx(p.b1, d["init_common_encoder_0_bias"]) == 0
+    for h in range(len(ks)):
+        assert mx(p.Wk[h], d[f"init_multihead_encoder_heads_{h}_weight"]) == 0
+        assert mx(p.bk[h], d[f"init_multihead_encoder_heads_{h}_bias"]) == 0
+    edge = name.endswith("edge")
+    gtol = 3e-3 if edge else 1e-5      # edge: r within 1e-3 of 1 amplifies GEMM rounding ~1e4x
+    opt = O.Adam(p, float(d["lr"]))
+    for s in range(3):
+        loss, grads, aux = O.step_grads(p, d["G"])
+        assert abs(loss - float(d[f"loss{s}"])) / float(d[f"loss{s}"]) < 2e-6
+        if s == 0:
+            assert mx(aux["Z"], d["Z0"]) < 2e-6
+            for h in range(len(ks)):
+                assert mx(aux["Qs"][h], d[f"Q0_{h}"]) < 1e-6
+                assert rel(grads[f"P{h}"], d[f"grad0_decoders_decoders_{h}_weight"]) < 1e-5
+                assert rel(grads[f"Wk{h}"], d[f"grad0_multihead_encoder_heads_{h}_weight"]) < gtol
+                assert rel(grads[f"bk{h}"], d[f"grad0_multihead_encoder_heads_{h}_bias"]) < gtol
+            assert rel(grads["V"], d["grad0_V"]) < gtol
+            assert rel(grads["g"], d["grad0_batch_norm_weight"]) < gtol
+            assert rel(grads["W1"], d["grad0_common_encoder_0_weight"]) < gtol
+            assert rel(grads["b1"], d["grad0_common_encoder_0_bias"]) < gtol
+        opt.step(p, grads)
+        if not edge:                   # Adam's first steps are sign-like: ill-conditioned on edge
+            assert mx(p.V, d[f"after{s}_V"]) < 2e-6
+            assert mx(p.W1, d[f"after{s}_common_encoder_0_weight"]) < 2e-6
+            assert mx(p.g, d[f"after{s}_batch_norm_weight"]) < 2e-6
+        for h in range(len(ks)):
+            tol = 5e-5 if edge else 1e-6
+            assert mx(p.P[h], d[f"after{s}_decoders_decoders_{h}_weight"]) < tol
+
+
+def test_multibatch_trajectory_and_batch_order():
+    d = np.load(f"{G}/multibatch_k8.npz")
+    Gm = O.unpack2bit(d["G_packed"], int(d["M"]))
+    p = O.make_params(int(d["seed"]), d["V0"], d["P0"], int(d["Hd"]), [int(d["K"])])
+    orders = []
+    p, Qs, losses = O.train_run(Gm, p, int(d["epochs"]), int(d["b"]), float(d["lr"]), int(d["seed"]), record_orders=orders)
+    assert np.array_equal(np.asarray(orders), d["orders"])           # RandomSampler two-draw rule
+    assert mx(Qs[0], d["hi_Q"]) < 5e-4
+    assert mx(p.P[0], d["hi_P"]) < 5e-5
+    assert mx(p.V, d["hi_V"]) < 5e-4
+    ref = d["hi_losses"].reshape(int(d["epochs"]), -1).sum(1)
+    assert np.allclose(losses, ref, rtol=1e-6)
+    # the reference's own bf16 ('medium') run is much further from its fp32 run than the oracle is
+    assert mx(d["med_Q"], d["hi_Q"]) > 10 * mx(Qs[0], d["hi_Q"])
+
+
+def test_multihead_trajectory():
+    d = np.load(f"{G}/multihead_run.npz")
+    ks = [int(k) for k in d["ks"]]
+    Gm = O.unpack2bit(d["G_packed"], int(d["M"]))
+    p = O.make_params(int(d["seed"]), d["V0"], d["P0"], int(d["Hd"]), ks)
+    p, Qs, losses = O.train_run(Gm, p, int(d["epochs"]), int(d["b"]), float(d["lr"]), int(d["seed"]))
+    for h in range(len(ks)):
+        assert mx(Qs[h], d[f"hi_Q{h}"]) < 1e-4
+        assert mx(p.P[h], d[f"hi_P{h}"]) < 1e-5
+    assert mx(p.V, d["hi_V"]) < 1e-4
+    assert np.allclose(losses, d["hi_losses"].reshape(int(d["epochs"]), -1).sum(1), rtol=1e-6)
+
+
+def test_ddp_emulation_world2():
+    d = np.load(f"{G}/ddp_w2.npz")
+    Gm = O.unpack2bit(d["G_packed"], int(d["M"]))
+    p = O.make_params(int(d["seed"]), d["V0"], d["P0"], int(d["Hd"]), [int(d["K"])])
+    orders = []
+    p, Qs, losses = O.train_run(Gm, p, int(d["epochs"]), int(d["batch"]), float(d["lr"]), int(d["seed"]), world=2,
+                                record_orders=orders)
+    eo = O.EpochOrder(int(d["N"]), int(d["seed"]), 2)
+    for r in range(2):
+        assert np.array_equal(eo.rank_indices(orders[0], r), d["rank_orders"][r])   # DistributedSampler shard
+    assert mx(Qs[0], d["Q"]) < 1e-4 and mx(p.P[0], d["P"]) < 1e-5 and mx(p.V, d["V"]) < 1e-4
+    assert np.allclose(losses, d["losses_rank0"].reshape(int(d["epochs"]), -1).sum(1), rtol=1e-6)
+
+
+@pytest.mark.parametrize("ep", [5, 25])
+def test_demo_c1(ep):
+    d = np.load(f"{G}/demo_k3.npz")
+    Gm = O.unpack2bit(d["G_packed"], int(d["M"]))
+    p = O.make_params(int(d["seed"]), d["Vt"].T, d["P_init"], int(d["Hd"]), [3])
+    p, Qs, losses = O.train_run(Gm, p, ep, 800, float(d["lr"]), int(d["seed"]))
+    assert mx(Qs[0], d[f"hi_e{ep}_Q"]) < 1e-4
+    assert mx(p.P[0], d[f"hi_e{ep}_P"]) < 1e-5
+    assert np.allclose(losses, d[f"hi_e{ep}_losses"], rtol=1e-6)
+    if ep == 5:
+        assert mx(p.V, d["hi_e5_V"]) < 1e-5
+        ll = O.loglikelihood(Gm, p.P[0], Qs[0])
+        assert abs(ll - float(d["hi_e5_loglik"])) / abs(float(d["hi_e5_loglik"])) < 1e-7
+        assert abs(O.hudson_fst(p.P[0][:, 1], p.P[0][:, 0]) - d["hi_e5_fst"][1, 0]) < 1e-5
