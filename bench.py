@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: genotypes/s (samples x SNPs per second of training) at K=8.
+
+A "step" is one training step of the hot path on one batch: gather 800 rows of the 2-bit packed
+matrix, encoder X.V, RMSNorm+MLP+softmax, decoder Q.P^T + clamp + BCE forward/backward (loss value
+included), MLP backward, dV = X^T.dZ, gradient all-reduce (N>1), Adam on every parameter, P clamp.
+Workload (BASELINE.json configs[3]): synthetic 100k samples x 500k SNPs, K=8, resident 2-bit packed
+in HBM (12.5 GB; sharded by samples over ranks), batch 800 PER GPU (weak scaling: the reference's
+global-batch-800 semantics would leave 100 rows per GPU at N=8).
+
+    python bench.py --gpus 1 --steps 100 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows", type=int, default=100_000, help="total samples N (sharded over ranks)")
+    ap.add_argument("--snps", type=int, default=500_000)
+    ap.add_argument("--k", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=800, help="rows per step PER GPU")
+    ap.add_argument("--hidden", type=int, default=1024)
+    ap.add_argument("--no-loss", action="store_true", help="skip the loss value (gradients unchanged); default computes it every step like the reference")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=2400, help="rows of the same workload used for the bounded CPU baseline")
+    return ap.parse_args()
+
+
+def make_dataset(eng, rows_local, row0, K, dev, seed=1234):
+    """Admixture-model synthetic genotypes generated on the device straight into packed bytes."""
+    from neural_admixture_amd._lib import lib, check, ptr
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    beta = torch.distributions.Beta(torch.tensor(0.5), torch.tensor(0.5))
+    torch.manual_seed(seed)
+    Fq = (0.5 * beta.sample((K, eng.M))).clamp(0.005, 0.5).float().to(dev)           # same on every rank
+    xp = torch.empty((rows_local, eng.ld), dtype=torch.uint8, device=dev)
+    dirich = torch.distributions.Dirichlet(torch.full((K,), 0.2))
+    chunk = 16384
+    for s in range(0, rows_local, chunk):
+        n = min(chunk, rows_local - s)
+        torch.manual_seed(seed + 1 + (row0 + s) // chunk)
+        Qt = dirich.sample((n,)).float().to(dev)
+        check(lib.nadm_synth_packed(ptr(xp[s:]), n, row0 + s, eng.M, eng.ld, ptr(Qt), ptr(Fq), K, 0.01, seed, None), "synth")
+    torch.cuda.synchronize()
+    del g
+    return xp
+
+
+def cpu_baseline(eng, args, dev):
+    """The C port of the step (oracle/nadm_oracle_c.c, OpenMP) on a bounded row sample of the same matrix."""
+    from neural_admixture_amd._lib import lib, check, ptr
+    from oracle.c_port import CPort
+    L = eng.lay
+    n = min(args.cpu_rows, eng.xp.shape[0])
+    b = min(args.batch, n)
+    Gd = torch.empty((n, L.M), dtype=torch.uint8, device=dev)
+    check(lib.nadm_unpack2bit(ptr(eng.xp), ptr(Gd), n, L.M, eng.ld, None), "unpack")
+    G = Gd.cpu().numpy()
+    del Gd
+    sm = eng.small.cpu().numpy()
+    h = L.heads
+    K = L.ks[0]
+    cp = CPort(eng.V().cpu().numpy(), eng.P(0).cpu().numpy(), sm[h.g_off:h.g_off + L.C], sm[h.w1_off:h.w1_off + L.Hd * L.C].reshape(L.Hd, L.C),
+               sm[h.b1_off:h.b1_off + L.Hd], sm[h.wk_off[0]:h.wk_off[0] + K * L.Hd].reshape(K, L.Hd), sm[h.bk_off[0]:h.bk_off[0] + K])
+    idx = np.arange(n)
+    cp.step(G, idx[:b], 2e-3)                      # warm-up step (page-in, thread pool)
+    nsteps = max(1, n // b)
+    t0 = time.perf_counter()
+    for s in range(nsteps):
+        cp.step(G, idx[s * b:(s + 1) * b], 2e-3)
+    dt = time.perf_counter() - t0
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": nsteps * b * L.M / dt, "unit": "genotypes/s", "cores": cp.threads(), "kind": "port",
+            "sample": f"{nsteps} steps of {b} rows x {L.M} SNPs (first {n} rows of the same matrix), fused C/OpenMP port of the step, cpu={model}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    import neural_admixture_amd as na
+    from neural_admixture_amd.model import init_encoder_weights
+
+    M, K, b = args.snps, args.k, args.batch
+    rows_local = args.rows // world
+    eng = na.Engine(M, 8, args.hidden, [K], dev, b)
+    eng.set_packed(make_dataset(eng, rows_local, rank * rows_local, K, dev))
+    rng = np.random.default_rng(42)                                     # identical parameters on every rank
+    V0 = (0.01 * rng.standard_normal((M, 8))).astype(np.float32)
+    P0 = rng.uniform(5e-6, 1 - 5e-6, size=(K, M)).astype(np.float32)
+    eng.load_params(V0, P0, init_encoder_weights(42, 8, args.hidden, [K]))
+    del V0, P0
+    gperm = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    perm = torch.randperm(rows_local, generator=gperm).to(torch.int32).to(dev)
+    nb = rows_local // b
+    with_loss = not args.no_loss
+    lr = 2e-3
+
+    def step(s):
+        o = (s % nb) * b
+        if world > 1:
+            eng.train_step_ddp(perm[o:o + b], b, lr, world, with_loss)
+        else:
+            eng.train_step(perm[o:o + b], b, lr, with_loss)
+
+    for s in range(args.warmup):
+        step(s)
+    eng.timers = {}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step(args.warmup + s)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    timers, eng.timers = eng.timers, None
+    loss_sum, loss_last = eng.read_loss()
+    assert np.isfinite(loss_last) or not with_loss
+
+    kms = {name: float(np.mean([a.elapsed_time(c) for a, c in evs])) for name, evs in timers.items()}
+    # dominant kernel = decode_bce.  Algorithmic bytes per launch: one 2-bit pass over the
+    # batch (b*M/4) + read P and write dP once (2 * 4*M*K).
+    dom = "decode_bce"
+    alg_bytes = b * M / 4 + 2 * 4 * M * K
+    achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
+    step_bytes = b * M * (0.75 + 36.0 * (8 + K) / b)                     # SURVEY.md 8d whole-step figure
+    out = {
+        "metric": "genotypes/sec (samples x SNPs / epoch-sec) at K=%d" % K,
+        "value": world * b * M * args.steps / dt, "unit": "genotypes/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[3]: synthetic {args.rows} samples x {M} SNPs, K={K}, 2-bit packed resident in HBM, "
+                               f"sample-sharded over {world} GPU(s), batch {b}/GPU, hidden {args.hidden}, n_components 8, "
+                               f"loss value {'every step' if with_loss else 'skipped'}",
+                   "global_batch": b * world, "parallelism": f"dp{world}"},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel_ms": kms, "alg_bytes_per_launch": alg_bytes,
+                     "whole_step": {"alg_bytes": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
+                                    "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}},
+        "loss_last_step": loss_last,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(eng, args, dev)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,135 @@
+/*
+ * nadm.h -- C ABI of the MI355X-native Neural ADMIXTURE training engine (libnadm.so).
+ *
+ * This is the drop-in boundary for the reference's hot path.  Every entry point names the
+ * reference interface it replaces (paths relative to the reference repo).  Conventions:
+ *   - plain pointers and sizes only; no torch / ATen types.
+ *   - every device pointer is CALLER-OWNED (the reference's contract too: the caller allocates
+ *     both tensors of pack2bit_cpu_to_gpu / unpack2bit_gpu_to_gpu, train.py:121,
+ *     neural_admixture.py:377,405); the library never allocates or frees device memory.
+ *   - every call is ASYNCHRONOUS on the hipStream_t passed as `stream` (void*; 0 = null stream)
+ *     unless stated otherwise.  (The reference's extension blocks with cudaDeviceSynchronize on the
+ *     legacy default stream, pack2bit.cu:115,141; callers that want that behaviour synchronise.)
+ *   - return value: 0 = ok, nonzero = error; nadm_last_error() returns a thread-local message
+ *     (the reference raises RuntimeError through TORCH_CHECK, pack2bit.cu:67-76,121-130; the
+ *     Python host mirror turns nonzero statuses into RuntimeError).
+ *   - one host thread per process/GPU, not re-entrant per stream (same as the reference).
+ *
+ * Device data layout (all float32 unless noted):
+ *   xp     uint8 [rows, ld]   2-bit packed genotypes, sample-major, SNP 4c+i in bits [2i,2i+1] of
+ *                             byte c (pack2bit.cu:26-31); ld >= ceil(M/4), ld % 16 == 0, pad bytes 0.
+ *   V      [M, CP]            encoder projection, CP = C rounded up to a multiple of 4, pad cols 0
+ *                             (reference: Q_P.V [M,C], neural_admixture.py:129-130).
+ *   P_h    [M, KP_h]          decoder head h, SNP-major, KP_h = padded K (nadm_pad_k), pad cols 0
+ *                             (reference: decoders[h].weight, logical [M,k], neural_admixture.py:73-74).
+ *   small  flat               g[C] | W1[Hd,C] | b1[Hd] | for h: Wk_h[k_h,Hd] | bk_h[k_h]
+ *                             (batch_norm.weight, common_encoder.0.{weight,bias},
+ *                              multihead_encoder.heads.h.{weight,bias}).
+ *   Q      [b, SP]            per-head softmax outputs; head h occupies columns
+ *                             [qoff_h, qoff_h + k_h), SP = sum KP_h; pad cols 0.
+ */
+#ifndef NADM_H
+#define NADM_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NADM_MAX_HEADS 32
+#define NADM_MAX_K 64
+#define NADM_ABI_VERSION 1
+
+/* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
+ * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
+typedef struct nadm_heads {
+    int32_t n_heads;
+    int32_t C;              /* n_components (true) */
+    int32_t CP;             /* padded */
+    int32_t Hd;             /* hidden size */
+    int32_t SP;             /* sum of padded K = row length of Q / dQ */
+    int32_t n_small;        /* number of floats in the small flat buffer */
+    int32_t k[NADM_MAX_HEADS];
+    int32_t kp[NADM_MAX_HEADS];
+    int32_t qoff[NADM_MAX_HEADS];
+    int32_t wk_off[NADM_MAX_HEADS];
+    int32_t bk_off[NADM_MAX_HEADS];
+    int32_t g_off, w1_off, b1_off;
+} nadm_heads_t;
+
+/* ---- introspection ------------------------------------------------------------------- */
+int         nadm_abi_version(void);
+const char* nadm_last_error(void);
+/* Padded widths used by the kernels: multiple of 4 up to 16, then {24,32,48,64}. <=0 if unsupported. */
+int         nadm_pad_k(int k);
+/* Fill a head table from (C, Hd, ks[n]) -- the layout every other call assumes. */
+int         nadm_heads_init(nadm_heads_t* out, int C, int Hd, const int32_t* ks, int n);
+/* Number of SNP chunks (= rows of partial buffers) the three genotype passes use for M SNPs. */
+int64_t     nadm_encode_chunks(int64_t M);      /* zpart  is [chunks, b, CP]  */
+int64_t     nadm_decode_chunks(int64_t M, int kp); /* per head: dqpart slab [chunks, b, kp], losspart [chunks] */
+int32_t     nadm_sample_splits(int b);          /* small_part is [splits, n_small] */
+
+/* ---- a1/a2: packing  (replaces pack2bit.cu:10-36,65-117 and :38-62,120-142) ------------ */
+/* Host-side pack: g_host uint8 [N,M] (row stride M) -> out_host [N,ld].  Synchronous, OpenMP. */
+int nadm_pack2bit_host(const uint8_t* g_host, uint8_t* out_host, int64_t N, int64_t M, int64_t ld);
+/* Device pack kernel: g_dev uint8 [rows,M] unpacked on device -> out_dev [rows,ld] (pad bytes zeroed). */
+int nadm_pack2bit(const uint8_t* g_dev, uint8_t* out_dev, int64_t rows, int64_t M, int64_t ld, void* stream);
+/* Device unpack (test / interop only; the training kernels decode in registers):
+ * in_dev [rows,ld] -> out_dev uint8 [rows,M]. */
+int nadm_unpack2bit(const uint8_t* in_dev, uint8_t* out_dev, int64_t rows, int64_t M, int64_t ld, void* stream);
+
+/* ---- a4/a5: encoder projection  Z = X.V  (neural_admixture.py:169-172) ----------------- */
+/* rows idx[0..b) of xp are the batch (replaces Dataset_admixture.__getitem__ + collate,
+ * loaders.py:62-72, and the per-step unpack2bit_gpu_to_gpu, neural_admixture.py:404-406).
+ * Writes per-chunk partial sums zpart [nadm_encode_chunks(M), b, CP]; nadm_mlp_fwd reduces them. */
+int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                    const float* V, int32_t CP, float* zpart, void* stream);
+
+/* ---- a6-a8: RMSNorm + Linear/ReLU + per-head Linear + softmax (neural_admixture.py:173-176) */
+int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const float* zpart, int64_t n_chunks, int32_t b,
+                 float* Z, float* rinv, float* Zn, float* H, float* Q, void* stream);
+
+/* ---- a9-a11: decoder Q.P^T -> clamp -> BCE(sum) forward + backward, one head -------------
+ * (neural_admixture.py:94-97, :288/:431, autograd of both).  P,dP [M,kp]; Q = Qbase + qoff
+ * with row stride SP; dqpart = this head's slab [nadm_decode_chunks(M,kp), b, kp]; losspart
+ * [chunks] (written only if with_loss != 0).  Missing genotypes are x = 0 in input and target. */
+int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                    const float* P, int32_t kp, const float* Q, int32_t SP,
+                    float* dP, float* dqpart, float* losspart, int32_t with_loss, void* stream);
+
+/* ---- a11: MLP backward (softmax, Linear, ReLU, RMSNorm) ---------------------------------- */
+/* Reduces dqpart (the heads' slabs laid back to back in head order, head h holding
+ * nadm_decode_chunks(M,kp_h)*b*kp_h floats), writes dZ [b,CP], the flat small-parameter gradient
+ * grad_small [n_small], and when n_loss>0 adds the step's loss (sum of losspart[0..n_loss)) to
+ * loss_acc[0] (running sum) and stores it in loss_acc[1] (last step); loss_acc is double[2].
+ * Scratch: dL [b,SP], dHpre [b,Hd], dgp [b,CP], small_part [nadm_sample_splits(b), n_small]. */
+int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const float* dqpart, int64_t M, int32_t b,
+                 const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
+                 float* dL, float* dHpre, float* dgp, float* small_part,
+                 float* dZ, float* grad_small,
+                 const float* losspart, int64_t n_loss, double* loss_acc, void* stream);
+
+/* ---- a11: dV = X^T . dZ  (autograd of neural_admixture.py:172) --------------------------- */
+int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                    const float* dZ, int32_t CP, float* dV, void* stream);
+
+/* ---- a12/a13: Adam(betas .9/.95, eps 1e-8) + restrict_P (neural_admixture.py:187-204,411-412)
+ * Flat update of n floats; `step` is the 1-based step count; gradients are multiplied by
+ * grad_scale first (1/world for the DDP mean, neural_admixture.py:317); elements with index
+ * >= clamp_from are clamped to [0,1] after the update (pass n for "no clamp"). */
+int nadm_adam(float* param, const float* grad, float* m, float* v, int64_t n, int64_t clamp_from,
+              float lr, int32_t step, float grad_scale, void* stream);
+
+/* ---- measurement helpers ------------------------------------------------------------------ */
+/* Synthetic admixture-model genotypes written directly as packed bytes:
+ * G ~ Binomial(2, Qt.F), `missing` fraction set to 3.  Qt [rows,K], Fq [K,M] float32 on device;
+ * counter-based RNG keyed by (seed, row0 + r, SNP) so shards generated on different ranks agree. */
+int nadm_synth_packed(uint8_t* xp, int64_t rows, int64_t row0, int64_t M, int64_t ld,
+                      const float* Qt, const float* Fq, int32_t K, float missing, uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NADM_H */

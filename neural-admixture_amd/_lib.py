@@ -1,0 +1,70 @@
+"""ctypes binding of the C ABI declared in include/nadm.h (csrc/libnadm.so).
+
+There is no CPU fallback: if the shared library is missing or a call fails, a RuntimeError is
+raised (the reference raises RuntimeError through TORCH_CHECK, pack2bit.cu:67-76)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnadm.so")
+
+MAX_HEADS = 32
+
+
+class Heads(C.Structure):
+    """Mirror of ``nadm_heads_t``."""
+    _fields_ = [("n_heads", C.c_int32), ("C", C.c_int32), ("CP", C.c_int32), ("Hd", C.c_int32),
+                ("SP", C.c_int32), ("n_small", C.c_int32),
+                ("k", C.c_int32 * MAX_HEADS), ("kp", C.c_int32 * MAX_HEADS), ("qoff", C.c_int32 * MAX_HEADS),
+                ("wk_off", C.c_int32 * MAX_HEADS), ("bk_off", C.c_int32 * MAX_HEADS),
+                ("g_off", C.c_int32), ("w1_off", C.c_int32), ("b1_off", C.c_int32)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"neural_admixture_amd: {LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the training path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64
+    HP = C.POINTER(Heads)
+    sig = {
+        "nadm_abi_version": (C.c_int, []),
+        "nadm_last_error": (C.c_char_p, []),
+        "nadm_pad_k": (C.c_int, [C.c_int]),
+        "nadm_heads_init": (C.c_int, [HP, C.c_int, C.c_int, C.POINTER(i32), C.c_int]),
+        "nadm_encode_chunks": (i64, [i64]),
+        "nadm_decode_chunks": (i64, [i64, C.c_int]),
+        "nadm_sample_splits": (i32, [C.c_int]),
+        "nadm_pack2bit_host": (C.c_int, [vp, vp, i64, i64, i64]),
+        "nadm_pack2bit": (C.c_int, [vp, vp, i64, i64, i64, vp]),
+        "nadm_unpack2bit": (C.c_int, [vp, vp, i64, i64, i64, vp]),
+        "nadm_encode_fwd": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp]),
+        "nadm_mlp_fwd": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]),
+        "nadm_decode_bce": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
+        "nadm_mlp_bwd": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]),
+        "nadm_encode_bwd": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp]),
+        "nadm_adam": (C.c_int, [vp, vp, vp, vp, i64, i64, f32, i32, f32, vp]),
+        "nadm_synth_packed": (C.c_int, [vp, i64, i64, i64, i64, vp, vp, i32, f32, u64, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.nadm_abi_version() != 1:
+        raise RuntimeError("neural_admixture_amd: libnadm.so ABI version mismatch")
+    return lib, tuple(sig)
+
+
+lib, EXPORTS = _load()
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = lib.nadm_last_error()
+        raise RuntimeError(f"libnadm {what}: {msg.decode() if msg else 'error'} (status {status})")
+
+
+def ptr(t):
+    """Raw device/host pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Build libnadm.so (gfx950 only) next to this script.  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
+hipcc $FLAGS -c nadm_genotype_passes.hip -o nadm_genotype_passes.o "$@"
+hipcc $FLAGS -c nadm_small_kernels.hip -o nadm_small_kernels.o "$@"
+hipcc --offload-arch=gfx950 -shared -fPIC -o libnadm.so nadm_genotype_passes.o nadm_small_kernels.o -lpthread
+echo "built $(pwd)/libnadm.so"

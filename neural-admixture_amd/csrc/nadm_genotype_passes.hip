@@ -1,0 +1,432 @@
+// The three passes over the 2-bit packed genotype matrix (gfx950 / MI355X).
+//
+//   pass 1  encode_fwd   Z  = X . V            reduce over SNPs   (neural_admixture.py:169-172)
+//   pass 2  decode_bce   R  = clamp(Q.P^T), BCE(sum) loss, dP = dR^T.Q, dQ = dR.P
+//                                              (neural_admixture.py:94-97, :288/:431 + autograd)
+//   pass 3  encode_bwd   dV = X^T . dZ         reduce over samples (autograd of :172)
+//
+// The batch is gathered by row index (idx) straight out of the packed matrix; genotypes are decoded
+// in registers, never materialised (the reference unpacks to uint8 [b,M] and then to fp32 [b,M]
+// every step: pack2bit.cu:38-62, neural_admixture.py:404-406,169-170).
+//
+// All three kernels stream X tiles HBM -> LDS with 16-byte-per-lane coalesced loads of whole row
+// segments (>= 128 B contiguous per gathered row), software-prefetched one tile ahead.
+#include "nadm_common.h"
+#include "../../include/nadm.h"
+#include "nadm_host.h"
+
+namespace nadm {
+
+// =================================================================================================
+// pass 1: Z partial = X[:, chunk] . V[chunk, :]        lane <-> sample, V rows wave-uniform
+// =================================================================================================
+constexpr int ENC_TB = 128;            // bytes of each gathered row per tile  (512 SNPs)
+constexpr int ENC_TILES = 2;           // tiles per chunk -> 1024 SNPs per chunk
+constexpr int ENC_LDW = ENC_TB / 4 + 1;  // LDS row stride in dwords (+1: lane r reads row r -> conflict-free)
+constexpr int ENC_CHUNK_SNPS = ENC_TB * 4 * ENC_TILES;
+
+template <int CP>
+__global__ void encode_fwd_kernel(const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx,
+                                  int b, int64_t M, const float* __restrict__ V, float* __restrict__ zpart,
+                                  int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [rows_per_block][ENC_LDW]
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;                  // == rows_per_block
+    const int64_t chunk = blockIdx.x;
+    const int row0 = blockIdx.y * rows_per_block;
+    const int nrows = min(rows_per_block, b - row0);
+    const int my_row = row0 + tid;
+    constexpr int PPR = ENC_TB / 16;              // 16-byte pieces per row segment
+    constexpr int MAXP = 8;                       // pieces per thread per tile (rows*PPR/nthr == PPR)
+    static_assert(PPR == MAXP, "one row's worth of pieces per thread");
+
+    float acc[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) acc[c] = 0.f;
+
+    uint4 stage[MAXP];
+    auto issue = [&](int tile) {
+        const int64_t byte0 = (chunk * ENC_TILES + tile) * ENC_TB;
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+            const int piece = tid + p * nthr;       // consecutive lanes -> consecutive 16 B of one row
+            const int r = piece / PPR, c16 = piece % PPR;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const int64_t off = byte0 + c16 * 16;
+            if (r < nrows && off < ld) {
+                const int64_t row = idx[row0 + r];
+                v = *reinterpret_cast<const uint4*>(xp + row * ld + off);
+            }
+            stage[p] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+            const int piece = tid + p * nthr;
+            const int r = piece / PPR, c16 = piece % PPR;
+            uint32_t* d = lds + r * ENC_LDW + c16 * 4;
+            d[0] = stage[p].x; d[1] = stage[p].y; d[2] = stage[p].z; d[3] = stage[p].w;
+        }
+    };
+
+    issue(0);
+    for (int tile = 0; tile < ENC_TILES; ++tile) {
+        __syncthreads();                 // previous tile's readers are done
+        commit();
+        __syncthreads();
+        if (tile + 1 < ENC_TILES) issue(tile + 1);
+        const int64_t snp0 = (chunk * ENC_TILES + tile) * (ENC_TB * 4);
+        if (snp0 < M) {
+            const uint32_t* myrow = lds + tid * ENC_LDW;
+            const int nd = (int)min<int64_t>(ENC_TB / 4, (M - snp0 + 15) / 16);
+            for (int d = 0; d < nd; ++d) {
+                const uint32_t bits = myrow[d];
+                const float* vrow = V + (snp0 + d * 16) * CP;        // wave-uniform address
+                const int ns = (int)min<int64_t>(16, M - (snp0 + d * 16));
+                if (ns == 16) {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        const float x = decode_x((bits >> (2 * s)) & 3u);
+#pragma unroll
+                        for (int c = 0; c < CP; ++c) acc[c] = fmaf(x, vrow[s * CP + c], acc[c]);
+                    }
+                } else {
+                    for (int s = 0; s < ns; ++s) {
+                        const float x = decode_x((bits >> (2 * s)) & 3u);
+#pragma unroll
+                        for (int c = 0; c < CP; ++c) acc[c] = fmaf(x, vrow[s * CP + c], acc[c]);
+                    }
+                }
+            }
+        }
+    }
+    if (my_row < b) {
+        float* o = zpart + (chunk * b + my_row) * CP;
+#pragma unroll
+        for (int c = 0; c < CP; c += 4)
+            *reinterpret_cast<float4*>(o + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+    }
+}
+
+// =================================================================================================
+// X tile loader shared by passes 2 and 3: [TS rows] x [RB bytes] into LDS, 256 threads
+// =================================================================================================
+constexpr int TS = 32;   // samples per tile
+
+template <int RB>
+struct TileLoader {
+    static constexpr int PPR = RB / 16;                 // 16 B pieces per row
+    static constexpr int NP = (TS * PPR + 255) / 256;   // pieces per thread
+    uint4 stage[NP];
+    __device__ __forceinline__ void issue(const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx,
+                                          int i0, int b, int64_t byte0, int tid) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int piece = tid + p * 256;
+            const int r = piece / PPR, c16 = piece % PPR;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const int64_t off = byte0 + c16 * 16;
+            if (piece < TS * PPR && i0 + r < b && off < ld) {
+                const int64_t row = idx[i0 + r];
+                v = *reinterpret_cast<const uint4*>(xp + row * ld + off);
+            }
+            stage[p] = v;
+        }
+    }
+    __device__ __forceinline__ void commit(uint8_t* buf, int tid) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int piece = tid + p * 256;
+            if (piece < TS * PPR) *reinterpret_cast<uint4*>(buf + piece * 16) = stage[p];   // row-major [TS][RB]
+        }
+    }
+};
+
+// =================================================================================================
+// pass 2: decoder + BCE forward/backward for one head.   lane <-> SPL consecutive SNPs
+//   block = 256 threads = 4 waves, each wave owns 64*SPL SNPs and walks all b samples;
+//   dP stays in registers for the whole block (written once), dQ partials are reduced over the
+//   wave (DPP) per sample, over the 4 waves through LDS per 32-sample tile, and written as one
+//   [b, KP] slab per chunk (row stride KP; deterministic; reduced over chunks by mlp_bwd).
+// =================================================================================================
+template <int KP, int SPL, bool LOSS>
+__global__ __launch_bounds__(256) void decode_bce_kernel(
+    const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
+    const float* __restrict__ P, const float* __restrict__ Q, int SP,
+    float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart) {
+    constexpr int RB = 256 * SPL / 4;                    // bytes of each row per tile
+    __shared__ __attribute__((aligned(16))) uint8_t s_x[2][TS * RB];
+    __shared__ __attribute__((aligned(16))) float s_q[2][TS * KP];
+    __shared__ __attribute__((aligned(16))) float s_t[4][TS * KP];
+    __shared__ float s_loss[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t chunk = blockIdx.x;
+    const int64_t byte0 = chunk * RB;
+    const int64_t m0 = (chunk * 256 + tid) * SPL;
+
+    float p[SPL][KP], dp[SPL][KP];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        const bool ok = (m0 + j) < M;
+#pragma unroll
+        for (int k = 0; k < KP; k += 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) v = *reinterpret_cast<const float4*>(P + (m0 + j) * KP + k);
+            p[j][k] = v.x; p[j][k + 1] = v.y; p[j][k + 2] = v.z; p[j][k + 3] = v.w;
+            dp[j][k] = dp[j][k + 1] = dp[j][k + 2] = dp[j][k + 3] = 0.f;
+        }
+    }
+    float lossacc = 0.f;
+
+    TileLoader<RB> loader;
+    auto load_q = [&](int i0, int buf) {       // Q tile [TS][KP] -> LDS (coalesced)
+        for (int e = tid; e < TS * KP; e += 256) {
+            const int r = e / KP, k = e % KP;
+            s_q[buf][e] = (i0 + r < b) ? Q[(int64_t)(i0 + r) * SP + k] : 0.f;
+        }
+    };
+
+    const int ntiles = (b + TS - 1) / TS;
+    loader.issue(xp, ld, idx, 0, b, byte0, tid);
+    loader.commit(s_x[0], tid);
+    load_q(0, 0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        const int i0 = t * TS;
+        const int nt = min(TS, b - i0);
+        if (t + 1 < ntiles) loader.issue(xp, ld, idx, i0 + TS, b, byte0, tid);
+
+        for (int ii = 0; ii < nt; ++ii) {
+            uint32_t bits;
+            if constexpr (SPL == 8) bits = *reinterpret_cast<const uint16_t*>(&s_x[cur][ii * RB + tid * 2]);
+            else bits = (uint32_t)s_x[cur][ii * RB + (tid * SPL) / 4] >> (((tid * SPL) & 3) * 2);
+            float q[KP], tq[KP];
+#pragma unroll
+            for (int k = 0; k < KP; k += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(&s_q[cur][ii * KP + k]);   // LDS broadcast
+                q[k] = v.x; q[k + 1] = v.y; q[k + 2] = v.z; q[k + 3] = v.w;
+                tq[k] = tq[k + 1] = tq[k + 2] = tq[k + 3] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) {
+                const float x = decode_x((bits >> (2 * j)) & 3u);
+                float rr = 0.f;
+#pragma unroll
+                for (int k = 0; k < KP; ++k) rr = fmaf(q[k], p[j][k], rr);
+                float r;
+                const float dR = bce_grad(rr, x, r);
+                if constexpr (LOSS) lossacc += bce_loss(r, x);
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    dp[j][k] = fmaf(dR, q[k], dp[j][k]);
+                    tq[k] = fmaf(dR, p[j][k], tq[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const float s = wave_sum_lane63(tq[k]);
+                if (lane == 63) s_t[wave][ii * KP + k] = s;
+            }
+        }
+        __syncthreads();                       // s_t complete; everyone done reading s_x[cur], s_q[cur]
+        for (int e = tid; e < nt * KP; e += 256) {
+            const float s = (s_t[0][e] + s_t[1][e]) + (s_t[2][e] + s_t[3][e]);
+            const int r = e / KP, k = e % KP;
+            dqpart[(chunk * b + i0 + r) * KP + k] = s;
+        }
+        if (t + 1 < ntiles) {
+            loader.commit(s_x[cur ^ 1], tid);
+            load_q(i0 + TS, cur ^ 1);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        if ((m0 + j) < M) {
+#pragma unroll
+            for (int k = 0; k < KP; k += 4)
+                *reinterpret_cast<float4*>(dP + (m0 + j) * KP + k) =
+                    make_float4(dp[j][k], dp[j][k + 1], dp[j][k + 2], dp[j][k + 3]);
+        }
+    }
+    if constexpr (LOSS) {
+        const float s = wave_sum_lane63(lossacc);
+        if (lane == 63) s_loss[wave] = s;
+        __syncthreads();
+        if (tid == 0) losspart[chunk] = (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]);
+    }
+}
+
+// =================================================================================================
+// pass 3: dV = X^T . dZ     lane <-> 4 consecutive SNPs (one packed byte), dZ rows via LDS broadcast
+// =================================================================================================
+template <int CP>
+__global__ __launch_bounds__(256) void encode_bwd_kernel(
+    const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
+    const float* __restrict__ dZ, float* __restrict__ dV) {
+    constexpr int SPL = 4;
+    constexpr int RB = 256;
+    __shared__ __attribute__((aligned(16))) uint8_t s_x[2][TS * RB];
+    __shared__ __attribute__((aligned(16))) float s_z[2][TS * CP];
+    const int tid = threadIdx.x;
+    const int64_t chunk = blockIdx.x;
+    const int64_t byte0 = chunk * RB;
+    const int64_t m0 = (chunk * 256 + tid) * SPL;
+
+    float acc[SPL][CP];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j)
+#pragma unroll
+        for (int c = 0; c < CP; ++c) acc[j][c] = 0.f;
+
+    TileLoader<RB> loader;
+    auto load_z = [&](int i0, int buf) {
+        for (int e = tid; e < TS * CP; e += 256) {
+            const int r = e / CP;
+            s_z[buf][e] = (i0 + r < b) ? dZ[(int64_t)i0 * CP + e] : 0.f;
+        }
+    };
+    const int ntiles = (b + TS - 1) / TS;
+    loader.issue(xp, ld, idx, 0, b, byte0, tid);
+    loader.commit(s_x[0], tid);
+    load_z(0, 0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        const int i0 = t * TS;
+        const int nt = min(TS, b - i0);
+        if (t + 1 < ntiles) loader.issue(xp, ld, idx, i0 + TS, b, byte0, tid);
+        for (int ii = 0; ii < nt; ++ii) {
+            const uint32_t bits = s_x[cur][ii * RB + tid];
+            float z[CP];
+#pragma unroll
+            for (int c = 0; c < CP; c += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(&s_z[cur][ii * CP + c]);
+                z[c] = v.x; z[c + 1] = v.y; z[c + 2] = v.z; z[c + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) {
+                const float x = decode_x((bits >> (2 * j)) & 3u);
+#pragma unroll
+                for (int c = 0; c < CP; ++c) acc[j][c] = fmaf(x, z[c], acc[j][c]);
+            }
+        }
+        if (t + 1 < ntiles) {
+            loader.commit(s_x[cur ^ 1], tid);
+            load_z(i0 + TS, cur ^ 1);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        if ((m0 + j) < M) {
+#pragma unroll
+            for (int c = 0; c < CP; c += 4)
+                *reinterpret_cast<float4*>(dV + (m0 + j) * CP + c) =
+                    make_float4(acc[j][c], acc[j][c + 1], acc[j][c + 2], acc[j][c + 3]);
+        }
+    }
+}
+
+// ---- SNPs per lane in pass 2 as a function of the padded head width (register budget ~128) ----
+constexpr int dec_spl(int kp) { return kp <= 8 ? 8 : (kp <= 16 ? 4 : (kp <= 32 ? 2 : 1)); }
+
+template <int KP>
+static int launch_decode(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, const float* P,
+                         const float* Q, int SP, float* dP, float* dqpart, float* losspart, int with_loss,
+                         hipStream_t st) {
+    constexpr int SPL = dec_spl(KP);
+    const int64_t chunks = (M + 256 * SPL - 1) / (256 * SPL);
+    dim3 grid((unsigned)chunks), block(256);
+    if (with_loss)
+        hipLaunchKernelGGL((decode_bce_kernel<KP, SPL, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
+    else
+        hipLaunchKernelGGL((decode_bce_kernel<KP, SPL, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
+    return check_launch("decode_bce");
+}
+
+}  // namespace nadm
+
+using namespace nadm;
+
+extern "C" int64_t nadm_encode_chunks(int64_t M) { return (M + ENC_CHUNK_SNPS - 1) / ENC_CHUNK_SNPS; }
+
+extern "C" int64_t nadm_decode_chunks(int64_t M, int kp) {
+    const int spl = dec_spl(kp);
+    return (M + 256 * spl - 1) / (256 * spl);
+}
+
+static int enc_rows_per_block(int b) {
+    const int max_rows = 832;                           // 13 waves; LDS = rows * 132 B <= 110 KB
+    const int gy = (b + max_rows - 1) / max_rows;
+    const int per = (b + gy - 1) / gy;
+    return ((per + 63) / 64) * 64;
+}
+
+extern "C" int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                               const float* V, int32_t CP, float* zpart, void* stream) {
+    if (!xp || !idx || !V || !zpart) return fail("nadm_encode_fwd: null pointer");
+    if (b <= 0 || M <= 0) return fail("nadm_encode_fwd: empty batch or M");
+    if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_encode_fwd: ld must be a multiple of 16 and >= ceil(M/4)");
+    const int rpb = enc_rows_per_block(b);
+    dim3 grid((unsigned)nadm_encode_chunks(M), (unsigned)((b + rpb - 1) / rpb)), block(rpb);
+    const size_t lds = (size_t)rpb * ENC_LDW * 4;
+    hipStream_t st = (hipStream_t)stream;
+#define ENC_CASE(cp)                                                                                                   \
+    case cp:                                                                                                           \
+        if (hipFuncSetAttribute((const void*)encode_fwd_kernel<cp>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                (int)lds) != hipSuccess) return fail("nadm_encode_fwd: cannot raise dynamic LDS limit"); \
+        hipLaunchKernelGGL((encode_fwd_kernel<cp>), grid, block, lds, st, xp, ld, idx, b, M, V, zpart, rpb);           \
+        break;
+    switch (CP) {
+        ENC_CASE(4) ENC_CASE(8) ENC_CASE(12) ENC_CASE(16) ENC_CASE(24) ENC_CASE(32)
+        default: return fail("nadm_encode_fwd: unsupported CP (4,8,12,16,24,32)");
+    }
+#undef ENC_CASE
+    return check_launch("encode_fwd");
+}
+
+extern "C" int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                               const float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
+                               float* losspart, int32_t with_loss, void* stream) {
+    if (!xp || !idx || !P || !Q || !dP || !dqpart) return fail("nadm_decode_bce: null pointer");
+    if (with_loss && !losspart) return fail("nadm_decode_bce: with_loss needs losspart");
+    if (b <= 0 || M <= 0) return fail("nadm_decode_bce: empty batch or M");
+    if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_decode_bce: ld must be a multiple of 16 and >= ceil(M/4)");
+    hipStream_t st = (hipStream_t)stream;
+    switch (kp) {
+        case 4: return launch_decode<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
+        case 8: return launch_decode<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
+        case 12: return launch_decode<12>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
+        case 16: return launch_decode<16>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
+        case 24: return launch_decode<24>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
+        case 32: return launch_decode<32>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
+        case 48: return launch_decode<48>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
+        case 64: return launch_decode<64>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
+        default: return fail("nadm_decode_bce: unsupported padded K (use nadm_pad_k)");
+    }
+}
+
+extern "C" int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                               const float* dZ, int32_t CP, float* dV, void* stream) {
+    if (!xp || !idx || !dZ || !dV) return fail("nadm_encode_bwd: null pointer");
+    if (b <= 0 || M <= 0) return fail("nadm_encode_bwd: empty batch or M");
+    if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_encode_bwd: ld must be a multiple of 16 and >= ceil(M/4)");
+    dim3 grid((unsigned)((M + 1023) / 1024)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (CP) {
+        case 4: hipLaunchKernelGGL((encode_bwd_kernel<4>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
+        case 8: hipLaunchKernelGGL((encode_bwd_kernel<8>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
+        case 12: hipLaunchKernelGGL((encode_bwd_kernel<12>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
+        case 16: hipLaunchKernelGGL((encode_bwd_kernel<16>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
+        case 24: hipLaunchKernelGGL((encode_bwd_kernel<24>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
+        case 32: hipLaunchKernelGGL((encode_bwd_kernel<32>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
+        default: return fail("nadm_encode_bwd: unsupported CP (4,8,12,16,24,32)");
+    }
+    return check_launch("encode_bwd");
+}

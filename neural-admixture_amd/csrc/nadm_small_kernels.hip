@@ -1,0 +1,583 @@
+// Small-tensor kernels: partial reductions, RMSNorm + MLP + softmax forward/backward, Adam, packing,
+// synthetic genotype generator.  None of these touches the genotype matrix except pack/unpack/synth;
+// they are latency-bound (a few microseconds each) and written for simplicity and determinism
+// (fixed reduction orders, no atomics).
+#include "nadm_common.h"
+#include "../../include/nadm.h"
+#include "nadm_host.h"
+#include <math.h>
+#include <thread>
+#include <vector>
+
+namespace nadm {
+
+constexpr int SJ = 32;          // samples per split in the weight-gradient kernel
+struct DqChunks { int64_t n[NADM_MAX_HEADS]; };   // per-head chunk counts of the dQ partial slabs
+
+// -------------------------------------------------------------------------------------------------
+// block-wide sum of `n` (<= 64) per-thread values each; result valid for all threads afterwards.
+// -------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* s_red /*[NT/64]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float s = wave_sum_lane63(v);
+    __syncthreads();
+    if (lane == 63) s_red[wave] = s;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) t += s_red[w];
+    return t;
+}
+
+// =================================================================================================
+// mlp_fwd: one block (256 threads) per sample.
+//   Z = sum_chunks zpart ; Zn = Z * rsqrt(mean(Z^2)+1e-8) * g   (torch.nn.RMSNorm, neural_admixture.py:135,173)
+//   H = relu(Zn W1^T + b1) (:138-140,174) ; per head: softmax(H Wk^T + bk) (:29,48,176)
+// =================================================================================================
+__global__ __launch_bounds__(256) void mlp_fwd_kernel(nadm_heads_t hd, const float* __restrict__ small,
+                                                      const float* __restrict__ zpart, int64_t n_chunks, int b,
+                                                      float* __restrict__ Z, float* __restrict__ rinv,
+                                                      float* __restrict__ Zn, float* __restrict__ H,
+                                                      float* __restrict__ Q) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = hd.C, CP = hd.CP, Hd = hd.Hd, SP = hd.SP;
+    float* s_red = sm;                 // [4]
+    float* s_zn = sm + 4;              // [CP]
+    float* s_h = s_zn + CP;            // [Hd]
+    float* s_logit = s_h + Hd;         // [SP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x;
+
+    // ---- Z = sum over chunks (fixed order: thread-strided, then wave DPP, then 4 waves) ----
+    for (int c = 0; c < CP; ++c) {
+        float a = 0.f;
+        for (int64_t ch = tid; ch < n_chunks; ch += 256) a += zpart[(ch * b + i) * CP + c];
+        const float zsum = block_sum<256>(a, s_red);
+        if (tid == 0) s_zn[c] = zsum;            // holds raw Z for now
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float ms = 0.f;
+        for (int c = 0; c < C; ++c) ms = fmaf(s_zn[c], s_zn[c], ms);
+        const float ri = 1.0f / sqrtf(ms / (float)C + 1e-8f);
+        rinv[i] = ri;
+        for (int c = 0; c < CP; ++c) {
+            const float z = s_zn[c];
+            Z[(int64_t)i * CP + c] = z;
+            const float zn = (c < C) ? z * ri * small[hd.g_off + c] : 0.f;
+            Zn[(int64_t)i * CP + c] = zn;
+            s_zn[c] = zn;
+        }
+    }
+    __syncthreads();
+    // ---- hidden layer ----
+    const float* W1 = small + hd.w1_off;
+    const float* b1 = small + hd.b1_off;
+    for (int h = tid; h < Hd; h += 256) {
+        float a = b1[h];
+        for (int c = 0; c < C; ++c) a = fmaf(s_zn[c], W1[h * C + c], a);
+        a = fmaxf(a, 0.f);
+        s_h[h] = a;
+        H[(int64_t)i * Hd + h] = a;
+    }
+    __syncthreads();
+    // ---- head logits: wave w takes columns w, w+4, ... ----
+    for (int hh = 0; hh < hd.n_heads; ++hh) {
+        const float* Wk = small + hd.wk_off[hh];
+        const float* bk = small + hd.bk_off[hh];
+        for (int k = wave; k < hd.k[hh]; k += 4) {
+            float a = 0.f;
+            for (int h = lane; h < Hd; h += 64) a = fmaf(s_h[h], Wk[k * Hd + h], a);
+            a = wave_sum_lane63(a);
+            if (lane == 63) s_logit[hd.qoff[hh] + k] = a + bk[k];
+        }
+    }
+    __syncthreads();
+    // ---- softmax per head (serial over k <= 64; one thread per head) ----
+    if (tid < hd.n_heads) {
+        const int k = hd.k[tid], kp = hd.kp[tid], o = hd.qoff[tid];
+        float mx = -INFINITY;
+        for (int j = 0; j < k; ++j) mx = fmaxf(mx, s_logit[o + j]);
+        float sum = 0.f;
+        for (int j = 0; j < k; ++j) { const float e = expf(s_logit[o + j] - mx); s_logit[o + j] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < kp; ++j) Q[(int64_t)i * SP + o + j] = (j < k) ? s_logit[o + j] * inv : 0.f;
+    }
+}
+
+// =================================================================================================
+// mlp_bwd_a: one block per sample.  dQ = sum_chunks dqpart ; softmax backward ; dH ; relu mask ;
+// dZn ; RMSNorm backward -> dZ.   (autograd of neural_admixture.py:173-176)
+//   dlogit = Q * (dQ - sum_k dQ*Q) ; dZ = rinv*t - Z*rinv^3*mean_c(t*Z), t = dZn*g ; dg_i = dZn*Z*rinv
+// Block 0 also folds the step's loss partials (double) into loss_acc.
+// =================================================================================================
+__global__ __launch_bounds__(256) void mlp_bwd_a_kernel(nadm_heads_t hd, const float* __restrict__ small,
+                                                        const float* __restrict__ dqpart, DqChunks dq_chunks, int b,
+                                                        const float* __restrict__ Z, const float* __restrict__ rinv,
+                                                        const float* __restrict__ H, const float* __restrict__ Q,
+                                                        float* __restrict__ dL, float* __restrict__ dHpre,
+                                                        float* __restrict__ dgp, float* __restrict__ dZ,
+                                                        const float* __restrict__ losspart, int64_t n_loss,
+                                                        double* __restrict__ loss_acc) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = hd.C, CP = hd.CP, Hd = hd.Hd, SP = hd.SP;
+    float* s_red = sm;                  // [4]
+    float* s_dl = sm + 4;               // [SP]
+    float* s_dzn = s_dl + SP;           // [CP]
+    float* s_grp = s_dzn + CP;          // [256]
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x;
+
+    // ---- dQ[s] = sum over chunks, per head (each head has its own slab [chunks_h, b, kp_h]);
+    //      threads split (column, chunk-group), then a fixed-order combine ----
+    {
+        int64_t base = 0;
+        for (int hh = 0; hh < hd.n_heads; ++hh) {
+            const int kp = hd.kp[hh];
+            const int64_t nch = dq_chunks.n[hh];
+            const int G = 256 / kp;                        // kp <= 64 -> G >= 4
+            const int col = tid % kp, grp = tid / kp;
+            float a = 0.f;
+            if (grp < G)
+                for (int64_t ch = grp; ch < nch; ch += G) a += dqpart[base + (ch * b + i) * kp + col];
+            s_grp[tid] = a;
+            __syncthreads();
+            if (tid < kp) {
+                float t = 0.f;
+                for (int g = 0; g < G; ++g) t += s_grp[g * kp + tid];
+                s_dl[hd.qoff[hh] + tid] = t;                // raw dQ for now
+            }
+            __syncthreads();
+            base += nch * b * kp;
+        }
+    }
+    // ---- softmax backward per head ----
+    if (tid < hd.n_heads) {
+        const int k = hd.k[tid], kp = hd.kp[tid], o = hd.qoff[tid];
+        const float* q = Q + (int64_t)i * SP + o;
+        float dot = 0.f;
+        for (int j = 0; j < k; ++j) dot = fmaf(s_dl[o + j], q[j], dot);
+        for (int j = 0; j < kp; ++j) {
+            const float v = (j < k) ? q[j] * (s_dl[o + j] - dot) : 0.f;
+            s_dl[o + j] = v;
+            dL[(int64_t)i * SP + o + j] = v;
+        }
+    }
+    __syncthreads();
+    // ---- dH, relu mask, dZn partials ----
+    float dzn[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) dzn[c] = 0.f;
+    const float* W1 = small + hd.w1_off;
+    for (int h = tid; h < Hd; h += 256) {
+        float a = 0.f;
+        for (int hh = 0; hh < hd.n_heads; ++hh) {
+            const float* Wk = small + hd.wk_off[hh];
+            const int o = hd.qoff[hh];
+            for (int k = 0; k < hd.k[hh]; ++k) a = fmaf(s_dl[o + k], Wk[k * Hd + h], a);
+        }
+        a = (H[(int64_t)i * Hd + h] > 0.f) ? a : 0.f;
+        dHpre[(int64_t)i * Hd + h] = a;
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+            if (c < C) dzn[c] = fmaf(a, W1[h * C + c], dzn[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        if (c < C) {                                   // uniform branch
+            const float t = block_sum<256>(dzn[c], s_red);
+            if (tid == 0) s_dzn[c] = t;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float ri = rinv[i];
+        const float* g = small + hd.g_off;
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) dot = fmaf(s_dzn[c] * g[c], Z[(int64_t)i * CP + c], dot);
+        const float mean_tz = dot / (float)C;
+        const float ri3 = ri * ri * ri;
+        for (int c = 0; c < CP; ++c) {
+            float dz = 0.f, dgv = 0.f;
+            if (c < C) {
+                const float z = Z[(int64_t)i * CP + c];
+                dz = ri * (s_dzn[c] * g[c]) - z * ri3 * mean_tz;
+                dgv = s_dzn[c] * z * ri;
+            }
+            dZ[(int64_t)i * CP + c] = dz;
+            dgp[(int64_t)i * CP + c] = dgv;
+        }
+    }
+    // ---- loss (block 0 only) ----
+    if (i == 0 && n_loss > 0) {
+        double a = 0.0;
+        for (int64_t e = tid; e < n_loss; e += 256) a += (double)losspart[e];
+        a = wave_sum_all_f64(a);
+        __shared__ double s_l[4];
+        __syncthreads();
+        if ((tid & 63) == 0) s_l[tid >> 6] = a;
+        __syncthreads();
+        if (tid == 0) {
+            const double tot = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]);
+            loss_acc[0] += tot;          // running (epoch) sum
+            loss_acc[1] = tot;           // last step
+        }
+    }
+}
+
+// =================================================================================================
+// mlp_bwd_b: weight gradients, split over samples: grid (ceil(Hd/256), splits).
+//   dWk[k][h] = sum_i dL[i][k] H[i][h] ; dW1[h][c] = sum_i dHpre[i][h] Zn[i][c] ; db1[h] = sum_i dHpre[i][h]
+//   dbk[k] = sum_i dL[i][k] ; dg[c] = sum_i dgp[i][c]      (block x == 0)
+// writes small_part[split][n_small]; small_reduce sums the splits in fixed order.
+// =================================================================================================
+__global__ __launch_bounds__(256) void mlp_bwd_b_kernel(nadm_heads_t hd, int b, const float* __restrict__ Zn,
+                                                        const float* __restrict__ H, const float* __restrict__ dL,
+                                                        const float* __restrict__ dHpre, const float* __restrict__ dgp,
+                                                        float* __restrict__ small_part) {
+    const int C = hd.C, CP = hd.CP, Hd = hd.Hd, SP = hd.SP;
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x * 256 + tid;
+    const int j = blockIdx.y;
+    const int i0 = j * SJ, i1 = min(b, i0 + SJ);
+    float* out = small_part + (int64_t)j * hd.n_small;
+    if (h < Hd) {
+        // W1 / b1
+        float aw[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) aw[c] = 0.f;
+        float ab = 0.f;
+        for (int i = i0; i < i1; ++i) {
+            const float d = dHpre[(int64_t)i * Hd + h];
+            ab += d;
+#pragma unroll
+            for (int c = 0; c < 32; ++c)
+                if (c < C) aw[c] = fmaf(d, Zn[(int64_t)i * CP + c], aw[c]);
+        }
+        out[hd.b1_off + h] = ab;
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+            if (c < C) out[hd.w1_off + h * C + c] = aw[c];
+        // Wk per head, 16 columns at a time
+        for (int hh = 0; hh < hd.n_heads; ++hh) {
+            const int o = hd.qoff[hh], k = hd.k[hh];
+            for (int k0 = 0; k0 < k; k0 += 16) {
+                float a[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) a[s] = 0.f;
+                for (int i = i0; i < i1; ++i) {
+                    const float hv = H[(int64_t)i * Hd + h];
+                    const float* dl = dL + (int64_t)i * SP + o + k0;     // padded columns are zero
+#pragma unroll
+                    for (int s = 0; s < 16; ++s)
+                        if (k0 + s < hd.kp[hh]) a[s] = fmaf(dl[s], hv, a[s]);
+                }
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    if (k0 + s < k) out[hd.wk_off[hh] + (k0 + s) * Hd + h] = a[s];
+            }
+        }
+    }
+    if (blockIdx.x == 0) {
+        // biases of the heads and the RMSNorm weight: tiny column sums
+        for (int hh = 0; hh < hd.n_heads; ++hh)
+            for (int k = tid; k < hd.k[hh]; k += 256) {
+                float a = 0.f;
+                for (int i = i0; i < i1; ++i) a += dL[(int64_t)i * SP + hd.qoff[hh] + k];
+                out[hd.bk_off[hh] + k] = a;
+            }
+        for (int c = tid; c < C; c += 256) {
+            float a = 0.f;
+            for (int i = i0; i < i1; ++i) a += dgp[(int64_t)i * CP + c];
+            out[hd.g_off + c] = a;
+        }
+    }
+}
+
+__global__ void small_reduce_kernel(const float* __restrict__ part, int splits, int n, float* __restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float a = 0.f;
+    for (int j = 0; j < splits; ++j) a += part[(int64_t)j * n + e];
+    out[e] = a;
+}
+
+// =================================================================================================
+// Adam + clamp (torch.optim.Adam fused kernel closed form; neural_admixture.py:187-204,411-412)
+// =================================================================================================
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   int64_t clamp_from, float step_size, float bc2_sqrt,
+                                                   float grad_scale) {
+    const float b2 = 0.95f, eps = 1e-8f;
+    const float omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.95);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < n; e += stride) {
+        if (e + 4 <= n) {
+            const float4 P4 = *reinterpret_cast<const float4*>(p + e);
+            const float4 G4 = *reinterpret_cast<const float4*>(g + e);
+            const float4 M4 = *reinterpret_cast<const float4*>(m + e);
+            const float4 V4 = *reinterpret_cast<const float4*>(v + e);
+            float pp[4] = {P4.x, P4.y, P4.z, P4.w}, gg[4] = {G4.x, G4.y, G4.z, G4.w};
+            float mm[4] = {M4.x, M4.y, M4.z, M4.w}, vv[4] = {V4.x, V4.y, V4.z, V4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float gr = gg[q] * grad_scale;
+                mm[q] = mm[q] + (gr - mm[q]) * omb1;
+                vv[q] = vv[q] * b2 + gr * gr * omb2;
+                const float den = sqrtf(vv[q]) / bc2_sqrt + eps;
+                float np_ = pp[q] - step_size * (mm[q] / den);
+                if (e + q >= clamp_from) np_ = fminf(fmaxf(np_, 0.f), 1.f);
+                pp[q] = np_;
+            }
+            *reinterpret_cast<float4*>(p + e) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+            *reinterpret_cast<float4*>(m + e) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            *reinterpret_cast<float4*>(v + e) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        } else {
+            for (int64_t q = e; q < n; ++q) {
+                const float gr = g[q] * grad_scale;
+                const float mq = m[q] + (gr - m[q]) * omb1;
+                const float vq = v[q] * b2 + gr * gr * omb2;
+                const float den = sqrtf(vq) / bc2_sqrt + eps;
+                float np_ = p[q] - step_size * (mq / den);
+                if (q >= clamp_from) np_ = fminf(fmaxf(np_, 0.f), 1.f);
+                p[q] = np_; m[q] = mq; v[q] = vq;
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// pack / unpack (pack2bit.cu:10-62).  One thread per output dword (16 genotypes).
+// =================================================================================================
+__global__ void pack2bit_kernel(const uint8_t* __restrict__ g, uint8_t* __restrict__ out, int64_t rows, int64_t M,
+                                int64_t ld) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;    // dword within row
+    const int64_t r = blockIdx.y;
+    if (r >= rows || w * 4 >= ld) return;
+    const uint8_t* src = g + r * M + w * 16;
+    uint32_t word = 0;
+    const int64_t left = M - w * 16;
+    if (left >= 16) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) word |= (uint32_t)(src[s] & 3u) << (2 * s);
+    } else {
+        for (int s = 0; s < left; ++s) word |= (uint32_t)(src[s] & 3u) << (2 * s);
+    }
+    *reinterpret_cast<uint32_t*>(out + r * ld + w * 4) = word;
+}
+
+__global__ void unpack2bit_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int64_t rows, int64_t M,
+                                  int64_t ld) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;    // packed byte within row
+    const int64_t r = blockIdx.y;
+    if (r >= rows || c * 4 >= M) return;
+    const uint32_t v = in[r * ld + c];
+    for (int s = 0; s < 4; ++s)
+        if (c * 4 + s < M) out[r * M + c * 4 + s] = (v >> (2 * s)) & 3u;
+}
+
+// =================================================================================================
+// synthetic genotypes: G ~ Binomial(2, Qt.F), missing -> 3, written packed.
+// Counter-based hash RNG keyed by (seed, global row, SNP): independent of launch geometry.
+// =================================================================================================
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {   // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void synth_kernel(uint8_t* __restrict__ xp, int64_t rows, int64_t row0, int64_t M, int64_t ld,
+                             const float* __restrict__ Qt, const float* __restrict__ Fq, int K, float missing,
+                             uint64_t seed) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;    // packed byte
+    const int64_t r = blockIdx.y;
+    if (r >= rows || c >= ld) return;
+    uint32_t byte = 0;
+    for (int s = 0; s < 4; ++s) {
+        const int64_t m = c * 4 + s;
+        if (m >= M) break;
+        float f = 0.f;
+        for (int k = 0; k < K; ++k) f = fmaf(Qt[r * K + k], Fq[(int64_t)k * M + m], f);
+        const uint64_t h = mix64(seed ^ mix64((uint64_t)(row0 + r) * 0x9E3779B97F4A7C15ull + (uint64_t)m));
+        const float u1 = (float)(h & 0xFFFFFF) * (1.0f / 16777216.0f);
+        const float u2 = (float)((h >> 24) & 0xFFFFFF) * (1.0f / 16777216.0f);
+        const float u3 = (float)((h >> 48) & 0xFFFF) * (1.0f / 65536.0f);
+        uint32_t gcode = (u1 < f ? 1u : 0u) + (u2 < f ? 1u : 0u);
+        if (u3 < missing) gcode = 3u;
+        byte |= gcode << (2 * s);
+    }
+    xp[r * ld + c] = (uint8_t)byte;
+}
+
+}  // namespace nadm
+
+using namespace nadm;
+
+// -------------------------------------------------------------------------------------------------
+extern "C" int nadm_abi_version(void) { return NADM_ABI_VERSION; }
+extern "C" const char* nadm_last_error(void) { return err_buf(); }
+
+extern "C" int nadm_pad_k(int k) {
+    if (k <= 0 || k > NADM_MAX_K) return -1;
+    if (k <= 16) return (k + 3) & ~3;
+    if (k <= 24) return 24;
+    if (k <= 32) return 32;
+    if (k <= 48) return 48;
+    return 64;
+}
+static int pad_c(int c) {
+    if (c <= 0 || c > 32) return -1;
+    if (c <= 16) return (c + 3) & ~3;
+    return c <= 24 ? 24 : 32;
+}
+
+extern "C" int nadm_heads_init(nadm_heads_t* out, int C, int Hd, const int32_t* ks, int n) {
+    if (!out || !ks) return fail("nadm_heads_init: null pointer");
+    if (n <= 0 || n > NADM_MAX_HEADS) return fail("nadm_heads_init: 1..32 heads supported");
+    if (pad_c(C) < 0) return fail("nadm_heads_init: n_components must be in 1..32");
+    if (Hd <= 0 || Hd > 8192) return fail("nadm_heads_init: hidden size must be in 1..8192");
+    memset(out, 0, sizeof(*out));
+    out->n_heads = n; out->C = C; out->CP = pad_c(C); out->Hd = Hd;
+    int off = 0;
+    out->g_off = off; off += C;
+    out->w1_off = off; off += Hd * C;
+    out->b1_off = off; off += Hd;
+    int q = 0;
+    for (int h = 0; h < n; ++h) {
+        const int kp = nadm_pad_k(ks[h]);
+        if (kp < 0) return fail("nadm_heads_init: K must be in 1..64");
+        if (h > 0 && ks[h] <= ks[h - 1]) return fail("nadm_heads_init: ks must be strictly ascending");
+        out->k[h] = ks[h]; out->kp[h] = kp; out->qoff[h] = q; q += kp;
+        out->wk_off[h] = off; off += ks[h] * Hd;
+        out->bk_off[h] = off; off += ks[h];
+    }
+    out->SP = q;
+    out->n_small = off;
+    return 0;
+}
+
+extern "C" int32_t nadm_sample_splits(int b) { return (b + SJ - 1) / SJ; }
+
+extern "C" int nadm_pack2bit_host(const uint8_t* g, uint8_t* out, int64_t N, int64_t M, int64_t ld) {
+    if (!g || !out) return fail("nadm_pack2bit_host: null pointer");
+    if (ld * 4 < M) return fail("nadm_pack2bit_host: ld < ceil(M/4)");
+    auto work = [=](int64_t r_begin, int64_t r_end) {
+        for (int64_t r = r_begin; r < r_end; ++r) {
+            const uint8_t* src = g + r * M;
+            uint8_t* dst = out + r * ld;
+            const int64_t full = M / 4;
+            for (int64_t c = 0; c < full; ++c) {
+                const uint8_t* s = src + 4 * c;
+                dst[c] = (uint8_t)((s[0] & 3) | ((s[1] & 3) << 2) | ((s[2] & 3) << 4) | ((s[3] & 3) << 6));
+            }
+            if (full * 4 < M) {
+                uint8_t v = 0;
+                for (int64_t s = full * 4; s < M; ++s) v |= (uint8_t)((src[s] & 3) << (2 * (s - full * 4)));
+                dst[full] = v;
+            }
+            for (int64_t c = (M + 3) / 4; c < ld; ++c) dst[c] = 0;
+        }
+    };
+    int nt = (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > 32) nt = 32;
+    if ((int64_t)nt > N) nt = (int)(N > 0 ? N : 1);
+    if (N * M < (1 << 22)) nt = 1;
+    if (nt == 1) {
+        work(0, N);
+    } else {
+        std::vector<std::thread> th;
+        const int64_t per = (N + nt - 1) / nt;
+        for (int t = 0; t < nt; ++t) {
+            const int64_t r0 = t * per, r1 = r0 + per < N ? r0 + per : N;
+            if (r0 < r1) th.emplace_back(work, r0, r1);
+        }
+        for (auto& t : th) t.join();
+    }
+    return 0;
+}
+
+extern "C" int nadm_pack2bit(const uint8_t* g_dev, uint8_t* out_dev, int64_t rows, int64_t M, int64_t ld, void* stream) {
+    if (!g_dev || !out_dev) return fail("nadm_pack2bit: null pointer");
+    if (ld % 4 != 0 || ld * 4 < M) return fail("nadm_pack2bit: ld must be a multiple of 4 and >= ceil(M/4)");
+    if (rows == 0 || M == 0) return 0;
+    if (rows > 65535 * 1024ll) return fail("nadm_pack2bit: too many rows for one call");
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        dim3 grid((unsigned)((ld / 4 + 255) / 256), (unsigned)nr), block(256);
+        hipLaunchKernelGGL(pack2bit_kernel, grid, block, 0, (hipStream_t)stream, g_dev + r0 * M, out_dev + r0 * ld, nr, M, ld);
+    }
+    return check_launch("pack2bit");
+}
+
+extern "C" int nadm_unpack2bit(const uint8_t* in_dev, uint8_t* out_dev, int64_t rows, int64_t M, int64_t ld, void* stream) {
+    if (!in_dev || !out_dev) return fail("nadm_unpack2bit: null pointer");
+    if (ld * 4 < M) return fail("nadm_unpack2bit: ld < ceil(M/4)");
+    if (rows == 0 || M == 0) return 0;
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        dim3 grid((unsigned)(((M + 3) / 4 + 255) / 256), (unsigned)nr), block(256);
+        hipLaunchKernelGGL(unpack2bit_kernel, grid, block, 0, (hipStream_t)stream, in_dev + r0 * ld, out_dev + r0 * M, nr, M, ld);
+    }
+    return check_launch("unpack2bit");
+}
+
+extern "C" int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const float* zpart, int64_t n_chunks, int32_t b,
+                            float* Z, float* rinv, float* Zn, float* H, float* Q, void* stream) {
+    if (!hd || !small || !zpart || !Z || !rinv || !Zn || !H || !Q) return fail("nadm_mlp_fwd: null pointer");
+    if (b <= 0) return fail("nadm_mlp_fwd: empty batch");
+    const size_t lds = (size_t)(4 + hd->CP + hd->Hd + hd->SP) * 4;
+    hipLaunchKernelGGL(mlp_fwd_kernel, dim3(b), dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q);
+    return check_launch("mlp_fwd");
+}
+
+extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const float* dqpart, int64_t M, int32_t b,
+                            const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
+                            float* dL, float* dHpre, float* dgp, float* small_part, float* dZ, float* grad_small,
+                            const float* losspart, int64_t n_loss, double* loss_acc, void* stream) {
+    if (!hd || !small || !dqpart || !Z || !rinv || !Zn || !H || !Q || !dL || !dHpre || !dgp || !small_part || !dZ || !grad_small)
+        return fail("nadm_mlp_bwd: null pointer");
+    if (n_loss > 0 && (!losspart || !loss_acc)) return fail("nadm_mlp_bwd: n_loss > 0 needs losspart and loss_acc");
+    if (b <= 0) return fail("nadm_mlp_bwd: empty batch");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(4 + hd->SP + hd->CP + 256) * 4;
+    DqChunks dqc;
+    for (int h = 0; h < NADM_MAX_HEADS; ++h) dqc.n[h] = h < hd->n_heads ? nadm_decode_chunks(M, hd->kp[h]) : 0;
+    hipLaunchKernelGGL(mlp_bwd_a_kernel, dim3(b), dim3(256), lds, st, *hd, small, dqpart, dqc, b, Z, rinv, H, Q, dL, dHpre,
+                       dgp, dZ, losspart, n_loss, loss_acc);
+    const int splits = nadm_sample_splits(b);
+    hipLaunchKernelGGL(mlp_bwd_b_kernel, dim3((hd->Hd + 255) / 256, splits), dim3(256), 0, st, *hd, b, Zn, H, dL, dHpre, dgp, small_part);
+    hipLaunchKernelGGL(small_reduce_kernel, dim3((hd->n_small + 255) / 256), dim3(256), 0, st, small_part, splits, hd->n_small, grad_small);
+    return check_launch("mlp_bwd");
+}
+
+extern "C" int nadm_adam(float* param, const float* grad, float* m, float* v, int64_t n, int64_t clamp_from, float lr,
+                         int32_t step, float grad_scale, void* stream) {
+    if (!param || !grad || !m || !v) return fail("nadm_adam: null pointer");
+    if (step < 1) return fail("nadm_adam: step is 1-based");
+    if (n <= 0) return 0;
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) return fail("nadm_adam: buffers must be 16-byte aligned");
+    const double bc1 = 1.0 - pow(0.9, (double)step);
+    const double bc2 = 1.0 - pow(0.95, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, clamp_from, step_size,
+                       bc2_sqrt, grad_scale);
+    return check_launch("adam");
+}
+
+extern "C" int nadm_synth_packed(uint8_t* xp, int64_t rows, int64_t row0, int64_t M, int64_t ld, const float* Qt, const float* Fq,
+                                 int32_t K, float missing, uint64_t seed, void* stream) {
+    if (!xp || !Qt || !Fq) return fail("nadm_synth_packed: null pointer");
+    if (ld * 4 < M) return fail("nadm_synth_packed: ld < ceil(M/4)");
+    for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+        const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
+        dim3 grid((unsigned)((ld + 255) / 256), (unsigned)nr), block(256);
+        hipLaunchKernelGGL(synth_kernel, grid, block, 0, (hipStream_t)stream, xp + r0 * ld, nr, row0 + r0, M, ld, Qt + r0 * K, Fq, K, missing, seed);
+    }
+    return check_launch("synth_packed");
+}

@@ -1,0 +1,207 @@
+"""Device-side state and step sequencing for the training hot path.
+
+One Engine per process / GPU.  It owns (through torch) every HBM buffer and drives the C-ABI
+kernels on torch's current stream.  Mirrors what ``NeuralAdmixture._run_epoch`` / ``_run_step`` do
+per batch (neural_admixture.py:394-432): gather + decode, forward, loss, backward, (all-reduce),
+Adam, restrict_P -- without materialising any [b, M] tensor.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from ._lib import lib, check, ptr
+from .layout import ModelLayout
+
+_f32 = torch.float32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    def __init__(self, M: int, C_: int, Hd: int, ks: Sequence[int], device: torch.device, max_batch: int):
+        if device.type != "cuda":
+            raise RuntimeError("neural_admixture_amd.Engine needs a ROCm GPU device (no CPU fallback)")
+        self.device = device
+        self.lay = L = ModelLayout(M, C_, Hd, ks)
+        self.M, self.ld = L.M, ModelLayout.row_stride(L.M)
+        self.bmax = int(max_batch)
+        z = lambda n, dt=_f32: torch.zeros(int(n), dtype=dt, device=device)
+        # parameters, gradients, Adam moments
+        self.big, self.gbig, self.mbig, self.vbig = z(L.n_big), z(L.n_big), z(L.n_big), z(L.n_big)
+        self.small, self.gsmall, self.msmall, self.vsmall = z(L.n_small), z(L.n_small), z(L.n_small), z(L.n_small)
+        # activations / scratch
+        b = self.bmax
+        self.zpart = z(L.enc_chunks * b * L.CP)
+        self.Z, self.rinv, self.Zn = z(b * L.CP), z(b), z(b * L.CP)
+        self.H, self.Q = z(b * L.Hd), z(b * L.SP)
+        self.dL, self.dHpre, self.dgp, self.dZ = z(b * L.SP), z(b * L.Hd), z(b * L.CP), z(b * L.CP)
+        self.dqpart = z(L.dq_offsets(b)[1])
+        self.losspart = z(L.n_loss)
+        self.small_part = z(int(lib.nadm_sample_splits(b)) * L.n_small)
+        self.loss_acc = torch.zeros(2, dtype=torch.float64, device=device)
+        self.xp: Optional[torch.Tensor] = None          # packed genotypes [rows, ld]
+        self.step_count = 0
+        # optional per-kernel timing (bench.py): name -> list of (start_event, end_event) on the launch stream
+        self.timers: Optional[dict] = None
+
+    def _timed(self, name):
+        if self.timers is None:
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self.timers.setdefault(name, []).append(ev)
+        ev[0].record()
+        return ev
+
+    # ------------------------------------------------------------------ data
+    def set_packed(self, xp: torch.Tensor) -> None:
+        if xp.dtype != torch.uint8 or xp.dim() != 2 or xp.shape[1] != self.ld or not xp.is_contiguous():
+            raise RuntimeError(f"packed genotypes must be contiguous uint8 [rows, {self.ld}]")
+        self.xp = xp
+
+    def pack_from_host(self, data_u8: torch.Tensor, rows: Optional[np.ndarray] = None, chunk_rows: int = 8192) -> None:
+        """uint8 [N,M] CPU tensor -> packed rows in HBM.  Packs on the host (2 bits/genotype cross
+        PCIe instead of 8; the reference ships unpacked bytes in 1024-row chunks with a blocking
+        sync per chunk, pack2bit.cu:79-115).  ``rows``: optional row selection/order (rank shard)."""
+        if data_u8.dtype != torch.uint8 or data_u8.dim() != 2 or data_u8.device.type != "cpu":
+            raise RuntimeError("pack_from_host expects a uint8 [N,M] CPU tensor")
+        N, M = data_u8.shape
+        if M != self.M:
+            raise RuntimeError("pack_from_host: SNP count mismatch")
+        n_out = N if rows is None else len(rows)
+        xp = torch.empty((n_out, self.ld), dtype=torch.uint8, device=self.device)
+        stage = torch.empty((min(chunk_rows, max(n_out, 1)), self.ld), dtype=torch.uint8).pin_memory() \
+            if torch.cuda.is_available() else None
+        for s in range(0, n_out, chunk_rows):
+            e = min(n_out, s + chunk_rows)
+            src = data_u8[s:e] if rows is None else data_u8[torch.as_tensor(rows[s:e], dtype=torch.long)]
+            src = src.contiguous()
+            check(lib.nadm_pack2bit_host(ptr(src), ptr(stage), e - s, M, self.ld), "pack2bit_host")
+            xp[s:e].copy_(stage[: e - s], non_blocking=False)
+        self.xp = xp
+
+    # ------------------------------------------------------------------ parameters
+    def load_params(self, V_MC: np.ndarray, P_SM: np.ndarray, small: np.ndarray) -> None:
+        """V_MC [M,C]; P_SM [sum(ks), M] (reference P_init layout, train.py:63,67); small = flat
+        g|W1|b1|Wk|bk in the nadm.h order."""
+        L = self.lay
+        big = np.zeros(L.n_big, dtype=np.float32)
+        big[: L.M * L.CP].reshape(L.M, L.CP)[:, : L.C] = V_MC
+        ini = 0
+        for h, k in enumerate(L.ks):
+            big[L.p_off[h]: L.p_off[h] + L.M * L.kp[h]].reshape(L.M, L.kp[h])[:, :k] = P_SM[ini:ini + k].T
+            ini += k
+        self.big.copy_(torch.from_numpy(big))
+        self.small.copy_(torch.from_numpy(np.ascontiguousarray(small, dtype=np.float32)))
+        for t in (self.mbig, self.vbig, self.msmall, self.vsmall, self.gbig, self.gsmall):
+            t.zero_()
+        self.step_count = 0
+
+    def V(self) -> torch.Tensor:
+        L = self.lay
+        return self.big[: L.M * L.CP].view(L.M, L.CP)[:, : L.C]
+
+    def P(self, h: int) -> torch.Tensor:
+        L = self.lay
+        return self.big[L.p_off[h]: L.p_off[h] + L.M * L.kp[h]].view(L.M, L.kp[h])[:, : L.ks[h]]
+
+    def gV(self) -> torch.Tensor:
+        L = self.lay
+        return self.gbig[: L.M * L.CP].view(L.M, L.CP)[:, : L.C]
+
+    def gP(self, h: int) -> torch.Tensor:
+        L = self.lay
+        return self.gbig[L.p_off[h]: L.p_off[h] + L.M * L.kp[h]].view(L.M, L.kp[h])[:, : L.ks[h]]
+
+    # ------------------------------------------------------------------ kernels
+    def forward(self, idx: torch.Tensor, b: int) -> None:
+        """idx int32 [b] device row indices into xp.  Fills Z, rinv, Zn, H, Q."""
+        L, st = self.lay, _stream()
+        if b > self.bmax:
+            raise RuntimeError("batch larger than the engine was sized for")
+        ev = self._timed("encode_fwd")
+        check(lib.nadm_encode_fwd(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self.big), L.CP, ptr(self.zpart), st), "encode_fwd")
+        if ev: ev[1].record()
+        check(lib.nadm_mlp_fwd(C.byref(L.heads), ptr(self.small), ptr(self.zpart), L.enc_chunks, b, ptr(self.Z), ptr(self.rinv),
+                               ptr(self.Zn), ptr(self.H), ptr(self.Q), st), "mlp_fwd")
+
+    def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_decoder_done=None) -> None:
+        """Decoder + BCE fwd/bwd per head, MLP backward, dV.  Gradients land in gbig / gsmall.
+        ``on_decoder_done`` (optional callable) is invoked after the dP kernels are enqueued -- the
+        multi-GPU path starts the all-reduce of the P gradients there, overlapping pass 3."""
+        L, st = self.lay, _stream()
+        dq_offs, _ = L.dq_offsets(b)
+        loss_offs = L.loss_offsets()
+        fsz = 4
+        ev = self._timed("decode_bce")
+        for h in range(len(L.ks)):
+            check(lib.nadm_decode_bce(
+                ptr(self.xp), self.ld, ptr(idx), b, L.M,
+                C.c_void_p(self.big.data_ptr() + L.p_off[h] * fsz), L.kp[h],
+                C.c_void_p(self.Q.data_ptr() + L.qoff[h] * fsz), L.SP,
+                C.c_void_p(self.gbig.data_ptr() + L.p_off[h] * fsz),
+                C.c_void_p(self.dqpart.data_ptr() + dq_offs[h] * fsz),
+                C.c_void_p(self.losspart.data_ptr() + loss_offs[h] * fsz), 1 if with_loss else 0, st), "decode_bce")
+        if ev: ev[1].record()
+        if on_decoder_done is not None:
+            on_decoder_done()
+        check(lib.nadm_mlp_bwd(C.byref(L.heads), ptr(self.small), ptr(self.dqpart), L.M, b, ptr(self.Z), ptr(self.rinv), ptr(self.Zn),
+                               ptr(self.H), ptr(self.Q), ptr(self.dL), ptr(self.dHpre), ptr(self.dgp), ptr(self.small_part),
+                               ptr(self.dZ), ptr(self.gsmall), ptr(self.losspart), L.n_loss if with_loss else 0,
+                               ptr(self.loss_acc), st), "mlp_bwd")
+        ev = self._timed("encode_bwd")
+        check(lib.nadm_encode_bwd(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self.dZ), L.CP, ptr(self.gbig), st), "encode_bwd")
+        if ev: ev[1].record()
+
+    def adam(self, lr: float, grad_scale: float = 1.0) -> None:
+        L, st = self.lay, _stream()
+        self.step_count += 1
+        ev = self._timed("adam")
+        check(lib.nadm_adam(ptr(self.big), ptr(self.gbig), ptr(self.mbig), ptr(self.vbig), L.n_big, L.clamp_from,
+                            lr, self.step_count, grad_scale, st), "adam(big)")
+        check(lib.nadm_adam(ptr(self.small), ptr(self.gsmall), ptr(self.msmall), ptr(self.vsmall), L.n_small, L.n_small,
+                            lr, self.step_count, grad_scale, st), "adam(small)")
+        if ev: ev[1].record()
+
+    def train_step(self, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True) -> None:
+        """One single-GPU step (neural_admixture.py:403-414 without the per-step host sync)."""
+        self.forward(idx, b)
+        self.backward(idx, b, with_loss)
+        self.adam(lr)
+
+    def train_step_ddp(self, idx: torch.Tensor, b: int, lr: float, world: int, with_loss: bool = True) -> None:
+        """Sample-sharded data-parallel step: local gradients -> all-reduce(sum) over RCCL -> Adam with
+        grad_scale 1/world (DDP's mean, neural_admixture.py:315-319).  The P-gradient all-reduce is
+        launched as soon as pass 2 is enqueued and overlaps the MLP backward and pass 3."""
+        import torch.distributed as dist
+        L = self.lay
+        works = []
+
+        def start_p():
+            works.append(dist.all_reduce(self.gbig[L.clamp_from:], op=dist.ReduceOp.SUM, async_op=True))
+        self.forward(idx, b)
+        self.backward(idx, b, with_loss, on_decoder_done=start_p)
+        works.append(dist.all_reduce(self.gbig[: L.clamp_from], op=dist.ReduceOp.SUM, async_op=True))
+        works.append(dist.all_reduce(self.gsmall, op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
+        self.adam(lr, 1.0 / world)
+
+    def infer_q(self, idx: torch.Tensor, b: int) -> List[torch.Tensor]:
+        """Encoder-only pass (final Q, neural_admixture.py:369-383; src/inference.py:71-77)."""
+        L = self.lay
+        self.forward(idx, b)
+        Q = self.Q[: b * L.SP].view(b, L.SP)
+        return [Q[:, L.qoff[h]: L.qoff[h] + k].clone() for h, k in enumerate(L.ks)]
+
+    def read_loss(self, reset: bool = True):
+        """(running sum since last reset, last step) -- one host sync."""
+        v = self.loss_acc.cpu().numpy().copy()
+        if reset:
+            self.loss_acc.zero_()
+        return float(v[0]), float(v[1])

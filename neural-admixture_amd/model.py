@@ -1,0 +1,243 @@
+"""Host-side mirror of the reference's model classes for the hot path.
+
+``Q_P``            -- parameter container with the reference's state_dict keys / config JSON
+                     (neural_admixture.py:100-230) and an inference ``__call__``.
+``NeuralAdmixture`` -- trainer with the reference's constructor and ``launch_training`` signature
+                     (neural_admixture.py:232-392), driving :class:`Engine` instead of autograd.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import sys
+from collections import OrderedDict
+from pathlib import Path
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .engine import Engine
+from .layout import ModelLayout
+
+logging.basicConfig(stream=sys.stdout, level=logging.INFO, format="%(message)s")
+log = logging.getLogger(__name__)
+
+
+def init_encoder_weights(seed: int, C: int, Hd: int, ks):
+    """Same RNG stream as the reference's module construction under ``torch.manual_seed(seed)``
+    (src/utils.py:107): Linear(C,Hd) then Linear(Hd,k) for ascending k (neural_admixture.py:138-141,29),
+    default nn.Linear init; RMSNorm weight = 1.  Returns the flat `small` vector (nadm.h order)."""
+    torch.manual_seed(seed)
+    lin1 = torch.nn.Linear(C, Hd, bias=True)
+    heads = [torch.nn.Linear(Hd, k, bias=True) for k in sorted(ks)]
+    parts = [torch.ones(C), lin1.weight.detach().reshape(-1), lin1.bias.detach()]
+    for h in heads:
+        parts += [h.weight.detach().reshape(-1), h.bias.detach()]
+    return torch.cat(parts).to(torch.float32).numpy().copy()
+
+
+class Q_P:
+    """Parameter container / inference facade.  Not an nn.Module: the math lives in the HIP kernels."""
+
+    def __init__(self, hidden_size: int, num_features: int, V: Optional[torch.Tensor] = None, P: Optional[torch.Tensor] = None,
+                 ks_list: List[int] = [], is_train: bool = True, engine: Optional[Engine] = None):
+        self.hidden_size, self.num_features = int(hidden_size), int(num_features)
+        self.ks_list = [int(k) for k in ks_list]
+        self.engine = engine
+        self._pending = None
+        if engine is None and V is not None:
+            self._pending = {"V": V}
+
+    # ---- reference-compatible export (keys measured in SURVEY.md section 5) ----
+    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        e, L = self.engine, self.engine.lay
+        sm = e.small.detach().cpu()
+        h = L.heads
+        sd = OrderedDict()
+        sd["V"] = e.V().detach().cpu().contiguous()
+        sd["batch_norm.weight"] = sm[h.g_off: h.g_off + L.C].clone()
+        sd["common_encoder.0.weight"] = sm[h.w1_off: h.w1_off + L.Hd * L.C].view(L.Hd, L.C).clone()
+        sd["common_encoder.0.bias"] = sm[h.b1_off: h.b1_off + L.Hd].clone()
+        for i, k in enumerate(L.ks):
+            sd[f"multihead_encoder.heads.{i}.weight"] = sm[h.wk_off[i]: h.wk_off[i] + k * L.Hd].view(k, L.Hd).clone()
+            sd[f"multihead_encoder.heads.{i}.bias"] = sm[h.bk_off[i]: h.bk_off[i] + k].clone()
+        for i in range(len(L.ks)):
+            sd[f"decoders.decoders.{i}.weight"] = e.P(i).detach().cpu().contiguous()
+        return sd
+
+    def load_state_dict(self, sd, device: Optional[torch.device] = None, max_batch: int = 1024):
+        """Build an inference engine from a reference-format state dict (no decoders needed)."""
+        V = sd["V"].float()
+        M, C = V.shape
+        dev = device or torch.device("cuda:0")
+        self.engine = Engine(M, C, self.hidden_size, self.ks_list, dev, max_batch)
+        parts = [sd["batch_norm.weight"], sd["common_encoder.0.weight"].reshape(-1), sd["common_encoder.0.bias"]]
+        for i in range(len(self.ks_list)):
+            parts += [sd[f"multihead_encoder.heads.{i}.weight"].reshape(-1), sd[f"multihead_encoder.heads.{i}.bias"]]
+        small = torch.cat([p.float().cpu() for p in parts]).numpy()
+        P = np.zeros((sum(self.ks_list), M), dtype=np.float32)
+        for i, k in enumerate(self.ks_list):
+            key = f"decoders.decoders.{i}.weight"
+            if key in sd:
+                o = sum(self.ks_list[:i])
+                P[o:o + k] = sd[key].float().cpu().numpy().T
+        self.engine.load_params(V.cpu().numpy(), P, small)
+        return self
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def __call__(self, x: torch.Tensor):
+        """x uint8 [b,M] (CPU or GPU) -> (list of Q_k [b,k], None).  Mirrors inference-mode forward
+        (neural_admixture.py:157-177 with _return_infer)."""
+        e = self.engine
+        b = x.shape[0]
+        e.pack_from_host(x.cpu().contiguous())
+        idx = torch.arange(b, dtype=torch.int32, device=e.device)
+        return e.infer_q(idx, b), None
+
+    def save_config(self, name: str, save_dir: str) -> None:
+        cfg = {"ks": self.ks_list, "num_features": self.num_features, "hidden_size": self.hidden_size, "activation": "relu"}
+        with open(Path(save_dir) / f"{name}_config.json", "w") as fb:
+            json.dump(cfg, fb)
+        log.info("    Configuration file saved.")
+
+
+def hudsons_fst(p1: torch.Tensor, p2: torch.Tensor) -> float:
+    """neural_admixture.py:532-553."""
+    num = torch.mean((p1 - p2) ** 2)
+    den = torch.mean(p1 * (1 - p2) + p2 * (1 - p1)) + 1e-7
+    return (num / den).item()
+
+
+class NeuralAdmixture:
+    """Trainer mirror (constructor signature of neural_admixture.py:248-249)."""
+
+    def __init__(self, k, epochs, batch_size, learning_rate, device, seed, num_gpus, master, pack2bit=None,
+                 min_k=None, max_k=None, supervised_loss_weight=100, loss_mode: str = "logged"):
+        self.k, self.min_k, self.max_k = k, min_k, max_k
+        self.ks_list = [int(k)] if k is not None else list(range(int(min_k), int(max_k) + 1))
+        self.num_gpus, self.device, self.master, self.seed = num_gpus, device, master, int(seed)
+        self.epochs = int(epochs)
+        self.global_batch = int(batch_size)
+        self.batch_size = int(batch_size) // num_gpus if num_gpus > 0 else int(batch_size)   # :287
+        self.lr = float(learning_rate)
+        self.loss_mode = loss_mode       # "logged": loss only on epochs that print it (:416); "always": every step
+        self.epoch_losses: dict = {}
+
+    # ---- batch order (src/loaders.py:8-35; sampler objects are torch's own) ----
+    def _world(self):
+        import torch.distributed as dist
+        if self.num_gpus > 1 and dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(), dist.get_rank()
+        return 1, 0
+
+    def launch_training(self, P, data, hidden_size, num_features, V, M, N, pops=None):
+        """P torch [sum(ks), M]; data uint8 CPU [N,M] (unpacked; this method packs the rank's rows);
+        V torch [M,C].  Returns (Qs, Ps, model) like neural_admixture.py:392,530 (numpy lists on master)."""
+        if pops is not None:
+            raise NotImplementedError("supervised mode (pops) is not on the accelerated path yet")
+        from torch.utils.data import RandomSampler
+        from torch.utils.data.distributed import DistributedSampler
+        world, rank = self._world()
+        dev = self.device
+        C = int(num_features)
+        infer_b = min(N, 1024)
+        eng = Engine(M, C, hidden_size, self.ks_list, dev, max(self.batch_size, infer_b))
+        self.engine = eng
+        small = init_encoder_weights(self.seed, C, hidden_size, self.ks_list)
+        eng.load_params(V.detach().cpu().numpy(), P.detach().cpu().numpy(), small)
+
+        if world > 1:
+            shard = np.asarray(list(iter(DistributedSampler(range(N), num_replicas=world, rank=rank, shuffle=True, seed=self.seed))),
+                               dtype=np.int64)            # set_epoch never called (loaders.py:27): fixed shard
+            eng.pack_from_host(data, rows=shard)
+            n_local = len(shard)
+        else:
+            shard = None
+            eng.pack_from_host(data)
+            n_local = N
+            generator = torch.Generator().manual_seed(self.seed)     # neural_admixture.py:283
+            sampler = RandomSampler(range(N), generator=generator)
+
+        if self.master:
+            log.info("")
+            log.info("    Starting training...")
+            log.info("")
+        b = self.batch_size
+        seq = torch.arange(n_local, dtype=torch.int32, device=dev)
+        for epoch in range(self.epochs):
+            logged = (epoch % 5 == 0)
+            with_loss = logged or self.loss_mode == "always"
+            if world > 1:
+                order = seq                                # rows are stored in shard order
+            else:
+                order = torch.as_tensor(np.asarray(list(iter(sampler)), dtype=np.int32)).to(dev)
+            for s in range(0, n_local, b):
+                bb = min(b, n_local - s)
+                if world > 1:
+                    eng.train_step_ddp(order[s:s + bb], bb, self.lr, world, with_loss)
+                else:
+                    eng.train_step(order[s:s + bb], bb, self.lr, with_loss)
+            if with_loss:
+                loss_acc, _ = eng.read_loss(reset=True)
+                self.epoch_losses[epoch] = loss_acc
+                if logged and self.master:
+                    log.info(f"            Loss in epoch {epoch:3d} on device {dev} is {loss_acc:,.0f}")
+
+        # ---- final Q: sequential batches of <=1024, encoder only (:369-383) ----
+        Qloc = [[] for _ in self.ks_list]
+        for s in range(0, n_local, infer_b):
+            bb = min(infer_b, n_local - s)
+            for h, q in enumerate(eng.infer_q(seq[s:s + bb], bb)):
+                Qloc[h].append(q)
+        Qloc = [torch.cat(q, dim=0) for q in Qloc]
+        if world > 1:
+            import torch.distributed as dist
+            Qs = []
+            for h, q in enumerate(Qloc):
+                bufs = [torch.empty_like(q) for _ in range(world)]
+                dist.all_gather(bufs, q)
+                shards = [torch.empty(n_local, dtype=torch.int64, device=dev) for _ in range(world)]
+                dist.all_gather(shards, torch.as_tensor(shard, device=dev))
+                full = torch.empty((N, q.shape[1]), dtype=q.dtype, device=dev)
+                for r in range(world):
+                    full[shards[r]] = bufs[r]
+                Qs.append(full)
+        else:
+            Qs = Qloc
+        if self.master:
+            log.info("")
+            log.info("    Training finished!")
+            log.info("")
+        self.raw_model = Q_P(hidden_size, C, ks_list=self.ks_list, engine=eng)
+        self.display_divergences()
+        if self.master:
+            Ps = [eng.P(h).detach().cpu().numpy().copy() for h in range(len(self.ks_list))]
+            Qs = [q.cpu().numpy() for q in Qs]
+        else:
+            Ps, Qs = [], []
+        return Qs, Ps, self.raw_model
+
+    def display_divergences(self) -> None:
+        """Pairwise Hudson Fst between estimated populations (neural_admixture.py:476-509)."""
+        if not self.master:
+            return
+        for i, k in enumerate(self.ks_list):
+            dec = self.engine.P(i)
+            header = '\t'.join([f'Pop{p}' for p in range(k - 1)])
+            log.info("    Results:")
+            log.info(f'\n            Fst divergences between estimated populations: (K = {k})')
+            log.info("")
+            log.info(f'                \t{header}')
+            log.info('            Pop0')
+            for j in range(1, k):
+                out = f'            Pop{j}'
+                for l in range(j):
+                    out += f"\t{hudsons_fst(dec[:, l], dec[:, j]):0.3f}"
+                log.info(out)
+            log.info("\n")

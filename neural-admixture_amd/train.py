@@ -1,0 +1,87 @@
+"""Drop-in for ``neural_admixture.model.train.train`` (train.py:19-149): same positional signature,
+same returns ``(Ps, Qs, model)``.  PCA-space GMM decoder init stays Python/sklearn (as the
+north star asks); packing, the step loop and the final-Q pass run on the MI355X engine."""
+from __future__ import annotations
+
+import logging
+import sys
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .model import NeuralAdmixture
+from .report import loglikelihood_packed
+
+logging.basicConfig(stream=sys.stdout, level=logging.INFO, format="%(message)s")
+log = logging.getLogger(__name__)
+
+
+def gmm_p_init(data_np: np.ndarray, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_components: int, seed: int) -> np.ndarray:
+    """P_init [sum(ks), M] = clip(GMM means @ V, 5e-6, 1-5e-6) in the PCA subspace (train.py:49-68).
+    Note the projection keeps missing (3) as 1.5, exactly like the reference (train.py:52)."""
+    from sklearn.mixture import GaussianMixture
+    N = data_np.shape[0]
+    X_pca = np.zeros((N, n_components), dtype=np.float32)
+    for i in range(0, N, 1024):
+        X_pca[i:i + 1024] = (data_np[i:i + 1024].astype(np.float32) / 2) @ V_CM.T
+    X_pca = X_pca.astype("float64")
+    ks = [K] if K is not None else list(range(min_k, max_k + 1))
+    Ps = []
+    for k in ks:
+        gmm = GaussianMixture(n_components=k, n_init=5, init_params="k-means++", tol=1e-4, covariance_type="full",
+                              max_iter=100, random_state=seed).fit(X_pca)
+        Ps.append(np.clip(gmm.means_ @ V_CM, 5e-6, 1 - 5e-6))
+    return np.concatenate(Ps, axis=0)
+
+
+def train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int, data: torch.Tensor, device: torch.device,
+          num_gpus: int, hidden_size: int, master: bool, V: np.ndarray, pops, min_k: int = None, max_k: int = None,
+          n_components: int = None):
+    """See module docstring.  ``data`` uint8 [N,M] CPU tensor; ``V`` numpy [C,M] (RSVD output,
+    svd.py:83); returns Ps (list of [M,k] float32), Qs (list of [N,k] float32), model."""
+    if pops is not None:
+        raise NotImplementedError("supervised mode (pops) is not on the accelerated path yet")
+    if device.type != "cuda":
+        raise RuntimeError("neural_admixture_amd.train requires a ROCm GPU device; the CPU path is the reference's own")
+    N, M = data.shape
+    if n_components is None:
+        n_components = V.shape[0]
+    total_K = K if K is not None else sum(range(min_k, max_k + 1))
+    if master:
+        log.info("")
+        log.info("    Running Gaussian Mixture in PCA subspace...")
+        log.info("")
+        P = gmm_p_init(data.numpy(), V, K, min_k, max_k, n_components, seed)
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    if num_gpus > 1 and dist.is_available() and dist.is_initialized():
+        if master:
+            P_init = torch.as_tensor(P, dtype=torch.float32, device=device).contiguous()
+            Vt = torch.as_tensor(V.T, dtype=torch.float32, device=device).contiguous()
+            log.info("    Broadcasting to all GPUs...")
+        else:
+            P_init = torch.empty((total_K, M), dtype=torch.float32, device=device)
+            Vt = torch.empty((M, n_components), dtype=torch.float32, device=device)
+        dist.broadcast(P_init, src=0)          # train.py:109
+        dist.broadcast(Vt, src=0)              # train.py:110
+        dist.barrier()
+        if master:
+            log.info("    Finished broadcasting!")
+    else:
+        P_init = torch.as_tensor(P, dtype=torch.float32).contiguous()
+        Vt = torch.as_tensor(V.T, dtype=torch.float32).contiguous()
+
+    model = NeuralAdmixture(K, epochs, batch_size, learning_rate, device, seed, num_gpus, master, None, min_k, max_k)
+    Qs, Ps, raw = model.launch_training(P_init, data, hidden_size, Vt.shape[1], Vt, M, N, pops)
+
+    if master:
+        ks = [K] if K is not None else list(range(min_k, max_k + 1))
+        for i, k in enumerate(ks):
+            logl = loglikelihood_packed(model.engine, data, Ps[i], Qs[i])
+            if K is not None:
+                log.info(f"    Log-likelihood: {logl:2f}.")
+            else:
+                log.info(f"    Log-likelihood for K={k}: {logl:2f}.")
+    return Ps, Qs, raw
