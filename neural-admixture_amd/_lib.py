@@ -5,6 +5,10 @@ raised (the reference raises RuntimeError through TORCH_CHECK, pack2bit.cu:67-76
 import ctypes as C
 import os
 
+# torch must load first: it bundles its own libamdhip64.so.7, and the HIP runtime has to be the one
+# torch initialised (same soname as /opt/rocm's; whichever is loaded first serves both).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libnadm.so")
 

@@ -379,8 +379,15 @@ extern "C" int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx
     hipStream_t st = (hipStream_t)stream;
 #define ENC_CASE(cp)                                                                                                   \
     case cp:                                                                                                           \
-        if (hipFuncSetAttribute((const void*)encode_fwd_kernel<cp>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
-                                (int)lds) != hipSuccess) return fail("nadm_encode_fwd: cannot raise dynamic LDS limit"); \
+        if (lds > 48 * 1024) {                                                                                         \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_fwd_kernel<cp>),            \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+            if (e != hipSuccess) {                                                                                     \
+                snprintf(err_buf(), 512, "nadm_encode_fwd: cannot raise dynamic LDS limit to %zu: %s", lds,            \
+                         hipGetErrorString(e));                                                                        \
+                return 1;                                                                                              \
+            }                                                                                                          \
+        }                                                                                                              \
         hipLaunchKernelGGL((encode_fwd_kernel<cp>), grid, block, lds, st, xp, ld, idx, b, M, V, zpart, rpb);           \
         break;
     switch (CP) {

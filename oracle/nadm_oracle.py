@@ -29,6 +29,24 @@ RMS_EPS = 1e-8            # torch.nn.RMSNorm(eps=1e-8), neural_admixture.py:135
 BETA1, BETA2, ADAM_EPS = 0.9, 0.95, 1e-8   # neural_admixture.py:204 (torch.optim.Adam defaults eps)
 
 
+class precision64:
+    """Context manager: run the restatement in float64 (tests use it as a rounding-free yardstick to
+    tell accumulated fp32 rounding from a real discrepancy).  Not used for the golden comparisons."""
+
+    def __enter__(self):
+        g = globals()
+        self._saved = (g["F32"], g["BCE_EPS"], g["LOG_CLAMP"])
+        g["F32"] = np.float64
+        g["BCE_EPS"] = np.float64(1e-12)
+        g["LOG_CLAMP"] = np.float64(-100.0)
+        return self
+
+    def __exit__(self, *exc):
+        g = globals()
+        g["F32"], g["BCE_EPS"], g["LOG_CLAMP"] = self._saved
+        return False
+
+
 # --------------------------------------------------------------------------------------------
 # 2-bit packing  (src/utils_c/pack2bit.cu:10-36 pack, :38-62 unpack)
 # --------------------------------------------------------------------------------------------
