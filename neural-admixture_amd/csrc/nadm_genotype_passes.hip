@@ -14,6 +14,8 @@
 #include "nadm_common.h"
 #include "../../include/nadm.h"
 #include "nadm_host.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace nadm {
 
@@ -333,8 +335,264 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(
     }
 }
 
+
+// =================================================================================================
+// pass 2, matrix-core version (KP <= 16): fp32 MFMA 16x16x4 for R^T = P.Q^T and dQ^T = P^T.dR^T,
+// VALU for the per-genotype BCE algebra and for dP = dR^T.Q.
+//
+//   tile = 16 SNPs x 16 samples, D layout of v_mfma_f32_16x16x4_f32: lane l holds rows 4(l>>4)+r,
+//   column l&15.  With rows = SNPs and columns = samples:
+//     * a lane's 4 D registers are 4 CONSECUTIVE SNPs of ONE sample = exactly one packed byte,
+//     * the dR registers are directly the B operand (B[k = SNP (l>>4, r)][col = sample l&15]) of
+//       dQ^T += P^T.dR^T, which the matrix core reduces over SNPs (no cross-lane traffic),
+//     * dP reduces over samples = over the low lane bits, which MFMA cannot do from this layout; it
+//       runs on the VALU into lane-local accumulators [tile][4 SNPs][KP] that persist for the whole
+//       sample loop and are reduced over the 16 sample-lanes ONCE per block (DPP).
+//   f32-input MFMA is bit-for-bit an fmaf chain, so numerics equal the VALU kernel up to summation
+//   order (cdna_hip_programming.md section 3).
+//
+//   block = 16 waves (1024 threads) = one block per CU at 4 waves/SIMD (<=128 VGPRs);
+//   wave w owns NTW tiles: SNPs  snp_wave0 + 8a*(NTW/2).. : for NTW=2 tile t, row (a,r) <-> SNP
+//   8a + 4t + r, so the lane reads ONE ushort per sample (tile 0 = low byte, tile 1 = high byte).
+//   X / Q tiles of 32 samples are double-buffered in LDS and prefetched one tile ahead; dQ partials
+//   of the 16 waves are combined through LDS per 32-sample tile and written as one [b,KP] slab
+//   per chunk (deterministic fixed-order sums everywhere).
+// =================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CTRL>
+__device__ __forceinline__ float row_xchg_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {     // sum over the 16 lanes of a DPP row, in all lanes
+    v = row_xchg_add<0xB1>(v);
+    v = row_xchg_add<0x4E>(v);
+    v = row_xchg_add<0x141>(v);
+    v = row_xchg_add<0x140>(v);
+    return v;
+}
+
+constexpr int MF_MAXW = 16;
+constexpr int mf_waves(int kp) { return (kp == 8 || kp == 16) ? 12 : 16; }        // 12 waves -> 168-VGPR budget at 3 waves/SIMD (KP=8 keeps 64 dP accumulators)
+constexpr int MF_RS_PAD = 16;       // LDS row stride of the X tile = row bytes + 16 (16 B aligned, de-phased banks)
+constexpr int mf_ntw(int kp) { return kp <= 8 ? 2 : 1; }            // 16-SNP tiles per wave (dP accumulators: NTW*4*KP regs)
+constexpr int mf_chunk_snps(int kp) { return mf_waves(kp) * 16 * mf_ntw(kp); }
+
+// gradient w.r.t. the pre-clamp reconstruction and (optionally) the BCE loss term of one genotype.
+// cf = float(code) with missing already mapped to 0, so x = cf/2.
+// loss uses one log: x=0 -> log(1-r), x=1 -> log r, x=.5 -> .5*log(r(1-r)); the -100 clamps of the two
+// separate terms can only bind when r is exactly 0 or 1, where the merged form gives the same value.
+template <bool LOSS>
+__device__ __forceinline__ float bce_elem(float r_raw, float cf, float& lossacc) {
+    const float r = __builtin_amdgcn_fmed3f(r_raw, 0.f, 1.f);
+    const float omr = 1.f - r;
+    const float den_raw = omr * r;
+    const float g = fmaf(-0.5f, cf, r) * __builtin_amdgcn_rcpf(fmaxf(den_raw, 1e-12f));
+    if constexpr (LOSS) {
+        const bool is1 = (cf == 1.f);
+        const float t = (cf == 2.f) ? r : (is1 ? den_raw : omr);
+        const float w = is1 ? 0.5f * 0.69314718055994530942f : 0.69314718055994530942f;
+        lossacc -= fmaxf(__builtin_amdgcn_logf(t) * w, is1 ? -50.f : -100.f);
+    }
+    return (r == r_raw) ? g : 0.f;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// acc.xy += s.x * q.xy   (packed FMA, src0 low half broadcast to both lanes of the pair)
+__device__ __forceinline__ void pk_fma_bcast(f32x2& acc, const f32x2 s, const f32x2 q) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(s), "v"(q));
+}
+
+template <int KP, bool LOSS>
+__global__ __launch_bounds__(64 * mf_waves(KP)) void decode_bce_mfma_kernel(
+    const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
+    const float* __restrict__ P, const float* __restrict__ Q, int SP,
+    float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart) {
+    constexpr int KQ = KP / 4;
+    constexpr int NTW = mf_ntw(KP);
+    constexpr int MF_WAVES = mf_waves(KP);
+    constexpr int RB = MF_WAVES * 4 * NTW;              // packed bytes per row per block (96 or 64)
+    constexpr int RS = RB + MF_RS_PAD;
+    constexpr int PPR = RB / 16;                         // 16 B pieces per row
+    __shared__ __attribute__((aligned(16))) uint8_t s_x[2][TS * RS];
+    __shared__ __attribute__((aligned(16))) float s_q[2][TS * KP];
+    __shared__ __attribute__((aligned(16))) float s_dq[MF_WAVES][TS * KP];
+    __shared__ float s_loss[MF_WAVES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int a = lane >> 4, n = lane & 15;
+    const int64_t chunk = blockIdx.x;
+    const int64_t byte0 = chunk * RB;
+    const int64_t snp_wave0 = chunk * mf_chunk_snps(KP) + wave * (16 * NTW);
+    // SNP of (tile t, row-block a', r'):  snp_wave0 + 4*NTW*a' + 4*t + r'
+    auto snp_of = [&](int t, int ab, int r) -> int64_t { return snp_wave0 + 4 * NTW * ab + 4 * t + r; };
+    auto ldP = [&](int64_t m, int k) -> float { return (m < M && k < KP) ? P[m * KP + k] : 0.f; };
+
+    // ---- resident MFMA operands built from P (one-off, straight from global) ----
+    float pa_r[NTW][KQ];        // R^T = P.Q^T   : A[row = SNP n][k = a + 4j]
+    float pa_q[NTW][4];         // dQ^T += P^T.dR: A[row = k = n][kk = SNP (a, r)]
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) pa_r[t][j] = ldP(snp_of(t, n >> 2, n & 3), a + 4 * j);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pa_q[t][r] = ldP(snp_of(t, a, r), n);
+    }
+    f32x2 dp[NTW][4][KP / 2];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < KP / 2; ++k) dp[t][r][k] = (f32x2){0.f, 0.f};
+    float lossacc = 0.f;
+
+    // ---- X / Q tile staging (threads 0..TS*PPR-1 move one 16 B piece each) ----
+    uint4 stage = make_uint4(0, 0, 0, 0);
+    auto issue = [&](int i0) {
+        if (tid < TS * PPR) {
+            const int r = tid / PPR, c16 = tid % PPR;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            const int64_t off = byte0 + c16 * 16;
+            if (i0 + r < b && off < ld) {
+                const int64_t row = idx[i0 + r];
+                v = *reinterpret_cast<const uint4*>(xp + row * ld + off);
+            }
+            stage = v;
+        }
+    };
+    auto commit = [&](int buf) {
+        if (tid < TS * PPR) {
+            const int r = tid / PPR, c16 = tid % PPR;
+            *reinterpret_cast<uint4*>(&s_x[buf][r * RS + c16 * 16]) = stage;
+        }
+    };
+    auto load_q = [&](int i0, int buf) {
+        if (tid < TS * KP) {
+            const int r = tid / KP, k = tid % KP;
+            s_q[buf][tid] = (i0 + r < b) ? Q[(int64_t)(i0 + r) * SP + k] : 0.f;
+        }
+    };
+    static_assert(TS * KP <= 64 * MF_WAVES, "Q tile must fit one pass of the block");
+
+    issue(0);
+    commit(0);
+    load_q(0, 0);
+    __syncthreads();
+
+    const int ntiles = (b + TS - 1) / TS;
+    for (int tl = 0; tl < ntiles; ++tl) {
+        const int cur = tl & 1;
+        const int i0 = tl * TS;
+        const int nt = min(TS, b - i0);
+        if (tl + 1 < ntiles) issue(i0 + TS);
+
+#pragma unroll 1
+        for (int stl = 0; stl < TS / 16; ++stl) {
+            if (i0 + 16 * stl < b) {                                  // block-uniform
+                const int srow = 16 * stl + n;                          // this lane's sample row in the tile
+                float qb[KQ];                                           // B of R^T: Q[sample n][k = a + 4j]
+#pragma unroll
+                for (int j = 0; j < KQ; ++j) qb[j] = s_q[cur][srow * KP + a + 4 * j];
+                f32x2 q8[KP / 2];                                       // this lane's sample: all KP columns
+#pragma unroll
+                for (int j = 0; j < KQ; ++j) {
+                    const float4 v = *reinterpret_cast<const float4*>(&s_q[cur][srow * KP + 4 * j]);
+                    q8[2 * j] = (f32x2){v.x, v.y}; q8[2 * j + 1] = (f32x2){v.z, v.w};
+                }
+                uint32_t bits;                                          // NTW bytes: 4 SNPs x NTW tiles of this sample
+                if constexpr (NTW == 2) bits = *reinterpret_cast<const uint16_t*>(&s_x[cur][srow * RS + wave * 8 + 2 * a]);
+                else bits = s_x[cur][srow * RS + wave * 4 + a];
+                bits &= ~((bits & (bits >> 1) & 0x5555u) * 3u);         // missing (3) -> 0: x = 0 in input and target
+
+                f32x4 dq = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) {
+                    f32x4 D = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < KQ; ++j) D = __builtin_amdgcn_mfma_f32_16x16x4f32(pa_r[t][j], qb[j], D, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float cf = (float)((bits >> (8 * t + 2 * r)) & 3u);
+                        f32x2 dR2;
+                        dR2.x = bce_elem<LOSS>(D[r], cf, lossacc);
+#pragma unroll
+                        for (int k = 0; k < KP / 2; ++k) pk_fma_bcast(dp[t][r][k], dR2, q8[k]);
+                        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(pa_q[t][r], dR2.x, dq, 0, 0, 0);
+                    }
+                }
+                // dQ^T tile: lane (a, n) holds k = 4a + r', sample n  ->  s_dq[wave][sample][k]
+                if (4 * a < KP)
+                    *reinterpret_cast<float4*>(&s_dq[wave][srow * KP + 4 * a]) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+            }
+        }
+        __syncthreads();
+        if (tid < nt * KP) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < MF_WAVES; ++w) s += s_dq[w][tid];
+            const int r = tid / KP, k = tid % KP;
+            dqpart[(chunk * b + i0 + r) * KP + k] = s;
+        }
+        if (tl + 1 < ntiles) {
+            commit(cur ^ 1);
+            load_q(i0 + TS, cur ^ 1);
+        }
+        __syncthreads();
+    }
+
+    // ---- dP: reduce the lane-local accumulators over the 16 sample lanes, lane n==0 stores ----
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float o[KP];
+#pragma unroll
+            for (int k = 0; k < KP / 2; ++k) { o[2 * k] = row16_sum(dp[t][r][k].x); o[2 * k + 1] = row16_sum(dp[t][r][k].y); }
+            const int64_t m = snp_of(t, a, r);
+            if (n == 0 && m < M) {
+#pragma unroll
+                for (int k = 0; k < KP; k += 4)
+                    *reinterpret_cast<float4*>(dP + m * KP + k) = make_float4(o[k], o[k + 1], o[k + 2], o[k + 3]);
+            }
+        }
+    }
+    if constexpr (LOSS) {
+        const float s = wave_sum_lane63(lossacc);
+        if (lane == 63) s_loss[wave] = s;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < MF_WAVES; ++w) tot += s_loss[w];
+            losspart[chunk] = tot;
+        }
+    }
+}
+
 // ---- SNPs per lane in pass 2 as a function of the padded head width (register budget ~128) ----
 constexpr int dec_spl(int kp) { return kp <= 8 ? 8 : (kp <= 16 ? 4 : (kp <= 32 ? 2 : 1)); }
+
+static bool use_mfma_decode() {
+    static const bool v = [] {
+        const char* e = getenv("NADM_DECODE_IMPL");
+        return !(e && strcmp(e, "valu") == 0);
+    }();
+    return v;
+}
+
+template <int KP>
+static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, const float* P,
+                              const float* Q, int SP, float* dP, float* dqpart, float* losspart, int with_loss,
+                              hipStream_t st) {
+    const int64_t chunks = (M + mf_chunk_snps(KP) - 1) / mf_chunk_snps(KP);
+    dim3 grid((unsigned)chunks), block(64 * mf_waves(KP));
+    if (with_loss)
+        hipLaunchKernelGGL((decode_bce_mfma_kernel<KP, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
+    else
+        hipLaunchKernelGGL((decode_bce_mfma_kernel<KP, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
+    return check_launch("decode_bce_mfma");
+}
 
 template <int KP>
 static int launch_decode(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, const float* P,
@@ -357,6 +615,7 @@ using namespace nadm;
 extern "C" int64_t nadm_encode_chunks(int64_t M) { return (M + ENC_CHUNK_SNPS - 1) / ENC_CHUNK_SNPS; }
 
 extern "C" int64_t nadm_decode_chunks(int64_t M, int kp) {
+    if (kp <= 16 && use_mfma_decode()) return (M + mf_chunk_snps(kp) - 1) / mf_chunk_snps(kp);
     const int spl = dec_spl(kp);
     return (M + 256 * spl - 1) / (256 * spl);
 }
@@ -406,6 +665,15 @@ extern "C" int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx
     if (b <= 0 || M <= 0) return fail("nadm_decode_bce: empty batch or M");
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_decode_bce: ld must be a multiple of 16 and >= ceil(M/4)");
     hipStream_t st = (hipStream_t)stream;
+    if (kp <= 16 && use_mfma_decode()) {
+        switch (kp) {
+            case 4: return launch_decode_mfma<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
+            case 8: return launch_decode_mfma<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
+            case 12: return launch_decode_mfma<12>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
+            case 16: return launch_decode_mfma<16>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
+            default: return fail("nadm_decode_bce: unsupported padded K (use nadm_pad_k)");
+        }
+    }
     switch (kp) {
         case 4: return launch_decode<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
         case 8: return launch_decode<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
