@@ -24,8 +24,12 @@ def _stream():
 
 
 class Engine:
+    # tests/ subclass this with the oracle behind the kernel-calling methods to exercise the
+    # distributed orchestration on CPU/gloo; the product class itself refuses to run without a GPU.
+    _CPU_TEST_DOUBLE = False
+
     def __init__(self, M: int, C_: int, Hd: int, ks: Sequence[int], device: torch.device, max_batch: int):
-        if device.type != "cuda":
+        if device.type != "cuda" and not self._CPU_TEST_DOUBLE:
             raise RuntimeError("neural_admixture_amd.Engine needs a ROCm GPU device (no CPU fallback)")
         self.device = device
         self.lay = L = ModelLayout(M, C_, Hd, ks)

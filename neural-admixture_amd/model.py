@@ -116,6 +116,7 @@ def hudsons_fst(p1: torch.Tensor, p2: torch.Tensor) -> float:
 
 class NeuralAdmixture:
     """Trainer mirror (constructor signature of neural_admixture.py:248-249)."""
+    engine_cls = Engine          # tests swap in an oracle-backed double to run the DDP orchestration on gloo
 
     def __init__(self, k, epochs, batch_size, learning_rate, device, seed, num_gpus, master, pack2bit=None,
                  min_k=None, max_k=None, supervised_loss_weight=100, loss_mode: str = "logged"):
@@ -147,7 +148,7 @@ class NeuralAdmixture:
         dev = self.device
         C = int(num_features)
         infer_b = min(N, 1024)
-        eng = Engine(M, C, hidden_size, self.ks_list, dev, max(self.batch_size, infer_b))
+        eng = self.engine_cls(M, C, hidden_size, self.ks_list, dev, max(self.batch_size, infer_b))
         self.engine = eng
         small = init_encoder_weights(self.seed, C, hidden_size, self.ks_list)
         eng.load_params(V.detach().cpu().numpy(), P.detach().cpu().numpy(), small)

@@ -1,0 +1,82 @@
+"""Oracle-backed test double of neural_admixture_amd.Engine (TEST INFRASTRUCTURE).
+
+Only the kernel-calling primitives are replaced by the numpy oracle; everything else -- the flat
+parameter/gradient layout, train_step_ddp's all-reduce + 1/world scaling, sharding, the final-Q
+gather in NeuralAdmixture.launch_training -- is the product code, which is what the gloo tests cover."""
+import numpy as np
+import torch
+
+from neural_admixture_amd.engine import Engine
+from oracle import nadm_oracle as O
+
+
+class OracleEngine(Engine):
+    _CPU_TEST_DOUBLE = True
+
+    def pack_from_host(self, data_u8, rows=None, chunk_rows=8192):
+        G = data_u8.numpy()
+        self.G = np.ascontiguousarray(G if rows is None else G[np.asarray(rows)])
+        self.xp = torch.zeros((self.G.shape[0], self.ld), dtype=torch.uint8)
+
+    def _params(self) -> O.Params:
+        L, h = self.lay, self.lay.heads
+        sm = self.small.numpy()
+        big = self.big.numpy()
+        V = big[: L.M * L.CP].reshape(L.M, L.CP)[:, : L.C].copy()
+        P = [big[L.p_off[i]: L.p_off[i] + L.M * L.kp[i]].reshape(L.M, L.kp[i])[:, :k].copy() for i, k in enumerate(L.ks)]
+        Wk = [sm[h.wk_off[i]: h.wk_off[i] + k * L.Hd].reshape(k, L.Hd).copy() for i, k in enumerate(L.ks)]
+        bk = [sm[h.bk_off[i]: h.bk_off[i] + k].copy() for i, k in enumerate(L.ks)]
+        return O.Params(V, sm[h.g_off: h.g_off + L.C].copy(), sm[h.w1_off: h.w1_off + L.Hd * L.C].reshape(L.Hd, L.C).copy(),
+                        sm[h.b1_off: h.b1_off + L.Hd].copy(), Wk, bk, P, list(L.ks))
+
+    def forward(self, idx, b):
+        self._idx = idx.numpy().astype(np.int64)[:b]
+        p = self._params()
+        _, _, _, _, Qs = O.encoder_forward(p, O.decode_x(self.G[self._idx]))
+        L = self.lay
+        Q = np.zeros((b, L.SP), dtype=np.float32)
+        for i, k in enumerate(L.ks):
+            Q[:, L.qoff[i]: L.qoff[i] + k] = Qs[i]
+        self.Q[: b * L.SP] = torch.from_numpy(Q.reshape(-1))
+
+    def backward(self, idx, b, with_loss=True, on_decoder_done=None):
+        L, h = self.lay, self.lay.heads
+        loss, g, _ = O.step_grads(self._params(), self.G[self._idx])
+        big = np.zeros(L.n_big, dtype=np.float32)
+        big[: L.M * L.CP].reshape(L.M, L.CP)[:, : L.C] = g["V"]
+        for i, k in enumerate(L.ks):
+            big[L.p_off[i]: L.p_off[i] + L.M * L.kp[i]].reshape(L.M, L.kp[i])[:, :k] = g[f"P{i}"]
+        sm = np.zeros(L.n_small, dtype=np.float32)
+        sm[h.g_off: h.g_off + L.C] = g["g"]
+        sm[h.w1_off: h.w1_off + L.Hd * L.C] = g["W1"].reshape(-1)
+        sm[h.b1_off: h.b1_off + L.Hd] = g["b1"]
+        for i, k in enumerate(L.ks):
+            sm[h.wk_off[i]: h.wk_off[i] + k * L.Hd] = g[f"Wk{i}"].reshape(-1)
+            sm[h.bk_off[i]: h.bk_off[i] + k] = g[f"bk{i}"]
+        self.gbig.copy_(torch.from_numpy(big))
+        if on_decoder_done is not None:
+            on_decoder_done()
+        self.gsmall.copy_(torch.from_numpy(sm))
+        if with_loss:
+            self.loss_acc[0] += loss
+            self.loss_acc[1] = loss
+
+    def adam(self, lr, grad_scale=1.0):
+        self.step_count += 1
+        t = self.step_count
+        bc1, bc2 = 1.0 - O.BETA1 ** t, 1.0 - O.BETA2 ** t
+        for p_, g_, m_, v_, cf in ((self.big, self.gbig, self.mbig, self.vbig, self.lay.clamp_from),
+                                   (self.small, self.gsmall, self.msmall, self.vsmall, None)):
+            g = g_ * np.float32(grad_scale)
+            m_.add_((g - m_) * np.float32(1.0 - O.BETA1))
+            v_.mul_(np.float32(O.BETA2)).add_(g * g * np.float32(1.0 - O.BETA2))
+            den = v_.sqrt() / np.float32(np.sqrt(bc2)) + np.float32(O.ADAM_EPS)
+            p_.sub_(np.float32(lr / bc1) * (m_ / den))
+            if cf is not None:
+                p_[cf:].clamp_(0.0, 1.0)
+
+    def infer_q(self, idx, b):
+        self.forward(idx, b)
+        L = self.lay
+        Q = self.Q[: b * L.SP].view(b, L.SP)
+        return [Q[:, L.qoff[i]: L.qoff[i] + k].clone() for i, k in enumerate(L.ks)]

@@ -1,0 +1,147 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/nadm.h declares,
+argument validation fails loudly without touching a GPU, the host packer is bit-exact, and the
+host-side mirror (layout, initial weights, samplers, signatures, output formats) matches the reference."""
+import ctypes as C
+import inspect
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nadm_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    from neural_admixture_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "nadm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(nadm_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 17
+    raw = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in nadm.h but not exported"
+    assert declared == set(_lib.EXPORTS)               # the Python binding covers the whole header
+    assert _lib.lib.nadm_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    from neural_admixture_amd._lib import lib, check
+    assert [lib.nadm_pad_k(k) for k in (1, 3, 4, 7, 8, 9, 13, 16, 17, 24, 25, 33, 48, 49, 64)] == \
+        [4, 4, 4, 8, 8, 12, 16, 16, 24, 24, 32, 48, 48, 64, 64]
+    assert lib.nadm_pad_k(0) < 0 and lib.nadm_pad_k(65) < 0
+    with pytest.raises(RuntimeError, match="null pointer"):
+        check(lib.nadm_encode_fwd(None, 16, None, 1, 4, None, 8, None, None), "encode_fwd")
+    with pytest.raises(RuntimeError, match="1-based"):
+        buf = torch.zeros(8)
+        p = C.c_void_p(buf.data_ptr())
+        check(lib.nadm_adam(p, p, p, p, 8, 8, 1e-3, 0, 1.0, None), "adam")
+    from neural_admixture_amd._lib import Heads
+    h = Heads()
+    ks = (C.c_int32 * 2)(5, 3)
+    with pytest.raises(RuntimeError, match="ascending"):
+        check(lib.nadm_heads_init(C.byref(h), 8, 64, ks, 2), "heads_init")
+    ks = (C.c_int32 * 1)(65)
+    with pytest.raises(RuntimeError):
+        check(lib.nadm_heads_init(C.byref(h), 8, 64, ks, 1), "heads_init")
+
+
+def test_engine_refuses_cpu_device():
+    import neural_admixture_amd as na
+    with pytest.raises(RuntimeError, match="GPU"):
+        na.Engine(100, 8, 16, [3], torch.device("cpu"), 10)
+    with pytest.raises(RuntimeError, match="GPU"):
+        na.train(1, 8, 1e-3, 3, 0, torch.zeros((4, 100), dtype=torch.uint8), torch.device("cpu"), 0, 16, True, np.zeros((8, 100), np.float32), None)
+
+
+@pytest.mark.parametrize("shape", [(5, 11), (3, 9), (0, 7), (4, 0), (300, 4099), (1, 1)])
+def test_host_packer_bit_exact(shape):
+    from neural_admixture_amd._lib import lib, check, ptr
+    from neural_admixture_amd.layout import ModelLayout
+    rng = np.random.default_rng(sum(shape))
+    Gm = rng.integers(0, 256, size=shape, dtype=np.uint8)         # high bits must be masked
+    N, M = shape
+    ld = max(16, ModelLayout.row_stride(M))
+    src = torch.from_numpy(np.ascontiguousarray(Gm).reshape(N, M)) if N * M else torch.zeros((N, M), dtype=torch.uint8)
+    out = torch.full((max(N, 1), ld), 255, dtype=torch.uint8)
+    if N and M:
+        check(lib.nadm_pack2bit_host(ptr(src), ptr(out), N, M, ld))
+        ref = O.pack2bit(Gm)
+        assert np.array_equal(out.numpy()[:N, :ref.shape[1]], ref)
+        assert not out.numpy()[:N, ref.shape[1]:].any()
+
+
+def test_pack_layout_golden():
+    from neural_admixture_amd._lib import lib, check, ptr
+    d = np.load(f"{G}/pack_layout.npz")
+    for g, pk in ((d["G"], d["packed"]), (d["G_hibits"], d["packed_hibits"])):
+        out = torch.zeros((g.shape[0], 16), dtype=torch.uint8)
+        check(lib.nadm_pack2bit_host(ptr(torch.from_numpy(np.ascontiguousarray(g))), ptr(out), g.shape[0], g.shape[1], 16))
+        assert np.array_equal(out.numpy()[:, :pk.shape[1]], pk)
+
+
+def test_layout_offsets_and_padding():
+    from neural_admixture_amd.layout import ModelLayout
+    L = ModelLayout(1000, 8, 64, [4, 2, 3])             # unsorted input is sorted like NeuralEncoder does (:27)
+    assert L.ks == [2, 3, 4] and L.kp == [4, 4, 4] and L.qoff == [0, 4, 8] and L.SP == 12
+    assert L.n_small == 8 + 64 * 8 + 64 + sum(k * 64 + k for k in (2, 3, 4))
+    assert L.p_off == [8000, 12000, 16000] and L.n_big == 20000 and L.clamp_from == 8000
+    assert ModelLayout.row_stride(1000) == 256 and ModelLayout.row_stride(8451) == 2128
+    offs, tot = L.dq_offsets(10)
+    assert offs[0] == 0 and tot == sum(c * 10 * kp for c, kp in zip(L.dec_chunks, L.kp))
+
+
+def test_initial_weights_match_reference_rng_stream():
+    from neural_admixture_amd.model import init_encoder_weights
+    d = np.load(f"{G}/one_step_multihead.npz")
+    v = init_encoder_weights(int(d["seed"]), 8, int(d["Hd"]), [2, 3, 4])
+    Hd = int(d["Hd"])
+    assert np.all(v[:8] == 1)
+    assert np.array_equal(v[8:8 + Hd * 8].reshape(Hd, 8), d["init_common_encoder_0_weight"])
+    assert np.array_equal(v[8 + Hd * 8: 8 + Hd * 9], d["init_common_encoder_0_bias"])
+    o = 8 + Hd * 9
+    for h, k in enumerate((2, 3, 4)):
+        assert np.array_equal(v[o:o + k * Hd].reshape(k, Hd), d[f"init_multihead_encoder_heads_{h}_weight"])
+        o += k * Hd
+        assert np.array_equal(v[o:o + k], d[f"init_multihead_encoder_heads_{h}_bias"])
+        o += k
+
+
+def test_train_signature_matches_reference():
+    import neural_admixture_amd as na
+    names = list(inspect.signature(na.train).parameters)
+    assert names == ["epochs", "batch_size", "learning_rate", "K", "seed", "data", "device", "num_gpus", "hidden_size",
+                     "master", "V", "pops", "min_k", "max_k", "n_components"]          # train.py:19-21
+    names = list(inspect.signature(na.NeuralAdmixture.__init__).parameters)[1:13]
+    assert names == ["k", "epochs", "batch_size", "learning_rate", "device", "seed", "num_gpus", "master", "pack2bit",
+                     "min_k", "max_k", "supervised_loss_weight"]                        # neural_admixture.py:248-249
+    names = list(inspect.signature(na.NeuralAdmixture.launch_training).parameters)[1:]
+    assert names == ["P", "data", "hidden_size", "num_features", "V", "M", "N", "pops"]  # :324-325
+
+
+def test_gmm_init_matches_reference_demo():
+    """P_init = clip(GMM means @ V) in the PCA subspace, same sklearn call as train.py:49-63."""
+    from neural_admixture_amd.train import gmm_p_init
+    d = np.load(f"{G}/demo_k3.npz")
+    Gm = O.unpack2bit(d["G_packed"], int(d["M"]))
+    P = gmm_p_init(Gm, d["Vt"], 3, None, None, 8, int(d["seed"]))
+    assert np.abs(P - d["P_init"]).max() < 1e-6
+
+
+def test_output_writers(tmp_path):
+    from neural_admixture_amd.io import write_outputs
+    from neural_admixture_amd.model import Q_P
+    Q = np.random.default_rng(0).random((5, 3)).astype(np.float32)
+    P = np.random.default_rng(1).random((7, 3)).astype(np.float32)
+    write_outputs([Q], "run", 3, None, None, tmp_path, [P])
+    assert np.array_equal(np.loadtxt(tmp_path / "run.3.Q", dtype=np.float32), Q)
+    assert np.array_equal(np.loadtxt(tmp_path / "run.3.P", dtype=np.float32), P)
+    first = open(tmp_path / "run.3.Q").readline().split(" ")
+    assert len(first) == 3 and re.fullmatch(r"\d\.\d{18}e[+-]\d{2}", first[0])          # savetxt default '%.18e'
+    Q_P(1024, 8, ks_list=[3]).save_config("run", str(tmp_path))
+    assert json.load(open(tmp_path / "run_config.json")) == {"ks": [3], "num_features": 8, "hidden_size": 1024, "activation": "relu"}
