@@ -23,11 +23,11 @@ namespace nadm {
 // pass 1: Z partial = X[:, chunk] . V[chunk, :]        lane <-> sample, V rows wave-uniform
 // =================================================================================================
 constexpr int ENC_TB = 128;            // bytes of each gathered row per tile  (512 SNPs)
-constexpr int ENC_TILES = 2;           // tiles per chunk -> 1024 SNPs per chunk
+constexpr int ENC_TILES_DEFAULT = 2;   // tiles per chunk -> 1024 SNPs per chunk (4 when paired with the MFMA chunking)
 constexpr int ENC_LDW = ENC_TB / 4 + 1;  // LDS row stride in dwords (+1: lane r reads row r -> conflict-free)
-constexpr int ENC_CHUNK_SNPS = ENC_TB * 4 * ENC_TILES;
+constexpr int ENC_CHUNK_SNPS = ENC_TB * 4 * ENC_TILES_DEFAULT;
 
-template <int CP>
+template <int CP, int ENC_TILES>
 __global__ void encode_fwd_kernel(const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx,
                                   int b, int64_t M, const float* __restrict__ V, float* __restrict__ zpart,
                                   int rows_per_block) {
@@ -108,6 +108,131 @@ __global__ void encode_fwd_kernel(const uint8_t* __restrict__ xp, int64_t ld, co
 #pragma unroll
         for (int c = 0; c < CP; c += 4)
             *reinterpret_cast<float4*>(o + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+    }
+}
+
+// =================================================================================================
+// pass 1, matrix-core version (CP <= 8): Z = X.V on v_mfma_f32_16x16x32_bf16.
+//   X in {0,.5,1} is exact in bf16; V (fp32) is split into three bf16 pieces hi+mid+lo (24 mantissa
+//   bits, so the products are exact and only the fp32 accumulation rounds, like the fp32 kernels).
+//   The 16 MFMA output columns hold [V_hi(8) | V_mid(8)], a second MFMA holds [V_lo(8) | 0]; the three
+//   column groups are added at the end of each 16-sample tile.
+//   A operand = X tile [16 samples x 32 SNPs]: lane (i = l&15, q = l>>4) needs 8 consecutive SNPs of
+//   sample i = 16 packed bits.  Each lane loads ONE 16-byte piece of its gathered row per sample
+//   tile (64 genotypes = the A operands of 8 k-steps; the k-step <-> SNP mapping is chosen so those
+//   bytes are contiguous) straight from HBM -- no LDS staging, no block barrier on the load path --
+//   and expands nibbles (2 genotypes) to bf16 pairs through a 16-entry, conflict-free LDS table.
+//   block = 8 waves, each owning a 256-SNP slice (its V operands stay in 64 VGPRs for the whole
+//   block); grid.y splits the batch.  Partial Z of the 8 waves is combined through LDS per sample
+//   tile (one barrier) and written as one [b,CP] slab per 2048-SNP chunk.
+// =================================================================================================
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int EM_WAVES = 8;
+constexpr int EM_SLICE = 256;                         // SNPs per wave
+constexpr int EM_CHUNK_SNPS = EM_WAVES * EM_SLICE;    // 2048
+constexpr int EM_TILES_PER_BLOCK = 13;                // 208 samples per block (grid.y)
+
+__device__ __forceinline__ uint32_t bf16_trunc_bits(float v) { return __float_as_uint(v) & 0xFFFF0000u; }
+
+template <int CP>
+__global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
+                                                              const int32_t* __restrict__ idx, int b, int64_t M,
+                                                              const float* __restrict__ V, float* __restrict__ zpart) {
+    static_assert(CP <= 8, "two MFMA column groups hold hi|mid and lo|0");
+    __shared__ uint32_t s_lut[16];
+    __shared__ __attribute__((aligned(16))) float s_z[2][EM_WAVES][16 * 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t chunk = blockIdx.x;
+    const int64_t slice0 = chunk * EM_CHUNK_SNPS + wave * EM_SLICE;
+    const int tile_begin = blockIdx.y * EM_TILES_PER_BLOCK;
+    const int tile_end = min((b + 15) / 16, tile_begin + EM_TILES_PER_BLOCK);
+    if (tid < 16) {
+        const uint32_t lo = tid & 3, hi = tid >> 2;
+        const uint32_t blo = lo == 1 ? 0x3F00u : (lo == 2 ? 0x3F80u : 0u);
+        const uint32_t bhi = hi == 1 ? 0x3F00u : (hi == 2 ? 0x3F80u : 0u);
+        s_lut[tid] = blo | (bhi << 16);
+    }
+    // ---- B operands: V rows of this wave's slice, split hi/mid/lo, for the 8 k-steps ----
+    // k-step s, lane (q, j): rows kk = 8q + e  <->  SNP slice0 + 64q + 8s + e ; column j: c = j & 7
+    bf16x8 b1[8], b2[8];
+    {
+        const int c = i & 7;
+        const bool upper = i >= 8;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            uint32_t w1[4], w2[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint32_t p1[2], p2[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int64_t m = slice0 + 64 * q + 8 * s8 + 2 * d + hh;
+                    const float v = (m < M && c < CP) ? V[m * CP + c] : 0.f;
+                    const uint32_t hi = bf16_trunc_bits(v);
+                    const float r1 = v - __uint_as_float(hi);
+                    const uint32_t mid = bf16_trunc_bits(r1);
+                    const float r2 = r1 - __uint_as_float(mid);
+                    const uint32_t lo = bf16_trunc_bits(r2);
+                    p1[hh] = (upper ? mid : hi) >> 16;
+                    p2[hh] = upper ? 0u : (lo >> 16);
+                }
+                w1[d] = p1[0] | (p1[1] << 16);
+                w2[d] = p2[0] | (p2[1] << 16);
+            }
+            b1[s8] = __builtin_bit_cast(bf16x8, make_uint4(w1[0], w1[1], w1[2], w1[3]));
+            b2[s8] = __builtin_bit_cast(bf16x8, make_uint4(w2[0], w2[1], w2[2], w2[3]));
+        }
+    }
+    __syncthreads();
+
+    const int64_t byte_off = chunk * (EM_CHUNK_SNPS / 4) + wave * (EM_SLICE / 4) + 16 * q;
+    const bool col_ok = byte_off < ld;
+    auto row_of = [&](int tile) -> int64_t {
+        const int smp = tile * 16 + i;
+        return (tile < tile_end && smp < b) ? (int64_t)idx[smp] : -1;
+    };
+    auto load_row = [&](int64_t row) -> uint4 {
+        if (row >= 0 && col_ok) return *reinterpret_cast<const uint4*>(xp + row * ld + byte_off);
+        return make_uint4(0, 0, 0, 0);
+    };
+    int64_t row_next = row_of(tile_begin + 1);
+    uint4 cur = load_row(row_of(tile_begin));
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const uint4 nxt = load_row(row_next);
+        row_next = row_of(tile + 2);
+        const uint32_t raw[4] = {cur.x, cur.y, cur.z, cur.w};
+        f32x4_t d1 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, d2 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            const uint32_t h16 = (raw[s8 >> 1] >> (16 * (s8 & 1))) & 0xFFFFu;
+            uint32_t aw[4];
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) aw[p4] = s_lut[(h16 >> (4 * p4)) & 15u];
+            const bf16x8 av = __builtin_bit_cast(bf16x8, make_uint4(aw[0], aw[1], aw[2], aw[3]));
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1[s8], d1, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b2[s8], d2, 0, 0, 0);
+        }
+        // D rows = samples 4q + r, column = i: fold [hi | mid] + [lo | 0] -> columns 0..7
+        const int buf = tile & 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float u = d1[r] + d2[r];
+            u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x128 /*row_ror:8*/, 0xf, 0xf, false));
+            if (i < 8) s_z[buf][wave][(4 * q + r) * 8 + i] = u;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < EM_WAVES; ++w) sum += s_z[buf][w][tid];
+            const int smp = tile * 16 + (tid >> 3), c = tid & 7;
+            if (smp < b && c < CP) zpart[(chunk * b + smp) * CP + c] = sum;
+        }
+        cur = nxt;
     }
 }
 
@@ -612,7 +737,20 @@ static int launch_decode(const uint8_t* xp, int64_t ld, const int32_t* idx, int 
 
 using namespace nadm;
 
-extern "C" int64_t nadm_encode_chunks(int64_t M) { return (M + ENC_CHUNK_SNPS - 1) / ENC_CHUNK_SNPS; }
+static bool use_mfma_encode() {
+    static const bool v = [] {
+        const char* e = getenv("NADM_ENCODE_IMPL");
+        return !(e && strcmp(e, "valu") == 0);
+    }();
+    return v;
+}
+
+// NOTE: the chunk count must not depend on CP (callers size zpart before they pass CP); the MFMA kernel
+// covers CP <= 8 and the VALU kernel writes the same 2048-SNP chunks when it is the fallback.
+extern "C" int64_t nadm_encode_chunks(int64_t M) {
+    if (use_mfma_encode()) return (M + EM_CHUNK_SNPS - 1) / EM_CHUNK_SNPS;
+    return (M + ENC_CHUNK_SNPS - 1) / ENC_CHUNK_SNPS;
+}
 
 extern "C" int64_t nadm_decode_chunks(int64_t M, int kp) {
     if (kp <= 16 && use_mfma_decode()) return (M + mf_chunk_snps(kp) - 1) / mf_chunk_snps(kp);
@@ -636,10 +774,17 @@ extern "C" int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx
     dim3 grid((unsigned)nadm_encode_chunks(M), (unsigned)((b + rpb - 1) / rpb)), block(rpb);
     const size_t lds = (size_t)rpb * ENC_LDW * 4;
     hipStream_t st = (hipStream_t)stream;
-#define ENC_CASE(cp)                                                                                                   \
-    case cp:                                                                                                           \
+    if (CP <= 8 && use_mfma_encode()) {
+        dim3 g2((unsigned)nadm_encode_chunks(M), (unsigned)(((b + 15) / 16 + EM_TILES_PER_BLOCK - 1) / EM_TILES_PER_BLOCK)), b2(512);
+        if (CP == 4) hipLaunchKernelGGL((encode_fwd_mfma_kernel<4>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart);
+        else hipLaunchKernelGGL((encode_fwd_mfma_kernel<8>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart);
+        return check_launch("encode_fwd_mfma");
+    }
+    const bool wide = use_mfma_encode();      // VALU fallback for CP > 8 keeps the 2048-SNP chunking
+#define ENC_LAUNCH(cp, tiles)                                                                                          \
+    {                                                                                                                  \
         if (lds > 48 * 1024) {                                                                                         \
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_fwd_kernel<cp>),            \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_fwd_kernel<cp, tiles>),     \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
             if (e != hipSuccess) {                                                                                     \
                 snprintf(err_buf(), 512, "nadm_encode_fwd: cannot raise dynamic LDS limit to %zu: %s", lds,            \
@@ -647,12 +792,17 @@ extern "C" int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx
                 return 1;                                                                                              \
             }                                                                                                          \
         }                                                                                                              \
-        hipLaunchKernelGGL((encode_fwd_kernel<cp>), grid, block, lds, st, xp, ld, idx, b, M, V, zpart, rpb);           \
+        hipLaunchKernelGGL((encode_fwd_kernel<cp, tiles>), grid, block, lds, st, xp, ld, idx, b, M, V, zpart, rpb);    \
+    }
+#define ENC_CASE(cp)                                                                                                   \
+    case cp:                                                                                                           \
+        if (wide) ENC_LAUNCH(cp, 4) else ENC_LAUNCH(cp, ENC_TILES_DEFAULT)                                             \
         break;
     switch (CP) {
         ENC_CASE(4) ENC_CASE(8) ENC_CASE(12) ENC_CASE(16) ENC_CASE(24) ENC_CASE(32)
         default: return fail("nadm_encode_fwd: unsupported CP (4,8,12,16,24,32)");
     }
+#undef ENC_LAUNCH
 #undef ENC_CASE
     return check_launch("encode_fwd");
 }

@@ -11,7 +11,8 @@
 
 namespace nadm {
 
-constexpr int SJ = 32;          // samples per split in the weight-gradient kernel
+constexpr int SJ = 16;          // samples per split in the weight-gradient kernel
+constexpr int MLP_SB = 4;       // samples per block in mlp_fwd / mlp_bwd_a
 struct DqChunks { int64_t n[NADM_MAX_HEADS]; };   // per-head chunk counts of the dQ partial slabs
 
 // -------------------------------------------------------------------------------------------------
@@ -31,10 +32,13 @@ __device__ __forceinline__ float block_sum(float v, float* s_red /*[NT/64]*/) {
 }
 
 // =================================================================================================
-// mlp_fwd: one block (256 threads) per sample.
+// mlp_fwd: one block (256 threads) per SB consecutive samples (SB = 4: the partial-slab rows of
+// 4 samples are one 128 B line at CP = 8; weights are fetched once per block and reused SB times).
 //   Z = sum_chunks zpart ; Zn = Z * rsqrt(mean(Z^2)+1e-8) * g   (torch.nn.RMSNorm, neural_admixture.py:135,173)
 //   H = relu(Zn W1^T + b1) (:138-140,174) ; per head: softmax(H Wk^T + bk) (:29,48,176)
+// All reductions are fixed-order (bit-reproducible).
 // =================================================================================================
+template <int SB>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(nadm_heads_t hd, const float* __restrict__ small,
                                                       const float* __restrict__ zpart, int64_t n_chunks, int b,
                                                       float* __restrict__ Z, float* __restrict__ rinv,
@@ -42,76 +46,119 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(nadm_heads_t hd, const flo
                                                       float* __restrict__ Q) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int C = hd.C, CP = hd.CP, Hd = hd.Hd, SP = hd.SP;
-    float* s_red = sm;                 // [4]
-    float* s_zn = sm + 4;              // [CP]
-    float* s_h = s_zn + CP;            // [Hd]
-    float* s_logit = s_h + Hd;         // [SP]
+    float* s_grp = sm;                        // [256] float4
+    float* s_zn = s_grp + 1024;               // [SB][CP]
+    float* s_h = s_zn + SB * CP;              // [SB][Hd]
+    float* s_logit = s_h + SB * Hd;           // [SB][SP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = blockIdx.x;
+    const int i0 = blockIdx.x * SB;
+    const int ns = min(SB, b - i0);
+    const int row = SB * CP;                  // floats of the SB samples in one chunk (contiguous)
 
-    // ---- Z = sum over chunks (fixed order: thread-strided, then wave DPP, then 4 waves) ----
-    for (int c = 0; c < CP; ++c) {
-        float a = 0.f;
-        for (int64_t ch = tid; ch < n_chunks; ch += 256) a += zpart[(ch * b + i) * CP + c];
-        const float zsum = block_sum<256>(a, s_red);
-        if (tid == 0) s_zn[c] = zsum;            // holds raw Z for now
+    // ---- Z = sum over chunks: thread (group g, float4 e4) sums chunks g, g+G, ... (independent 16 B loads,
+    //      unrolled so they are in flight together); then a fixed-order combine over the G groups ----
+    {
+        const int row4 = row / 4;             // float4 per chunk row of the SB samples (<= 32)
+        const int G = 256 / row4;
+        const int e4 = tid % row4, g = tid / row4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < G && e4 * 4 < ns * CP) {
+            const float4* src = reinterpret_cast<const float4*>(zpart + (int64_t)i0 * CP) + e4;
+            const int64_t stride4 = (int64_t)b * CP / 4;
+#pragma unroll 8
+            for (int64_t ch = g; ch < n_chunks; ch += G) {
+                const float4 v = src[ch * stride4];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+        }
+        reinterpret_cast<float4*>(s_grp)[tid] = a;
+        __syncthreads();
+        if (tid < row) {
+            float t = 0.f;
+            for (int gg = 0; gg < G; ++gg) t += s_grp[(gg * row4 + tid / 4) * 4 + (tid & 3)];
+            s_zn[tid] = t;                    // raw Z
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (tid == 0) {
+    if (tid < ns) {
+        float* z = s_zn + tid * CP;
         float ms = 0.f;
-        for (int c = 0; c < C; ++c) ms = fmaf(s_zn[c], s_zn[c], ms);
+        for (int c = 0; c < C; ++c) ms = fmaf(z[c], z[c], ms);
         const float ri = 1.0f / sqrtf(ms / (float)C + 1e-8f);
+        const int64_t i = i0 + tid;
         rinv[i] = ri;
         for (int c = 0; c < CP; ++c) {
-            const float z = s_zn[c];
-            Z[(int64_t)i * CP + c] = z;
-            const float zn = (c < C) ? z * ri * small[hd.g_off + c] : 0.f;
-            Zn[(int64_t)i * CP + c] = zn;
-            s_zn[c] = zn;
+            const float zz = z[c];
+            Z[i * CP + c] = zz;
+            const float zn = (c < C) ? zz * ri * small[hd.g_off + c] : 0.f;
+            Zn[i * CP + c] = zn;
+            z[c] = zn;
         }
     }
     __syncthreads();
-    // ---- hidden layer ----
+    // ---- hidden layer: W1 row fetched once, used for the SB samples ----
     const float* W1 = small + hd.w1_off;
     const float* b1 = small + hd.b1_off;
     for (int h = tid; h < Hd; h += 256) {
-        float a = b1[h];
-        for (int c = 0; c < C; ++c) a = fmaf(s_zn[c], W1[h * C + c], a);
-        a = fmaxf(a, 0.f);
-        s_h[h] = a;
-        H[(int64_t)i * Hd + h] = a;
+        float w[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) w[c] = (c < C) ? W1[h * C + c] : 0.f;
+        const float bb = b1[h];
+#pragma unroll
+        for (int s = 0; s < SB; ++s) {
+            float a = bb;
+#pragma unroll
+            for (int c = 0; c < 32; ++c)
+                if (c < C) a = fmaf(s_zn[s * CP + c], w[c], a);
+            a = fmaxf(a, 0.f);
+            s_h[s * Hd + h] = a;
+            if (s < ns) H[(int64_t)(i0 + s) * Hd + h] = a;
+        }
     }
     __syncthreads();
-    // ---- head logits: wave w takes columns w, w+4, ... ----
+    // ---- head logits: each wave takes columns wave, wave+4, ...; a Wk row is read once per SB samples ----
     for (int hh = 0; hh < hd.n_heads; ++hh) {
         const float* Wk = small + hd.wk_off[hh];
         const float* bk = small + hd.bk_off[hh];
         for (int k = wave; k < hd.k[hh]; k += 4) {
-            float a = 0.f;
-            for (int h = lane; h < Hd; h += 64) a = fmaf(s_h[h], Wk[k * Hd + h], a);
-            a = wave_sum_lane63(a);
-            if (lane == 63) s_logit[hd.qoff[hh] + k] = a + bk[k];
+            float a[SB];
+#pragma unroll
+            for (int s = 0; s < SB; ++s) a[s] = 0.f;
+#pragma unroll 4
+            for (int h = lane; h < Hd; h += 64) {
+                const float w = Wk[k * Hd + h];
+#pragma unroll
+                for (int s = 0; s < SB; ++s) a[s] = fmaf(s_h[s * Hd + h], w, a[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < SB; ++s) {
+                const float t = wave_sum_lane63(a[s]);
+                if (lane == 63) s_logit[s * SP + hd.qoff[hh] + k] = t + bk[k];
+            }
         }
     }
     __syncthreads();
-    // ---- softmax per head (serial over k <= 64; one thread per head) ----
-    if (tid < hd.n_heads) {
-        const int k = hd.k[tid], kp = hd.kp[tid], o = hd.qoff[tid];
+    // ---- softmax per (sample, head) ----
+    if (tid < ns * hd.n_heads) {
+        const int s = tid / hd.n_heads, hh = tid % hd.n_heads;
+        const int k = hd.k[hh], kp = hd.kp[hh], o = hd.qoff[hh];
+        float* lg = s_logit + s * SP + o;
         float mx = -INFINITY;
-        for (int j = 0; j < k; ++j) mx = fmaxf(mx, s_logit[o + j]);
+        for (int j = 0; j < k; ++j) mx = fmaxf(mx, lg[j]);
         float sum = 0.f;
-        for (int j = 0; j < k; ++j) { const float e = expf(s_logit[o + j] - mx); s_logit[o + j] = e; sum += e; }
+        for (int j = 0; j < k; ++j) { const float e = expf(lg[j] - mx); lg[j] = e; sum += e; }
         const float inv = 1.0f / sum;
-        for (int j = 0; j < kp; ++j) Q[(int64_t)i * SP + o + j] = (j < k) ? s_logit[o + j] * inv : 0.f;
+        for (int j = 0; j < kp; ++j) Q[(int64_t)(i0 + s) * SP + o + j] = (j < k) ? lg[j] * inv : 0.f;
     }
 }
 
 // =================================================================================================
-// mlp_bwd_a: one block per sample.  dQ = sum_chunks dqpart ; softmax backward ; dH ; relu mask ;
+// mlp_bwd_a: one block per SB samples.  dQ = sum_chunks dqpart ; softmax backward ; dH ; relu mask ;
 // dZn ; RMSNorm backward -> dZ.   (autograd of neural_admixture.py:173-176)
 //   dlogit = Q * (dQ - sum_k dQ*Q) ; dZ = rinv*t - Z*rinv^3*mean_c(t*Z), t = dZn*g ; dg_i = dZn*Z*rinv
 // Block 0 also folds the step's loss partials (double) into loss_acc.
 // =================================================================================================
+template <int SB>
 __global__ __launch_bounds__(256) void mlp_bwd_a_kernel(nadm_heads_t hd, const float* __restrict__ small,
                                                         const float* __restrict__ dqpart, DqChunks dq_chunks, int b,
                                                         const float* __restrict__ Z, const float* __restrict__ rinv,
@@ -122,95 +169,120 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_kernel(nadm_heads_t hd, const f
                                                         double* __restrict__ loss_acc) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int C = hd.C, CP = hd.CP, Hd = hd.Hd, SP = hd.SP;
-    float* s_red = sm;                  // [4]
-    float* s_dl = sm + 4;               // [SP]
-    float* s_dzn = s_dl + SP;           // [CP]
-    float* s_grp = s_dzn + CP;          // [256]
-    const int tid = threadIdx.x;
-    const int i = blockIdx.x;
+    float* s_grp = sm;                        // [256] float4
+    float* s_dl = s_grp + 1024;               // [SB][SP]
+    float* s_dzn = s_dl + SB * SP;            // [SB][CP]
+    float* s_dh = s_dzn + SB * CP;            // [SB][Hd]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * SB;
+    const int ns = min(SB, b - i0);
 
-    // ---- dQ[s] = sum over chunks, per head (each head has its own slab [chunks_h, b, kp_h]);
-    //      threads split (column, chunk-group), then a fixed-order combine ----
+    // ---- dQ = sum over chunks, per head (slab [chunks_h, b, kp_h]; the SB samples' rows are contiguous):
+    //      thread (group g, float4 e4), independent 16 B loads kept in flight by unrolling ----
     {
         int64_t base = 0;
         for (int hh = 0; hh < hd.n_heads; ++hh) {
             const int kp = hd.kp[hh];
+            const int row = SB * kp, row4 = row / 4;           // row4 <= 64
             const int64_t nch = dq_chunks.n[hh];
-            const int G = 256 / kp;                        // kp <= 64 -> G >= 4
-            const int col = tid % kp, grp = tid / kp;
-            float a = 0.f;
-            if (grp < G)
-                for (int64_t ch = grp; ch < nch; ch += G) a += dqpart[base + (ch * b + i) * kp + col];
-            s_grp[tid] = a;
+            const int G = 256 / row4;
+            const int e4 = tid % row4, g = tid / row4;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g < G && e4 * 4 < ns * kp) {
+                const float4* src = reinterpret_cast<const float4*>(dqpart + base + (int64_t)i0 * kp) + e4;
+                const int64_t stride4 = (int64_t)b * kp / 4;
+#pragma unroll 8
+                for (int64_t ch = g; ch < nch; ch += G) {
+                    const float4 v = src[ch * stride4];
+                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                }
+            }
+            reinterpret_cast<float4*>(s_grp)[tid] = a;
             __syncthreads();
-            if (tid < kp) {
+            if (tid < row) {
                 float t = 0.f;
-                for (int g = 0; g < G; ++g) t += s_grp[g * kp + tid];
-                s_dl[hd.qoff[hh] + tid] = t;                // raw dQ for now
+                for (int gg = 0; gg < G; ++gg) t += s_grp[(gg * row4 + tid / 4) * 4 + (tid & 3)];
+                s_dl[(tid / kp) * SP + hd.qoff[hh] + (tid % kp)] = t;      // raw dQ
             }
             __syncthreads();
             base += nch * b * kp;
         }
     }
-    // ---- softmax backward per head ----
-    if (tid < hd.n_heads) {
-        const int k = hd.k[tid], kp = hd.kp[tid], o = hd.qoff[tid];
-        const float* q = Q + (int64_t)i * SP + o;
+    // ---- softmax backward per (sample, head) ----
+    if (tid < ns * hd.n_heads) {
+        const int s = tid / hd.n_heads, hh = tid % hd.n_heads;
+        const int k = hd.k[hh], kp = hd.kp[hh], o = hd.qoff[hh];
+        const float* q = Q + (int64_t)(i0 + s) * SP + o;
+        float* dl = s_dl + s * SP + o;
         float dot = 0.f;
-        for (int j = 0; j < k; ++j) dot = fmaf(s_dl[o + j], q[j], dot);
+        for (int j = 0; j < k; ++j) dot = fmaf(dl[j], q[j], dot);
         for (int j = 0; j < kp; ++j) {
-            const float v = (j < k) ? q[j] * (s_dl[o + j] - dot) : 0.f;
-            s_dl[o + j] = v;
-            dL[(int64_t)i * SP + o + j] = v;
+            const float v = (j < k) ? q[j] * (dl[j] - dot) : 0.f;
+            dl[j] = v;
+            dL[(int64_t)(i0 + s) * SP + o + j] = v;
         }
     }
     __syncthreads();
-    // ---- dH, relu mask, dZn partials ----
-    float dzn[32];
-#pragma unroll
-    for (int c = 0; c < 32; ++c) dzn[c] = 0.f;
-    const float* W1 = small + hd.w1_off;
+    // ---- dH with relu mask: a Wk element is read once per SB samples ----
     for (int h = tid; h < Hd; h += 256) {
-        float a = 0.f;
+        float a[SB];
+#pragma unroll
+        for (int s = 0; s < SB; ++s) a[s] = 0.f;
         for (int hh = 0; hh < hd.n_heads; ++hh) {
             const float* Wk = small + hd.wk_off[hh];
             const int o = hd.qoff[hh];
-            for (int k = 0; k < hd.k[hh]; ++k) a = fmaf(s_dl[o + k], Wk[k * Hd + h], a);
+            for (int k = 0; k < hd.k[hh]; ++k) {
+                const float w = Wk[k * Hd + h];
+#pragma unroll
+                for (int s = 0; s < SB; ++s) a[s] = fmaf(s_dl[s * SP + o + k], w, a[s]);
+            }
         }
-        a = (H[(int64_t)i * Hd + h] > 0.f) ? a : 0.f;
-        dHpre[(int64_t)i * Hd + h] = a;
 #pragma unroll
-        for (int c = 0; c < 32; ++c)
-            if (c < C) dzn[c] = fmaf(a, W1[h * C + c], dzn[c]);
-    }
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        if (c < C) {                                   // uniform branch
-            const float t = block_sum<256>(dzn[c], s_red);
-            if (tid == 0) s_dzn[c] = t;
+        for (int s = 0; s < SB; ++s) {
+            float v = 0.f;
+            if (s < ns) {
+                v = (H[(int64_t)(i0 + s) * Hd + h] > 0.f) ? a[s] : 0.f;
+                dHpre[(int64_t)(i0 + s) * Hd + h] = v;
+            }
+            s_dh[s * Hd + h] = v;
         }
     }
     __syncthreads();
-    if (tid == 0) {
+    // ---- dZn[s][c] = sum_h dHpre[s][h] W1[h][c]: wave w takes pairs w, w+4, ... ----
+    {
+        const float* W1 = small + hd.w1_off;
+        for (int pr = wave; pr < SB * C; pr += 4) {
+            const int s = pr / C, c = pr % C;
+            float a = 0.f;
+#pragma unroll 4
+            for (int h = lane; h < Hd; h += 64) a = fmaf(s_dh[s * Hd + h], W1[h * C + c], a);
+            a = wave_sum_lane63(a);
+            if (lane == 63) s_dzn[s * CP + c] = a;
+        }
+    }
+    __syncthreads();
+    if (tid < ns) {
+        const int64_t i = i0 + tid;
         const float ri = rinv[i];
         const float* g = small + hd.g_off;
+        const float* dzn = s_dzn + tid * CP;
         float dot = 0.f;
-        for (int c = 0; c < C; ++c) dot = fmaf(s_dzn[c] * g[c], Z[(int64_t)i * CP + c], dot);
+        for (int c = 0; c < C; ++c) dot = fmaf(dzn[c] * g[c], Z[i * CP + c], dot);
         const float mean_tz = dot / (float)C;
         const float ri3 = ri * ri * ri;
         for (int c = 0; c < CP; ++c) {
             float dz = 0.f, dgv = 0.f;
             if (c < C) {
-                const float z = Z[(int64_t)i * CP + c];
-                dz = ri * (s_dzn[c] * g[c]) - z * ri3 * mean_tz;
-                dgv = s_dzn[c] * z * ri;
+                const float z = Z[i * CP + c];
+                dz = ri * (dzn[c] * g[c]) - z * ri3 * mean_tz;
+                dgv = dzn[c] * z * ri;
             }
-            dZ[(int64_t)i * CP + c] = dz;
-            dgp[(int64_t)i * CP + c] = dgv;
+            dZ[i * CP + c] = dz;
+            dgp[i * CP + c] = dgv;
         }
     }
     // ---- loss (block 0 only) ----
-    if (i == 0 && n_loss > 0) {
+    if (blockIdx.x == 0 && n_loss > 0) {
         double a = 0.0;
         for (int64_t e = tid; e < n_loss; e += 256) a += (double)losspart[e];
         a = wave_sum_all_f64(a);
@@ -227,7 +299,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_kernel(nadm_heads_t hd, const f
 }
 
 // =================================================================================================
-// mlp_bwd_b: weight gradients, split over samples: grid (ceil(Hd/256), splits).
+// mlp_bwd_b: weight gradients, split over samples: grid (ceil(Hd/256), splits of SJ samples).
 //   dWk[k][h] = sum_i dL[i][k] H[i][h] ; dW1[h][c] = sum_i dHpre[i][h] Zn[i][c] ; db1[h] = sum_i dHpre[i][h]
 //   dbk[k] = sum_i dL[i][k] ; dg[c] = sum_i dgp[i][c]      (block x == 0)
 // writes small_part[split][n_small]; small_reduce sums the splits in fixed order.
@@ -243,44 +315,34 @@ __global__ __launch_bounds__(256) void mlp_bwd_b_kernel(nadm_heads_t hd, int b, 
     const int i0 = j * SJ, i1 = min(b, i0 + SJ);
     float* out = small_part + (int64_t)j * hd.n_small;
     if (h < Hd) {
-        // W1 / b1
-        float aw[32];
+        float hv[SJ], dv[SJ];                 // this thread's column of H / dHpre for the split (coalesced loads, issued together)
 #pragma unroll
-        for (int c = 0; c < 32; ++c) aw[c] = 0.f;
-        float ab = 0.f;
-        for (int i = i0; i < i1; ++i) {
-            const float d = dHpre[(int64_t)i * Hd + h];
-            ab += d;
-#pragma unroll
-            for (int c = 0; c < 32; ++c)
-                if (c < C) aw[c] = fmaf(d, Zn[(int64_t)i * CP + c], aw[c]);
+        for (int ii = 0; ii < SJ; ++ii) {
+            const bool ok = i0 + ii < i1;
+            hv[ii] = ok ? H[(int64_t)(i0 + ii) * Hd + h] : 0.f;
+            dv[ii] = ok ? dHpre[(int64_t)(i0 + ii) * Hd + h] : 0.f;
         }
+        float ab = 0.f;
+#pragma unroll
+        for (int ii = 0; ii < SJ; ++ii) ab += dv[ii];
         out[hd.b1_off + h] = ab;
+        for (int c = 0; c < C; ++c) {
+            float a = 0.f;
 #pragma unroll
-        for (int c = 0; c < 32; ++c)
-            if (c < C) out[hd.w1_off + h * C + c] = aw[c];
-        // Wk per head, 16 columns at a time
+            for (int ii = 0; ii < SJ; ++ii) a = fmaf(dv[ii], (i0 + ii < i1) ? Zn[(int64_t)(i0 + ii) * CP + c] : 0.f, a);
+            out[hd.w1_off + h * C + c] = a;
+        }
         for (int hh = 0; hh < hd.n_heads; ++hh) {
-            const int o = hd.qoff[hh], k = hd.k[hh];
-            for (int k0 = 0; k0 < k; k0 += 16) {
-                float a[16];
+            const int o = hd.qoff[hh];
+            for (int k = 0; k < hd.k[hh]; ++k) {
+                float a = 0.f;
 #pragma unroll
-                for (int s = 0; s < 16; ++s) a[s] = 0.f;
-                for (int i = i0; i < i1; ++i) {
-                    const float hv = H[(int64_t)i * Hd + h];
-                    const float* dl = dL + (int64_t)i * SP + o + k0;     // padded columns are zero
-#pragma unroll
-                    for (int s = 0; s < 16; ++s)
-                        if (k0 + s < hd.kp[hh]) a[s] = fmaf(dl[s], hv, a[s]);
-                }
-#pragma unroll
-                for (int s = 0; s < 16; ++s)
-                    if (k0 + s < k) out[hd.wk_off[hh] + (k0 + s) * Hd + h] = a[s];
+                for (int ii = 0; ii < SJ; ++ii) a = fmaf((i0 + ii < i1) ? dL[(int64_t)(i0 + ii) * SP + o + k] : 0.f, hv[ii], a);
+                out[hd.wk_off[hh] + k * Hd + h] = a;
             }
         }
     }
     if (blockIdx.x == 0) {
-        // biases of the heads and the RMSNorm weight: tiny column sums
         for (int hh = 0; hh < hd.n_heads; ++hh)
             for (int k = tid; k < hd.k[hh]; k += 256) {
                 float a = 0.f;
@@ -299,6 +361,7 @@ __global__ void small_reduce_kernel(const float* __restrict__ part, int splits, 
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     float a = 0.f;
+#pragma unroll 8
     for (int j = 0; j < splits; ++j) a += part[(int64_t)j * n + e];
     out[e] = a;
 }
@@ -527,8 +590,13 @@ extern "C" int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const fl
                             float* Z, float* rinv, float* Zn, float* H, float* Q, void* stream) {
     if (!hd || !small || !zpart || !Z || !rinv || !Zn || !H || !Q) return fail("nadm_mlp_fwd: null pointer");
     if (b <= 0) return fail("nadm_mlp_fwd: empty batch");
-    const size_t lds = (size_t)(4 + hd->CP + hd->Hd + hd->SP) * 4;
-    hipLaunchKernelGGL(mlp_fwd_kernel, dim3(b), dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q);
+    if (hd->Hd <= 2048) {
+        const size_t lds = (size_t)(1024 + MLP_SB * (hd->CP + hd->Hd + hd->SP)) * 4;
+        hipLaunchKernelGGL((mlp_fwd_kernel<MLP_SB>), dim3((b + MLP_SB - 1) / MLP_SB), dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q);
+    } else {
+        const size_t lds = (size_t)(1024 + hd->CP + hd->Hd + hd->SP) * 4;
+        hipLaunchKernelGGL((mlp_fwd_kernel<1>), dim3(b), dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q);
+    }
     return check_launch("mlp_fwd");
 }
 
@@ -541,11 +609,17 @@ extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const fl
     if (n_loss > 0 && (!losspart || !loss_acc)) return fail("nadm_mlp_bwd: n_loss > 0 needs losspart and loss_acc");
     if (b <= 0) return fail("nadm_mlp_bwd: empty batch");
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)(4 + hd->SP + hd->CP + 256) * 4;
     DqChunks dqc;
     for (int h = 0; h < NADM_MAX_HEADS; ++h) dqc.n[h] = h < hd->n_heads ? nadm_decode_chunks(M, hd->kp[h]) : 0;
-    hipLaunchKernelGGL(mlp_bwd_a_kernel, dim3(b), dim3(256), lds, st, *hd, small, dqpart, dqc, b, Z, rinv, H, Q, dL, dHpre,
-                       dgp, dZ, losspart, n_loss, loss_acc);
+    if (hd->Hd <= 2048) {
+        const size_t lds = (size_t)(1024 + MLP_SB * (hd->SP + hd->CP + hd->Hd)) * 4;
+        hipLaunchKernelGGL((mlp_bwd_a_kernel<MLP_SB>), dim3((b + MLP_SB - 1) / MLP_SB), dim3(256), lds, st, *hd, small, dqpart, dqc, b, Z, rinv, H, Q,
+                           dL, dHpre, dgp, dZ, losspart, n_loss, loss_acc);
+    } else {
+        const size_t lds = (size_t)(1024 + hd->SP + hd->CP + hd->Hd) * 4;
+        hipLaunchKernelGGL((mlp_bwd_a_kernel<1>), dim3(b), dim3(256), lds, st, *hd, small, dqpart, dqc, b, Z, rinv, H, Q,
+                           dL, dHpre, dgp, dZ, losspart, n_loss, loss_acc);
+    }
     const int splits = nadm_sample_splits(b);
     hipLaunchKernelGGL(mlp_bwd_b_kernel, dim3((hd->Hd + 255) / 256, splits), dim3(256), 0, st, *hd, b, Zn, H, dL, dHpre, dgp, small_part);
     hipLaunchKernelGGL(small_reduce_kernel, dim3((hd->n_small + 255) / 256), dim3(256), 0, st, small_part, splits, hd->n_small, grad_small);
