@@ -497,10 +497,10 @@ __device__ __forceinline__ float row16_sum(float v) {     // sum over the 16 lan
     return v;
 }
 
-constexpr int MF_MAXW = 16;
-constexpr int mf_waves(int kp) { return (kp == 8 || kp == 16) ? 12 : 16; }        // 12 waves -> 168-VGPR budget at 3 waves/SIMD (KP=8 keeps 64 dP accumulators)
+constexpr int mf_ts(int kp) { return kp <= 8 ? 64 : 32; }   // samples per LDS tile in the matrix-core kernel (LDS <= 64 KB)
+constexpr int mf_waves(int kp) { return 8; }   // 2 waves/SIMD with a 256-VGPR budget: latency is hidden by ILP across a wave's NTW independent tiles
 constexpr int MF_RS_PAD = 16;       // LDS row stride of the X tile = row bytes + 16 (16 B aligned, de-phased banks)
-constexpr int mf_ntw(int kp) { return kp <= 8 ? 2 : 1; }            // 16-SNP tiles per wave (dP accumulators: NTW*4*KP regs)
+constexpr int mf_ntw(int kp) { return kp <= 8 ? 4 : 2; }            // 16-SNP tiles per wave (dP accumulators: NTW*4*KP regs <= 128)
 constexpr int mf_chunk_snps(int kp) { return mf_waves(kp) * 16 * mf_ntw(kp); }
 
 // gradient w.r.t. the pre-clamp reconstruction and (optionally) the BCE loss term of one genotype.
@@ -536,12 +536,13 @@ __global__ __launch_bounds__(64 * mf_waves(KP)) void decode_bce_mfma_kernel(
     constexpr int KQ = KP / 4;
     constexpr int NTW = mf_ntw(KP);
     constexpr int MF_WAVES = mf_waves(KP);
+    constexpr int MF_TS = mf_ts(KP);
     constexpr int RB = MF_WAVES * 4 * NTW;              // packed bytes per row per block (96 or 64)
     constexpr int RS = RB + MF_RS_PAD;
     constexpr int PPR = RB / 16;                         // 16 B pieces per row
-    __shared__ __attribute__((aligned(16))) uint8_t s_x[2][TS * RS];
-    __shared__ __attribute__((aligned(16))) float s_q[2][TS * KP];
-    __shared__ __attribute__((aligned(16))) float s_dq[MF_WAVES][TS * KP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_x[2][MF_TS * RS];
+    __shared__ __attribute__((aligned(16))) float s_q[2][MF_TS * KP];
+    __shared__ __attribute__((aligned(16))) float s_dq[MF_WAVES][MF_TS * KP];
     __shared__ float s_loss[MF_WAVES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -572,48 +573,67 @@ __global__ __launch_bounds__(64 * mf_waves(KP)) void decode_bce_mfma_kernel(
             for (int k = 0; k < KP / 2; ++k) dp[t][r][k] = (f32x2){0.f, 0.f};
     float lossacc = 0.f;
 
-    // ---- X / Q tile staging (threads 0..TS*PPR-1 move one 16 B piece each) ----
-    uint4 stage = make_uint4(0, 0, 0, 0);
+    // ---- X / Q tile staging.  Every thread issues the (unconditional, address-clamped) loads so that the
+    //      waits on them are unconditional too: a wait hidden inside a divergent branch makes the compiler
+    //      drain the prefetch at the first MFMA of the next tile.  The row index for the NEXT tile is
+    //      fetched one tile early, so the index->row dependency never stalls. ----
+    constexpr int NTHR = 64 * MF_WAVES;
+    constexpr int NPIECE = MF_TS * PPR;                      // 16 B pieces per X tile (<= NTHR)
+    static_assert(NPIECE <= NTHR, "one piece per thread");
+    const int pc = tid < NPIECE ? tid : tid - NPIECE * (tid / NPIECE);   // duplicate pieces beyond NPIECE (never committed)
+    const int pr = pc / PPR, pc16 = pc % PPR;
+    const int64_t poff = byte0 + pc16 * 16;
+    const bool pcol_ok = poff < ld;
+    const int64_t poff_c = pcol_ok ? poff : 0;
+    auto row_index = [&](int i0) -> int32_t { const int smp = i0 + pr; return idx[smp < b ? smp : b - 1]; };
+    int32_t row_pref = row_index(0);                         // kept as the raw 32-bit value: widened only when used
+    uint4 stage;
     auto issue = [&](int i0) {
-        if (tid < TS * PPR) {
-            const int r = tid / PPR, c16 = tid % PPR;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            const int64_t off = byte0 + c16 * 16;
-            if (i0 + r < b && off < ld) {
-                const int64_t row = idx[i0 + r];
-                v = *reinterpret_cast<const uint4*>(xp + row * ld + off);
-            }
-            stage = v;
+        stage = *reinterpret_cast<const uint4*>(xp + (int64_t)row_pref * ld + poff_c);
+        row_pref = row_index(i0 + MF_TS);                    // index of the tile after this one
+    };
+    auto commit = [&](int buf, int i0) {
+        const bool ok = pcol_ok && (i0 + pr < b);
+        const uint4 v = ok ? stage : make_uint4(0, 0, 0, 0);
+        if (tid < NPIECE) *reinterpret_cast<uint4*>(&s_x[buf][pr * RS + pc16 * 16]) = v;
+    };
+    constexpr int QPT = (MF_TS * KP + NTHR - 1) / NTHR;      // Q elements per thread per tile
+    float qstage[QPT];
+    auto issue_q = [&](int i0) {                             // global -> registers (consumed one tile later)
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+            const int e = tid + u * NTHR;
+            const int ec = e < MF_TS * KP ? e : 0;
+            const int r = ec / KP, k = ec % KP;
+            const int smp = i0 + r < b ? i0 + r : b - 1;
+            qstage[u] = Q[(int64_t)smp * SP + k];
         }
     };
-    auto commit = [&](int buf) {
-        if (tid < TS * PPR) {
-            const int r = tid / PPR, c16 = tid % PPR;
-            *reinterpret_cast<uint4*>(&s_x[buf][r * RS + c16 * 16]) = stage;
+    auto commit_q = [&](int buf, int i0) {
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+            const int e = tid + u * NTHR;
+            const int r = e / KP;
+            if (e < MF_TS * KP) s_q[buf][e] = (i0 + r < b) ? qstage[u] : 0.f;
         }
     };
-    auto load_q = [&](int i0, int buf) {
-        if (tid < TS * KP) {
-            const int r = tid / KP, k = tid % KP;
-            s_q[buf][tid] = (i0 + r < b) ? Q[(int64_t)(i0 + r) * SP + k] : 0.f;
-        }
-    };
-    static_assert(TS * KP <= 64 * MF_WAVES, "Q tile must fit one pass of the block");
 
     issue(0);
-    commit(0);
-    load_q(0, 0);
+    issue_q(0);
+    commit(0, 0);
+    commit_q(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): every prologue load (P operands, tile 0) has landed
     __syncthreads();
 
-    const int ntiles = (b + TS - 1) / TS;
+    const int ntiles = (b + MF_TS - 1) / MF_TS;
     for (int tl = 0; tl < ntiles; ++tl) {
         const int cur = tl & 1;
-        const int i0 = tl * TS;
-        const int nt = min(TS, b - i0);
-        if (tl + 1 < ntiles) issue(i0 + TS);
+        const int i0 = tl * MF_TS;
+        const int nt = min(MF_TS, b - i0);
+        if (tl + 1 < ntiles) { issue_q(i0 + MF_TS); issue(i0 + MF_TS); }   // block-uniform
 
 #pragma unroll 1
-        for (int stl = 0; stl < TS / 16; ++stl) {
+        for (int stl = 0; stl < MF_TS / 16; ++stl) {
             if (i0 + 16 * stl < b) {                                  // block-uniform
                 const int srow = 16 * stl + n;                          // this lane's sample row in the tile
                 float qb[KQ];                                           // B of R^T: Q[sample n][k = a + 4j]
@@ -626,9 +646,10 @@ __global__ __launch_bounds__(64 * mf_waves(KP)) void decode_bce_mfma_kernel(
                     q8[2 * j] = (f32x2){v.x, v.y}; q8[2 * j + 1] = (f32x2){v.z, v.w};
                 }
                 uint32_t bits;                                          // NTW bytes: 4 SNPs x NTW tiles of this sample
-                if constexpr (NTW == 2) bits = *reinterpret_cast<const uint16_t*>(&s_x[cur][srow * RS + wave * 8 + 2 * a]);
+                if constexpr (NTW == 4) bits = *reinterpret_cast<const uint32_t*>(&s_x[cur][srow * RS + wave * 16 + 4 * a]);
+                else if constexpr (NTW == 2) bits = *reinterpret_cast<const uint16_t*>(&s_x[cur][srow * RS + wave * 8 + 2 * a]);
                 else bits = s_x[cur][srow * RS + wave * 4 + a];
-                bits &= ~((bits & (bits >> 1) & 0x5555u) * 3u);         // missing (3) -> 0: x = 0 in input and target
+                bits &= ~((bits & (bits >> 1) & 0x55555555u) * 3u);         // missing (3) -> 0: x = 0 in input and target
 
                 f32x4 dq = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -652,16 +673,15 @@ __global__ __launch_bounds__(64 * mf_waves(KP)) void decode_bce_mfma_kernel(
             }
         }
         __syncthreads();
-        if (tid < nt * KP) {
+        for (int e = tid; e < nt * KP; e += NTHR) {
             float s = 0.f;
 #pragma unroll
-            for (int w = 0; w < MF_WAVES; ++w) s += s_dq[w][tid];
-            const int r = tid / KP, k = tid % KP;
-            dqpart[(chunk * b + i0 + r) * KP + k] = s;
+            for (int w = 0; w < MF_WAVES; ++w) s += s_dq[w][e];
+            dqpart[(chunk * b + i0) * KP + e] = s;
         }
         if (tl + 1 < ntiles) {
-            commit(cur ^ 1);
-            load_q(i0 + TS, cur ^ 1);
+            commit(cur ^ 1, i0 + MF_TS);
+            commit_q(cur ^ 1, i0 + MF_TS);
         }
         __syncthreads();
     }
