@@ -715,6 +715,166 @@ __global__ __launch_bounds__(64 * mf_waves(KP)) void decode_bce_mfma_kernel(
     }
 }
 
+// =================================================================================================
+// pass 3, matrix-core version (CP <= 8): dV = X^T . dZ on v_mfma_f32_16x16x32_bf16.
+//   D[rows = dZ columns (hi 0-7 | mid 8-15), cols = 16 SNPs] += A[rows][32 samples] . B[32 samples][16 SNPs]
+//   with dZ split hi+mid+lo into bf16 (second accumulator holds lo|0), X exact in bf16.
+//   The reduction runs over SAMPLES, but a packed byte holds 4 SNPs of ONE sample, so the B operand
+//   (8 consecutive samples of one SNP per lane) needs a bit transpose.  It is done in two steps:
+//     1. the tile loader reads 4 rows x 4 bytes per thread, transposes the 4x4 bytes with v_perm and
+//        stores the tile SNP-byte-major in LDS, so a lane gets 4 consecutive samples of its byte
+//        column with one ds_read_b32;
+//     2. per 2-bit field j the 4 codes are gathered into one byte with two shift-or steps and a
+//        256-entry LDS table turns that byte into 4 bf16 values (missing -> 0): half a B operand.
+//   One byte column feeds 4 MFMA column sets (fields j = 0..3).  dZ operands are split once per
+//   32-sample tile by one wave and shared through LDS.  block = 4 waves x 128 SNPs; tiles are
+//   double-buffered, global loads for tile t+1 are issued before tile t is computed.
+// =================================================================================================
+constexpr int EB_TS = 32;                 // samples per k-step / tile
+constexpr int EB_G = 2;                   // 64-SNP groups per wave
+constexpr int EB_COLS = 4 * EB_G * 16;    // packed byte columns per block (128)
+constexpr int EB_CS = 36;                 // LDS stride of one byte column (32 rows + pad: conflict-free)
+constexpr int EB_CHUNK_SNPS = EB_COLS * 4;
+
+template <int CP>
+__global__ __launch_bounds__(256) void encode_bwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
+                                                              const int32_t* __restrict__ idx, int b, int64_t M,
+                                                              const float* __restrict__ dZ, float* __restrict__ dV) {
+    static_assert(CP <= 8, "hi|mid and lo|0 share the 16 MFMA rows");
+    __shared__ __attribute__((aligned(16))) uint8_t s_xt[2][EB_COLS * EB_CS];
+    __shared__ __attribute__((aligned(16))) uint4 s_a[2][2][64];
+    __shared__ __attribute__((aligned(8))) uint2 s_lut[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mcol = lane & 15, q = lane >> 4;
+    const int64_t chunk = blockIdx.x;
+    const int64_t byte0 = chunk * EB_COLS;
+    {   // byte of four 2-bit codes -> 4 bf16 (x = code/2, missing -> 0)
+        auto bf = [](uint32_t c) -> uint32_t { return c == 1 ? 0x3F00u : (c == 2 ? 0x3F80u : 0u); };
+        const uint32_t t = tid;
+        s_lut[tid] = make_uint2(bf(t & 3) | (bf((t >> 2) & 3) << 16), bf((t >> 4) & 3) | (bf(t >> 6) << 16));
+    }
+    // ---- loader mapping: thread -> 4 rows x 4 byte columns ----
+    const int cg = tid & 31, rg = tid >> 5;                   // byte columns 4cg..4cg+3, rows 4rg..4rg+3 of the tile
+    const int64_t loff = byte0 + 4 * cg;
+    const bool lcol_ok = loff < ld;
+    const int64_t loff_c = lcol_ok ? loff : 0;
+    auto row_idx = [&](int i0, int k) -> int32_t { const int smp = i0 + 4 * rg + k; return idx[smp < b ? smp : b - 1]; };
+    int32_t rows_pref[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rows_pref[k] = row_idx(0, k);
+    uint32_t xw[4];
+    float zst[8];                                             // wave 0: dZ values of the next tile for its A operand slot
+    auto issue = [&](int i0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xw[k] = *reinterpret_cast<const uint32_t*>(xp + (int64_t)rows_pref[k] * ld + loff_c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rows_pref[k] = row_idx(i0 + EB_TS, k);
+        if (wave == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int smp = i0 + 8 * q + e;
+                zst[e] = dZ[(int64_t)(smp < b ? smp : b - 1) * CP + ((mcol & 7) < CP ? (mcol & 7) : 0)];
+            }
+        }
+    };
+    auto commit = [&](int buf, int i0) {
+        uint32_t d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = (lcol_ok && i0 + 4 * rg + k < b) ? xw[k] : 0u;
+        // 4x4 byte transpose: e[c] = byte c of rows 0..3
+        const uint32_t t01l = __builtin_amdgcn_perm(d[1], d[0], 0x05010400u);   // d0.b0 d1.b0 d0.b1 d1.b1
+        const uint32_t t01h = __builtin_amdgcn_perm(d[1], d[0], 0x07030602u);   // d0.b2 d1.b2 d0.b3 d1.b3
+        const uint32_t t23l = __builtin_amdgcn_perm(d[3], d[2], 0x05010400u);
+        const uint32_t t23h = __builtin_amdgcn_perm(d[3], d[2], 0x07030602u);
+        const uint32_t e0 = __builtin_amdgcn_perm(t23l, t01l, 0x05040100u);     // t01l.b0 t01l.b1 t23l.b0 t23l.b1
+        const uint32_t e1 = __builtin_amdgcn_perm(t23l, t01l, 0x07060302u);
+        const uint32_t e2 = __builtin_amdgcn_perm(t23h, t01h, 0x05040100u);
+        const uint32_t e3 = __builtin_amdgcn_perm(t23h, t01h, 0x07060302u);
+        uint8_t* base = &s_xt[buf][(4 * cg) * EB_CS + 4 * rg];
+        *reinterpret_cast<uint32_t*>(base) = e0;
+        *reinterpret_cast<uint32_t*>(base + EB_CS) = e1;
+        *reinterpret_cast<uint32_t*>(base + 2 * EB_CS) = e2;
+        *reinterpret_cast<uint32_t*>(base + 3 * EB_CS) = e3;
+        if (wave == 0) {
+            uint32_t w1[4], w2[4];
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                uint32_t p1[2], p2[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int e = 2 * dd + hh;
+                    const float v = (i0 + 8 * q + e < b && (mcol & 7) < CP) ? zst[e] : 0.f;
+                    const uint32_t hi = bf16_trunc_bits(v);
+                    const float r1 = v - __uint_as_float(hi);
+                    const uint32_t mid = bf16_trunc_bits(r1);
+                    const float r2 = r1 - __uint_as_float(mid);
+                    const uint32_t lo = bf16_trunc_bits(r2);
+                    p1[hh] = (mcol >= 8 ? mid : hi) >> 16;
+                    p2[hh] = mcol >= 8 ? 0u : (lo >> 16);
+                }
+                w1[dd] = p1[0] | (p1[1] << 16);
+                w2[dd] = p2[0] | (p2[1] << 16);
+            }
+            s_a[buf][0][lane] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+            s_a[buf][1][lane] = make_uint4(w2[0], w2[1], w2[2], w2[3]);
+        }
+    };
+
+    f32x4 acc1[EB_G][4], acc2[EB_G][4];
+#pragma unroll
+    for (int g = 0; g < EB_G; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc1[g][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[g][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    issue(0);
+    commit(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+
+    const int ntiles = (b + EB_TS - 1) / EB_TS;
+    for (int tl = 0; tl < ntiles; ++tl) {
+        const int cur = tl & 1;
+        const int i0 = tl * EB_TS;
+        if (tl + 1 < ntiles) issue(i0 + EB_TS);
+        const bf16x8 a1 = __builtin_bit_cast(bf16x8, s_a[cur][0][lane]);
+        const bf16x8 a2 = __builtin_bit_cast(bf16x8, s_a[cur][1][lane]);
+#pragma unroll
+        for (int g = 0; g < EB_G; ++g) {
+            const uint8_t* colp = &s_xt[cur][(wave * (16 * EB_G) + g * 16 + mcol) * EB_CS + 8 * q];
+            const uint32_t w0 = *reinterpret_cast<const uint32_t*>(colp);        // samples 8q..8q+3 of this byte column
+            const uint32_t w1 = *reinterpret_cast<const uint32_t*>(colp + 4);    // samples 8q+4..8q+7
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t t0 = (w0 >> (2 * j)) & 0x03030303u, t1 = (w1 >> (2 * j)) & 0x03030303u;
+                t0 |= t0 >> 6; t1 |= t1 >> 6;
+                t0 |= t0 >> 12; t1 |= t1 >> 12;
+                const uint2 lo = s_lut[t0 & 0xFFu], hi = s_lut[t1 & 0xFFu];
+                const bf16x8 bv = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                acc1[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bv, acc1[g][j], 0, 0, 0);
+                acc2[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bv, acc2[g][j], 0, 0, 0);
+            }
+        }
+        if (tl + 1 < ntiles) commit(cur ^ 1, i0 + EB_TS);
+        __syncthreads();
+    }
+
+    // ---- fold hi + mid + lo: rows c and c+8 sit 32 lanes apart; lanes with 4*(lane>>4) < CP store ----
+#pragma unroll
+    for (int g = 0; g < EB_G; ++g) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u = acc1[g][j][r] + acc2[g][j][r];
+                o[r] = u + __shfl_xor(u, 32, 64);
+            }
+            const int64_t m = chunk * EB_CHUNK_SNPS + (wave * (16 * EB_G) + g * 16 + mcol) * 4 + j;
+            if (q < 2 && 4 * q < CP && m < M) *reinterpret_cast<float4*>(dV + m * CP + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // ---- SNPs per lane in pass 2 as a function of the padded head width (register budget ~128) ----
 constexpr int dec_spl(int kp) { return kp <= 8 ? 8 : (kp <= 16 ? 4 : (kp <= 32 ? 2 : 1)); }
 
@@ -864,6 +1024,12 @@ extern "C" int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_encode_bwd: ld must be a multiple of 16 and >= ceil(M/4)");
     dim3 grid((unsigned)((M + 1023) / 1024)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (CP <= 8 && use_mfma_encode()) {
+        dim3 g2((unsigned)((M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS));
+        if (CP == 4) hipLaunchKernelGGL((encode_bwd_mfma_kernel<4>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV);
+        else hipLaunchKernelGGL((encode_bwd_mfma_kernel<8>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV);
+        return check_launch("encode_bwd_mfma");
+    }
     switch (CP) {
         case 4: hipLaunchKernelGGL((encode_bwd_kernel<4>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
         case 8: hipLaunchKernelGGL((encode_bwd_kernel<8>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
