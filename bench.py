@@ -161,6 +161,14 @@ def main():
     # batch (b*M/4) + read P and write dP once (2 * 4*M*K).
     dom = "decode_bce"
     alg_bytes = b * M / 4 + 2 * 4 * M * K
+    traffic = None                                                      # HBM bytes/launch from the committed PMC passes (same workload)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
+            pm = json.load(f)
+        if abs(pm["algorithmic_bytes_per_launch"] - alg_bytes) < 1:
+            traffic = pm["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
     step_bytes = b * M * (0.75 + 36.0 * (8 + K) / b)                     # SURVEY.md 8d whole-step figure
     out = {
@@ -173,7 +181,7 @@ def main():
                                f"loss value {'every step' if with_loss else 'skipped'}",
                    "global_batch": b * world, "parallelism": f"dp{world}"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kms, "alg_bytes_per_launch": alg_bytes,
                      "whole_step": {"alg_bytes": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
                                     "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}},
