@@ -716,6 +716,304 @@ __global__ __launch_bounds__(64 * mf_waves(KP)) void decode_bce_mfma_kernel(
 }
 
 // =================================================================================================
+// pass 2, bf16 matrix-core version (KP <= 8).  f32-input MFMA runs on the vector ALUs and does not overlap
+// with VALU work (tools/ubench_mfma_valu*.hip), so the three small GEMMs are moved to the real matrix pipe
+// (v_mfma_f32_16x16x32_bf16, 16x the f32 rate) with fp32 operands split into bf16 pieces:
+//   R^T = P.Q^T      P, Q split 3-way (hi+mid+lo = 24 mantissa bits); the 6 product terms >= 2^-16 fill the
+//                    K = 32 dimension of two MFMAs: [Ph Ph Pm Pm].[Qh Qm Qh Qm] and [Ph Pl 0 0].[Ql Qh 0 0]
+//   dQ^T = P^T.dR^T  dR split 2-way with round-to-nearest (v_cvt_pk_bf16_f32; 2^-17 relative, unbiased),
+//                    P 3-way in the 16 output rows ([Ph|Pm] and [Pl|0]); reduction = 32 SNPs = 2 tiles, the
+//                    lane's own 8 dR values ARE the B operand (no cross-lane movement)
+//   dP = dR^T.Q      same dR pieces, transposed through a 2 KB per-wave LDS buffer and read back with
+//                    ds_read_b64_tr_b16; Q 3-way in the 16 output columns; reduction = 32 samples = 2 tiles
+// The VALU only does the per-genotype BCE algebra and the bf16 split.  Work unit of a wave: 2 SNP tiles x
+// 2 sample tiles.  Everything else (tile staging, chunking, dQ partial slabs) is as in the f32 MFMA kernel.
+// =================================================================================================
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pk_bf16(float lo_half, float hi_half) {      // RNE, one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){lo_half, hi_half}, bf16x2_t));
+}
+// 3-way bf16 split of one fp32 value: 16-bit patterns of hi, mid, lo
+__device__ __forceinline__ void split3(float v, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = pk_bf16(v, 0.f) & 0xFFFFu;
+    const float r1 = v - __uint_as_float(h << 16);
+    m = pk_bf16(r1, 0.f) & 0xFFFFu;
+    const float r2 = r1 - __uint_as_float(m << 16);
+    l = pk_bf16(r2, 0.f) & 0xFFFFu;
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// Two genotypes at a time with packed f32 math.  On gfx950 every VALU instruction costs ~4.5 cycles per wave
+// (tools/ubench_ops.hip), v_pk_{add,mul,fma}_f32 included, so packing halves the price of every add/mul/fma;
+// max, rcp, compare/select and the conversions have no packed form.
+// Returns dR (gradient w.r.t. the pre-clamp reconstruction) and accumulates the BCE loss terms.
+// cf = float(code) with missing already mapped to 0, so x = cf/2.
+// loss uses one log per genotype: x=0 -> log(1-r), x=1 -> log r, x=.5 -> .5*log(r(1-r)); the -100 clamps of the
+// two separate terms can only bind when r is exactly 0 or 1, where the merged form gives the same value.
+template <bool LOSS>
+__device__ __forceinline__ f32x2_t bce_elem2(const float d0, const float d1, const uint32_t c0, const uint32_t c1, float& lossacc) {
+    const f32x2_t cf = {(float)c0, (float)c1};
+    const f32x2_t r = {__builtin_amdgcn_fmed3f(d0, 0.f, 1.f), __builtin_amdgcn_fmed3f(d1, 0.f, 1.f)};
+    const f32x2_t omr = (f32x2_t){1.f, 1.f} - r;
+    const f32x2_t den = omr * r;
+    const f32x2_t inv = {__builtin_amdgcn_rcpf(fmaxf(den.x, 1e-12f)), __builtin_amdgcn_rcpf(fmaxf(den.y, 1e-12f))};
+    const f32x2_t g = (r - (f32x2_t){0.5f, 0.5f} * cf) * inv;
+    if constexpr (LOSS) {
+        const float kLn2 = 0.69314718055994530942f;
+        const float t0 = (c0 == 2u) ? r.x : ((c0 == 1u) ? den.x : omr.x);
+        const float t1 = (c1 == 2u) ? r.y : ((c1 == 1u) ? den.y : omr.y);
+        const float w0 = (c0 == 1u) ? 0.5f * kLn2 : kLn2, w1 = (c1 == 1u) ? 0.5f * kLn2 : kLn2;
+        const float l0 = fmaxf(__builtin_amdgcn_logf(t0), -100.f / kLn2), l1 = fmaxf(__builtin_amdgcn_logf(t1), -100.f / kLn2);
+        lossacc = fmaf(-w0, l0, lossacc);
+        lossacc = fmaf(-w1, l1, lossacc);
+    }
+    return (f32x2_t){(r.x == d0) ? g.x : 0.f, (r.y == d1) ? g.y : 0.f};
+}
+
+constexpr int BF_WAVES = 8;
+constexpr int BF_NTW = 4;
+constexpr int BF_TS = 64;
+
+template <int KP, bool LOSS>
+__global__ __launch_bounds__(64 * BF_WAVES) void decode_bce_bf16_kernel(
+    const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
+    const float* __restrict__ P, const float* __restrict__ Q, int SP,
+    float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart) {
+    static_assert(KP <= 8, "one 8-wide k slot");
+    constexpr int NTW = BF_NTW, MF_WAVES = BF_WAVES, MF_TS = BF_TS;
+    constexpr int RB = MF_WAVES * 4 * NTW;               // 128 packed bytes per row per block
+    constexpr int RS = RB + MF_RS_PAD;
+    constexpr int PPR = RB / 16;
+    constexpr int NTHR = 64 * MF_WAVES;
+    __shared__ __attribute__((aligned(16))) uint8_t s_x[2][MF_TS * RS];
+    __shared__ __attribute__((aligned(16))) uint4 s_qr[2][MF_TS / 16][2][64];   // B operands of R^T per 16-sample tile
+    __shared__ __attribute__((aligned(16))) uint4 s_qd[2][MF_TS / 32][2][64];   // B operands of dP per 32-sample pair
+    __shared__ __attribute__((aligned(16))) float s_dq[MF_WAVES][MF_TS * KP];
+    __shared__ __attribute__((aligned(16))) uint16_t s_t[MF_WAVES][2][2][32 * 16];  // per wave: [SNP tile of the pair][hi / lo][32 samples][16 SNPs]
+    __shared__ float s_loss[MF_WAVES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int a = lane >> 4, n = lane & 15;
+    const int64_t chunk = blockIdx.x;
+    const int64_t byte0 = chunk * RB;
+    const int64_t snp_wave0 = chunk * (MF_WAVES * 16 * NTW) + wave * (16 * NTW);
+    auto snp_of = [&](int t, int ab, int r) -> int64_t { return snp_wave0 + 4 * NTW * ab + 4 * t + r; };
+
+    // zero the operand slots that are never written (k-slots 2,3 of the second R MFMA; columns 8..15 of the second dP MFMA)
+    for (int e = tid; e < 2 * (MF_TS / 16) * 2 * 64; e += NTHR) (&s_qr[0][0][0][0])[e] = make_uint4(0, 0, 0, 0);
+    for (int e = tid; e < 2 * (MF_TS / 32) * 2 * 64; e += NTHR) (&s_qd[0][0][0][0])[e] = make_uint4(0, 0, 0, 0);
+
+    // ---- resident A operands built from P ----
+    uint4 pa_r1[NTW], pa_r2[NTW];            // R^T: lane (row = SNP n, slot a)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int64_t m = snp_of(t, n >> 2, n & 3);
+        uint32_t h[8], md[8], lo[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = (m < M && k < KP) ? P[m * KP + k] : 0.f;
+            split3(v, h[k], md[k], lo[k]);
+        }
+        const uint4 H = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        const uint4 Md = make_uint4(md[0] | (md[1] << 16), md[2] | (md[3] << 16), md[4] | (md[5] << 16), md[6] | (md[7] << 16));
+        const uint4 Lo = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+        const uint4 Z = make_uint4(0, 0, 0, 0);
+        pa_r1[t] = (a < 2) ? H : Md;                      // slots [Ph Ph Pm Pm]
+        pa_r2[t] = (a == 0) ? H : ((a == 1) ? Lo : Z);    // slots [Ph Pl 0 0]
+    }
+    uint4 pa_q1[NTW / 2], pa_q2[NTW / 2];    // dQ^T: lane (row = k-row n: 0-7 hi / 8-15 mid, slot a = 8 SNPs of the tile pair)
+#pragma unroll
+    for (int tp = 0; tp < NTW / 2; ++tp) {
+        uint32_t w1[8], w2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t m = snp_of(2 * tp + (e >> 2), a, e & 3);
+            const int k = n & 7;
+            const float v = (m < M && k < KP) ? P[m * KP + k] : 0.f;
+            uint32_t h, md, lo;
+            split3(v, h, md, lo);
+            w1[e] = (n < 8) ? h : md;
+            w2[e] = (n < 8) ? lo : 0u;
+        }
+        pa_q1[tp] = make_uint4(w1[0] | (w1[1] << 16), w1[2] | (w1[3] << 16), w1[4] | (w1[5] << 16), w1[6] | (w1[7] << 16));
+        pa_q2[tp] = make_uint4(w2[0] | (w2[1] << 16), w2[2] | (w2[3] << 16), w2[4] | (w2[5] << 16), w2[6] | (w2[7] << 16));
+    }
+    f32x4 dpacc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) dpacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float lossacc = 0.f;
+
+    // ---- X / Q staging (same scheme as the f32 MFMA kernel: unconditional clamped loads, index one tile ahead) ----
+    constexpr int NPIECE = MF_TS * PPR;
+    static_assert(NPIECE == NTHR && MF_TS * 8 == NTHR, "one X piece and one Q element per thread");
+    const int pr = tid / PPR, pc16 = tid % PPR;
+    const int64_t poff = byte0 + pc16 * 16;
+    const bool pcol_ok = poff < ld;
+    const int64_t poff_c = pcol_ok ? poff : 0;
+    auto row_index = [&](int i0) -> int32_t { const int smp = i0 + pr; return idx[smp < b ? smp : b - 1]; };
+    int32_t row_pref = row_index(0);
+    uint4 stage;
+    float qstage;
+    const int qr = tid >> 3, qk = tid & 7;                 // this thread's Q element: row qr of the tile, column qk
+    auto issue = [&](int i0) {
+        const int smp = i0 + qr < b ? i0 + qr : b - 1;
+        qstage = Q[(int64_t)smp * SP + (qk < KP ? qk : 0)];
+        stage = *reinterpret_cast<const uint4*>(xp + (int64_t)row_pref * ld + poff_c);
+        row_pref = row_index(i0 + MF_TS);
+    };
+    auto commit = [&](int buf, int i0) {
+        const bool ok = pcol_ok && (i0 + pr < b);
+        *reinterpret_cast<uint4*>(&s_x[buf][pr * RS + pc16 * 16]) = ok ? stage : make_uint4(0, 0, 0, 0);
+        // Q element -> bf16 pieces scattered into the MFMA operand images
+        const float v = (i0 + qr < b && qk < KP) ? qstage : 0.f;
+        uint32_t h, md, lo;
+        split3(v, h, md, lo);
+        const int st = qr >> 4, i = qr & 15;
+        uint16_t* r1 = reinterpret_cast<uint16_t*>(&s_qr[buf][st][0][0]) + qk;       // + lane*8 (uint16 units)
+        uint16_t* r2 = reinterpret_cast<uint16_t*>(&s_qr[buf][st][1][0]) + qk;
+        r1[(i) * 8] = (uint16_t)h;        r1[(i + 32) * 8] = (uint16_t)h;            // slots 0,2: Qh
+        r1[(i + 16) * 8] = (uint16_t)md;  r1[(i + 48) * 8] = (uint16_t)md;           // slots 1,3: Qm
+        r2[(i) * 8] = (uint16_t)lo;       r2[(i + 16) * 8] = (uint16_t)h;            // slots 0,1: Ql, Qh
+        const int pair = qr >> 5, within = qr & 31, q8 = within >> 3, e = within & 7;
+        uint16_t* d1 = reinterpret_cast<uint16_t*>(&s_qd[buf][pair][0][0]) + e;
+        uint16_t* d2 = reinterpret_cast<uint16_t*>(&s_qd[buf][pair][1][0]) + e;
+        d1[(q8 * 16 + qk) * 8] = (uint16_t)h;                                        // columns 0..7: Qh
+        d1[(q8 * 16 + qk + 8) * 8] = (uint16_t)md;                                   // columns 8..15: Qm
+        d2[(q8 * 16 + qk) * 8] = (uint16_t)lo;                                       // columns 0..7: Ql
+    };
+
+    __syncthreads();                                        // zero fill visible before the first commit
+    issue(0);
+    commit(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+
+    uint16_t* const tw = &s_t[wave][0][0][0];
+    const int ntiles = (b + MF_TS - 1) / MF_TS;
+    for (int tl = 0; tl < ntiles; ++tl) {
+        const int cur = tl & 1;
+        const int i0 = tl * MF_TS;
+        const int nt = min(MF_TS, b - i0);
+        if (tl + 1 < ntiles) issue(i0 + MF_TS);
+
+#pragma unroll 1
+        for (int p = 0; p < MF_TS / 32; ++p) {
+            if (i0 + 32 * p < b) {                                     // block-uniform
+                uint32_t bits[2];
+                uint4 qb1[2], qb2[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int st = 2 * p + s2;
+                    uint32_t w = *reinterpret_cast<const uint32_t*>(&s_x[cur][(16 * st + n) * RS + wave * 16 + 4 * a]);
+                    w &= ~((w & (w >> 1) & 0x55555555u) * 3u);         // missing (3) -> 0
+                    bits[s2] = w;
+                    qb1[s2] = s_qr[cur][st][0][lane];
+                    qb2[s2] = s_qr[cur][st][1][lane];
+                }
+                const uint4 qd1 = s_qd[cur][p][0][lane], qd2 = s_qd[cur][p][1][lane];
+                f32x4 dq[2];
+                dq[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                dq[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tp = 0; tp < NTW / 2; ++tp) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        uint32_t hi[2][2], lo[2][2];                   // [t2][pair of r] of this sample tile
+#pragma unroll
+                        for (int t2 = 0; t2 < 2; ++t2) {
+                            const int t = 2 * tp + t2;
+                            f32x4 D = (f32x4){0.f, 0.f, 0.f, 0.f};
+                            D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r1[t]), as_bf16x8(qb1[s2]), D, 0, 0, 0);
+                            D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r2[t]), as_bf16x8(qb2[s2]), D, 0, 0, 0);
+                            const uint32_t cb = bits[s2] >> (8 * t);
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                const f32x2_t dR = bce_elem2<LOSS>(D[2 * h2], D[2 * h2 + 1], (cb >> (4 * h2)) & 3u, (cb >> (4 * h2 + 2)) & 3u, lossacc);
+                                const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector(dR, bf16x2_t));
+                                hi[t2][h2] = hp;
+                                const f32x2_t rem = dR - (f32x2_t){__uint_as_float(hp << 16), __uint_as_float(hp & 0xFFFF0000u)};
+                                lo[t2][h2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rem, bf16x2_t));
+                            }
+                            // transposition buffer of this SNP tile: T[t2][hl][sample 16*s2 + n][SNP 4a .. 4a+3]  (row = 16 bf16 = 32 B)
+                            *reinterpret_cast<uint2*>(tw + (2 * t2 + 0) * 512 + (16 * s2 + n) * 16 + 4 * a) = make_uint2(hi[t2][0], hi[t2][1]);
+                            *reinterpret_cast<uint2*>(tw + (2 * t2 + 1) * 512 + (16 * s2 + n) * 16 + 4 * a) = make_uint2(lo[t2][0], lo[t2][1]);
+                        }
+                        // dQ^T of this sample tile: the lane's 8 dR values (2 tiles x 4 SNPs) are the B operand
+                        const bf16x8 bh = as_bf16x8(make_uint4(hi[0][0], hi[0][1], hi[1][0], hi[1][1]));
+                        const bf16x8 bl = as_bf16x8(make_uint4(lo[0][0], lo[0][1], lo[1][0], lo[1][1]));
+                        dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q1[tp]), bh, dq[s2], 0, 0, 0);
+                        dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q2[tp]), bh, dq[s2], 0, 0, 0);
+                        dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q1[tp]), bl, dq[s2], 0, 0, 0);
+                    }
+                    // dP: per SNP tile, read dR (hi, lo) of the 32 samples back transposed, then 3 MFMAs
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2) {
+                        // A operand: lane (row = SNP n, slot a = samples 8a..8a+7): two transposing reads of 4 samples each
+                        typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_p;
+                        const int trow = 8 * a + (n >> 2), tcol = (n & 3) * 4;
+                        const uint16_t* th = tw + (2 * t2 + 0) * 512, *tlw = tw + (2 * t2 + 1) * 512;
+                        const s16x4_t h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(th + trow * 16 + tcol));
+                        const s16x4_t h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(th + (trow + 4) * 16 + tcol));
+                        const s16x4_t l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(tlw + trow * 16 + tcol));
+                        const s16x4_t l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(tlw + (trow + 4) * 16 + tcol));
+                        const bf16x8 ah = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                        const bf16x8 al = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                        const int t = 2 * tp + t2;
+                        dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd1), dpacc[t], 0, 0, 0);
+                        dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd2), dpacc[t], 0, 0, 0);
+                        dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(qd1), dpacc[t], 0, 0, 0);
+                    }
+                }
+                // dQ^T rows k (hi part + lo part) and k+8 (mid part) sit 32 lanes apart: fold, lanes a<2 store
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = dq[s2][r] + __shfl_xor(dq[s2][r], 32, 64);
+                    if (a < 2 && 4 * a < KP)
+                        *reinterpret_cast<float4*>(&s_dq[wave][(16 * (2 * p + s2) + n) * KP + 4 * a]) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < nt * KP; e += NTHR) {
+            float sm = 0.f;
+#pragma unroll
+            for (int w = 0; w < MF_WAVES; ++w) sm += s_dq[w][e];
+            dqpart[(chunk * b + i0) * KP + e] = sm;
+        }
+        if (tl + 1 < ntiles) commit(cur ^ 1, i0 + MF_TS);
+        __syncthreads();
+    }
+
+    // ---- dP: columns 0..7 (hi + lo parts) and 8..15 (mid part) fold with a rotate by 8 inside the 16-lane row ----
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = dpacc[t][r];
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /*row_ror:8*/, 0xf, 0xf, false));
+            const int64_t m = snp_of(t, a, r);
+            if (n < KP && m < M) dP[m * KP + n] = v;
+        }
+    }
+    if constexpr (LOSS) {
+        const float sl = wave_sum_lane63(lossacc);
+        if (lane == 63) s_loss[wave] = sl;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < MF_WAVES; ++w) tot += s_loss[w];
+            losspart[chunk] = tot;
+        }
+    }
+}
+
+// =================================================================================================
 // pass 3, matrix-core version (CP <= 8): dV = X^T . dZ on v_mfma_f32_16x16x32_bf16.
 //   D[rows = dZ columns (hi 0-7 | mid 8-15), cols = 16 SNPs] += A[rows][32 samples] . B[32 samples][16 SNPs]
 //   with dZ split hi+mid+lo into bf16 (second accumulator holds lo|0), X exact in bf16.
@@ -886,10 +1184,30 @@ static bool use_mfma_decode() {
     return v;
 }
 
+static bool use_bf16_decode() {
+    static const bool v = [] {
+        const char* e = getenv("NADM_DECODE_IMPL");
+        return !(e && strcmp(e, "mfma_f32") == 0);
+    }();
+    return v;
+}
+
 template <int KP>
 static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, const float* P,
                               const float* Q, int SP, float* dP, float* dqpart, float* losspart, int with_loss,
                               hipStream_t st) {
+    if constexpr (KP <= 8) {
+        if (use_bf16_decode()) {
+            static_assert(mf_chunk_snps(KP) == BF_WAVES * 16 * BF_NTW, "same chunking as the f32 MFMA kernel");
+            const int64_t chunks = (M + mf_chunk_snps(KP) - 1) / mf_chunk_snps(KP);
+            dim3 grid((unsigned)chunks), block(64 * BF_WAVES);
+            if (with_loss)
+                hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
+            else
+                hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
+            return check_launch("decode_bce_bf16");
+        }
+    }
     const int64_t chunks = (M + mf_chunk_snps(KP) - 1) / mf_chunk_snps(KP);
     dim3 grid((unsigned)chunks), block(64 * mf_waves(KP));
     if (with_loss)
