@@ -80,6 +80,18 @@ int nadm_pack2bit(const uint8_t* g_dev, uint8_t* out_dev, int64_t rows, int64_t 
  * in_dev [rows,ld] -> out_dev uint8 [rows,M]. */
 int nadm_unpack2bit(const uint8_t* in_dev, uint8_t* out_dev, int64_t rows, int64_t M, int64_t ld, void* stream);
 
+/* ---- 8(f)-1: PLINK .bed -> packed sample-major, no uint8 [N,M] detour -------------------------
+ * (replaces SNPReader._read_bed + utils_c.read_bed + pack2bit for BED input: src/snp_reader.py:16-45,
+ * src/utils_c/utils.pyx:43-67, pack2bit.cu:65-117).  bed = the file contents AFTER the 3 magic bytes,
+ * SNP-major [M, ceil(N/4)], 4 samples per byte, PLINK codes mapped with the reference's table [2,3,1,0]
+ * (0b01 = missing -> 3).  out_host [N, ld] gets the layout every kernel here consumes.  counts[4] receives
+ * the number of genotypes with code 0..3 (before any flip).  If flip_if_mean_ge1 != 0 and the mean code
+ * (3s included, like the reference's G.mean(), snp_reader.py:110) is >= 1, alleles are flipped 0<->2 and
+ * *flipped is set to 1; missing stays 3 (the reference's uint8 `2 - G` turns 3 into 255, which its own GPU
+ * path masks back to 3, pack2bit.cu:29).  Synchronous, multi-threaded. */
+int nadm_bed_to_packed(const uint8_t* bed, int64_t N, int64_t M, uint8_t* out_host, int64_t ld,
+                       int64_t* counts, int32_t flip_if_mean_ge1, int32_t* flipped);
+
 /* ---- a4/a5: encoder projection  Z = X.V  (neural_admixture.py:169-172) ----------------- */
 /* rows idx[0..b) of xp are the batch (replaces Dataset_admixture.__getitem__ + collate,
  * loaders.py:62-72, and the per-step unpack2bit_gpu_to_gpu, neural_admixture.py:404-406).

@@ -6,6 +6,7 @@
 #include "../../include/nadm.h"
 #include "nadm_host.h"
 #include <math.h>
+#include <array>
 #include <thread>
 #include <vector>
 
@@ -558,6 +559,72 @@ extern "C" int nadm_pack2bit_host(const uint8_t* g, uint8_t* out, int64_t N, int
         }
         for (auto& t : th) t.join();
     }
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------
+// PLINK .bed (SNP-major, 4 samples/byte) -> sample-major packed (4 SNPs/byte): a 2-bit matrix transpose
+// with the reference's recode table [2,3,1,0] (utils.pyx:52).  Each worker owns blocks of 256 SNPs so that
+// it writes 64 contiguous bytes per sample row.
+// -------------------------------------------------------------------------------------------------
+extern "C" int nadm_bed_to_packed(const uint8_t* bed, int64_t N, int64_t M, uint8_t* out, int64_t ld, int64_t* counts,
+                                  int32_t flip_if_mean_ge1, int32_t* flipped) {
+    if (!bed || !out || !counts) return fail("nadm_bed_to_packed: null pointer");
+    if (ld * 4 < M) return fail("nadm_bed_to_packed: ld < ceil(M/4)");
+    const int64_t nb = (N + 3) / 4;                       // bytes per SNP in the .bed
+    static const uint8_t lut[4] = {2, 3, 1, 0};
+    int nt = (int)std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > 64) nt = 64;
+    const int64_t nblk = (M + 255) / 256;
+    if (nblk < nt) nt = (int)(nblk > 0 ? nblk : 1);
+    std::vector<std::array<int64_t, 4>> cnt(nt, std::array<int64_t, 4>{0, 0, 0, 0});
+    auto work = [&](int t) {
+        std::vector<uint8_t> rows(4 * 64);
+        for (int64_t blk = t; blk < nblk; blk += nt) {
+            const int64_t m0 = blk * 256;
+            const int64_t nm = (M - m0 < 256) ? (M - m0) : 256;
+            const int64_t ncol = (nm + 3) / 4;            // output bytes per row in this block
+            for (int64_t bi = 0; bi < nb; ++bi) {
+                memset(rows.data(), 0, rows.size());
+                const int ns = (int)((N - 4 * bi < 4) ? (N - 4 * bi) : 4);
+                for (int64_t j = 0; j < nm; ++j) {
+                    const uint8_t v = bed[(m0 + j) * nb + bi];
+                    for (int s4 = 0; s4 < ns; ++s4) {
+                        const uint8_t code = lut[(v >> (2 * s4)) & 3];
+                        cnt[t][code]++;
+                        rows[s4 * 64 + (j >> 2)] |= (uint8_t)(code << (2 * (j & 3)));
+                    }
+                }
+                for (int s4 = 0; s4 < ns; ++s4) memcpy(out + (4 * bi + s4) * ld + (m0 >> 2), rows.data() + s4 * 64, (size_t)ncol);
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    for (int c = 0; c < 4; ++c) { counts[c] = 0; for (int t = 0; t < nt; ++t) counts[c] += cnt[t][c]; }
+    // zero the row padding
+    const int64_t mp = (M + 3) / 4;
+    if (ld > mp)
+        for (int64_t r = 0; r < N; ++r) memset(out + r * ld + mp, 0, (size_t)(ld - mp));
+    int did = 0;
+    if (flip_if_mean_ge1 && N > 0 && M > 0) {
+        const double mean = (double)(counts[1] + 2 * counts[2] + 3 * counts[3]) / ((double)N * (double)M);
+        if (mean >= 1.0) {
+            did = 1;                                      // 0 <-> 2, 1 and 3 unchanged: c ^= ((~c & 1) << 1) on every 2-bit field
+            const int64_t tail_fields = M & 3;
+            for (int64_t r = 0; r < N; ++r) {
+                uint8_t* row = out + r * ld;
+                for (int64_t c = 0; c < mp; ++c) row[c] ^= (uint8_t)((~row[c] & 0x55) << 1);
+                if (tail_fields) row[mp - 1] &= (uint8_t)((1u << (2 * tail_fields)) - 1);    // keep the tail bits zero
+            }
+        }
+    }
+    if (flipped) *flipped = did;
     return 0;
 }
 

@@ -72,6 +72,13 @@ class Engine:
         """uint8 [N,M] CPU tensor -> packed rows in HBM.  Packs on the host (2 bits/genotype cross
         PCIe instead of 8; the reference ships unpacked bytes in 1024-row chunks with a blocking
         sync per chunk, pack2bit.cu:79-115).  ``rows``: optional row selection/order (rank shard)."""
+        self.rows_are_sharded = rows is not None
+        if hasattr(data_u8, "packed"):                   # io.PackedGenotypes: already in the kernel layout, just ship the rows
+            if data_u8.M != self.M or data_u8.packed.shape[1] != self.ld:
+                raise RuntimeError("packed genotypes do not match the engine's SNP count / row stride")
+            src = data_u8.packed if rows is None else data_u8.packed[torch.as_tensor(rows, dtype=torch.long)]
+            self.xp = src.contiguous().to(self.device)
+            return
         if data_u8.dtype != torch.uint8 or data_u8.dim() != 2 or data_u8.device.type != "cpu":
             raise RuntimeError("pack_from_host expects a uint8 [N,M] CPU tensor")
         N, M = data_u8.shape

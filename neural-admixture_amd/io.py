@@ -23,3 +23,46 @@ def save_model(model, name: str, save_dir: str) -> None:
     sd = {k: v for k, v in model.state_dict().items() if not k.startswith('decoders')}
     torch.save(sd, f'{save_dir}/{name}.pt')
     model.save_config(name, save_dir)
+
+
+class PackedGenotypes:
+    """2-bit packed, sample-major genotype matrix on the host: uint8 [N, ld] (layout of include/nadm.h).
+    Accepted by ``train`` / ``NeuralAdmixture.launch_training`` in place of the uint8 [N,M] tensor, so a BED file
+    never has to be expanded to one byte per genotype (8(f)-1)."""
+
+    def __init__(self, packed: torch.Tensor, N: int, M: int, flipped: bool = False):
+        self.packed, self.N, self.M, self.flipped = packed, int(N), int(M), bool(flipped)
+        self.shape = (self.N, self.M)
+
+    def unpack_rows(self, s: int, e: int) -> np.ndarray:
+        """uint8 [e-s, M] (host; for the init-time PCA projection only)."""
+        pk = self.packed[s:e].numpy()
+        out = np.empty((pk.shape[0], pk.shape[1], 4), dtype=np.uint8)
+        for i in range(4):
+            out[:, :, i] = (pk >> (2 * i)) & 3
+        return out.reshape(pk.shape[0], -1)[:, : self.M]
+
+
+def read_bed_packed(path: str) -> PackedGenotypes:
+    """PLINK .bed/.fam -> :class:`PackedGenotypes`, same conventions as the reference's reader
+    (src/snp_reader.py:16-45: N = lines of .fam, magic bytes skipped, M from the file size; recode table
+    [2,3,1,0]; minor-allele flip when the mean code is >= 1, :109-110)."""
+    import ctypes as C
+    from ._lib import lib, check, ptr
+    from .layout import ModelLayout
+    p = Path(path)
+    with open(p.with_suffix(".fam")) as fam:
+        N = sum(1 for _ in fam)
+    B = np.fromfile(p.with_suffix(".bed"), dtype=np.uint8, offset=3)
+    nb = (N + 3) // 4
+    assert B.shape[0] % nb == 0, "bim file doesn't match!"
+    M = B.shape[0] // nb
+    ld = ModelLayout.row_stride(M)
+    out = torch.empty((N, ld), dtype=torch.uint8)
+    counts = (C.c_int64 * 4)()
+    flipped = C.c_int32(0)
+    check(lib.nadm_bed_to_packed(C.c_void_p(B.ctypes.data), N, M, ptr(out), ld, counts, 1, C.byref(flipped)), "bed_to_packed")
+    assert counts[0] + counts[1] + counts[2] + counts[3] == N * M
+    if counts[2] == 0 and counts[3] == 0 and counts[1] == 0:
+        raise AssertionError("Only biallelic SNPs are supported.")
+    return PackedGenotypes(out, N, M, bool(flipped.value))

@@ -18,14 +18,16 @@ logging.basicConfig(stream=sys.stdout, level=logging.INFO, format="%(message)s")
 log = logging.getLogger(__name__)
 
 
-def gmm_p_init(data_np: np.ndarray, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_components: int, seed: int) -> np.ndarray:
+def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_components: int, seed: int) -> np.ndarray:
     """P_init [sum(ks), M] = clip(GMM means @ V, 5e-6, 1-5e-6) in the PCA subspace (train.py:49-68).
-    Note the projection keeps missing (3) as 1.5, exactly like the reference (train.py:52)."""
+    Note the projection keeps missing (3) as 1.5, exactly like the reference (train.py:52).
+    ``data_np``: uint8 [N,M] array or an io.PackedGenotypes (decoded 1024 rows at a time)."""
     from sklearn.mixture import GaussianMixture
     N = data_np.shape[0]
+    rows = data_np.unpack_rows if hasattr(data_np, "unpack_rows") else (lambda s, e: data_np[s:e])
     X_pca = np.zeros((N, n_components), dtype=np.float32)
     for i in range(0, N, 1024):
-        X_pca[i:i + 1024] = (data_np[i:i + 1024].astype(np.float32) / 2) @ V_CM.T
+        X_pca[i:i + 1024] = (rows(i, min(N, i + 1024)).astype(np.float32) / 2) @ V_CM.T
     X_pca = X_pca.astype("float64")
     ks = [K] if K is not None else list(range(min_k, max_k + 1))
     Ps = []
@@ -39,7 +41,8 @@ def gmm_p_init(data_np: np.ndarray, V_CM: np.ndarray, K: Optional[int], min_k, m
 def train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int, data: torch.Tensor, device: torch.device,
           num_gpus: int, hidden_size: int, master: bool, V: np.ndarray, pops, min_k: int = None, max_k: int = None,
           n_components: int = None):
-    """See module docstring.  ``data`` uint8 [N,M] CPU tensor; ``V`` numpy [C,M] (RSVD output,
+    """See module docstring.  ``data`` uint8 [N,M] CPU tensor (or an ``io.PackedGenotypes``, e.g. from
+    ``io.read_bed_packed``); ``V`` numpy [C,M] (RSVD output,
     svd.py:83); returns Ps (list of [M,k] float32), Qs (list of [N,k] float32), model."""
     if pops is not None:
         raise NotImplementedError("supervised mode (pops) is not on the accelerated path yet")
@@ -53,7 +56,7 @@ def train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int,
         log.info("")
         log.info("    Running Gaussian Mixture in PCA subspace...")
         log.info("")
-        P = gmm_p_init(data.numpy(), V, K, min_k, max_k, n_components, seed)
+        P = gmm_p_init(data if hasattr(data, "unpack_rows") else data.numpy(), V, K, min_k, max_k, n_components, seed)
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
     if num_gpus > 1 and dist.is_available() and dist.is_initialized():

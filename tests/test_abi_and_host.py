@@ -145,3 +145,51 @@ def test_output_writers(tmp_path):
     assert len(first) == 3 and re.fullmatch(r"\d\.\d{18}e[+-]\d{2}", first[0])          # savetxt default '%.18e'
     Q_P(1024, 8, ks_list=[3]).save_config("run", str(tmp_path))
     assert json.load(open(tmp_path / "run_config.json")) == {"ks": [3], "num_features": 8, "hidden_size": 1024, "activation": "relu"}
+
+
+def _bed_bytes(G):
+    """Inverse of the reference's read_bed table [2,3,1,0] (utils.pyx:52): genotype code -> PLINK 2-bit code."""
+    inv = np.array([3, 2, 0, 1], dtype=np.uint8)           # code 0 -> 0b11, 1 -> 0b10, 2 -> 0b00, 3 (missing) -> 0b01
+    N, M = G.shape
+    nb = (N + 3) // 4
+    bed = np.zeros((M, nb), dtype=np.uint8)
+    for i in range(N):
+        bed[:, i // 4] |= (inv[G[i]] << (2 * (i % 4))).astype(np.uint8)
+    return bed.reshape(-1)
+
+
+@pytest.mark.parametrize("N,M,flip", [(105, 8451, False), (7, 5, False), (13, 1030, True), (4, 256, True), (1, 3, False)])
+def test_bed_to_packed_matches_reader_semantics(N, M, flip):
+    """BED -> packed without the uint8 detour == read_bed (table [2,3,1,0]) + minor-allele flip + pack2bit."""
+    import ctypes as C
+    from neural_admixture_amd._lib import lib, check, ptr
+    from neural_admixture_amd.layout import ModelLayout
+    rng = np.random.default_rng(N * 1000 + M)
+    p = [0.15, 0.2, 0.6, 0.05] if flip else [0.7, 0.18, 0.1, 0.02]
+    Gm = rng.choice(4, size=(N, M), p=p).astype(np.uint8)
+    bed = _bed_bytes(Gm)
+    ld = ModelLayout.row_stride(M)
+    out = torch.full((N, ld), 255, dtype=torch.uint8)
+    counts = (C.c_int64 * 4)()
+    flipped = C.c_int32(0)
+    check(lib.nadm_bed_to_packed(C.c_void_p(bed.ctypes.data), N, M, ptr(out), ld, counts, 1, C.byref(flipped)))
+    assert [counts[i] for i in range(4)] == [int((Gm == c).sum()) for c in range(4)]
+    do_flip = Gm.mean() >= 1
+    assert bool(flipped.value) == do_flip
+    want = Gm.copy()
+    if do_flip:                                            # 2 - G with missing left at 3 (pack2bit masks the wrapped 255 back to 3)
+        want = np.where(Gm == 3, 3, 2 - Gm.astype(np.int16)).astype(np.uint8)
+    ref = O.pack2bit(want)
+    assert np.array_equal(out.numpy()[:, :ref.shape[1]], ref)
+    assert not out.numpy()[:, ref.shape[1]:].any()
+
+
+def test_read_bed_packed_demo_fixture(tmp_path):
+    from neural_admixture_amd.io import read_bed_packed
+    d = np.load(f"{G}/demo_k3.npz")
+    d["bed_bytes"].tofile(tmp_path / "demo.bed")
+    (tmp_path / "demo.fam").write_text("\n".join(["s"] * int(d["N"])) + "\n")
+    pg = read_bed_packed(str(tmp_path / "demo.bed"))
+    assert (pg.N, pg.M) == (int(d["N"]), int(d["M"]))
+    assert np.array_equal(pg.packed.numpy()[:, :d["G_packed"].shape[1]], d["G_packed"])
+    assert np.array_equal(pg.unpack_rows(3, 9), O.unpack2bit(d["G_packed"], int(d["M"]))[3:9])

@@ -314,3 +314,33 @@ def test_full_width_against_torch_fp32_on_device():
     check(lib.nadm_encode_bwd(ptr(e.xp), e.ld, ptr(idx), b, M, ptr(e.dZ), e.lay.CP, ptr(e.gbig), None))
     torch.cuda.synchronize()
     assert torch.equal(e.gV(), 2 * g1)
+
+
+def test_train_boundary_on_demo_from_bed(tmp_path, caplog):
+    """The drop-in boundary itself: train(...) with the reference's positional signature on BASELINE config 1
+    (demo BED, K=3, 5 epochs), fed by the BED -> packed reader (no uint8 [N,M] matrix), same RSVD V as the
+    reference run; GMM init, training, final Q, log-likelihood report; outputs written in the reference's formats."""
+    import logging
+    import neural_admixture_amd as na
+    from neural_admixture_amd.io import read_bed_packed, write_outputs, save_model
+    dev = _dev()
+    d = np.load(f"{G}/demo_k3.npz")
+    d["bed_bytes"].tofile(tmp_path / "demo.bed")
+    (tmp_path / "demo.fam").write_text("\n".join(["s"] * int(d["N"])) + "\n")
+    data = read_bed_packed(str(tmp_path / "demo.bed"))
+    with caplog.at_level(logging.INFO):
+        Ps, Qs, model = na.train(5, 800, float(d["lr"]), 3, int(d["seed"]), data, dev, 1, int(d["Hd"]), True, d["Vt"], None, None, None, 8)
+    assert Ps[0].shape == (int(d["M"]), 3) and Qs[0].shape == (int(d["N"]), 3) and Ps[0].dtype == np.float32
+    assert mx(Qs[0], d["hi_e5_Q"]) < 2e-3 and mx(Ps[0], d["hi_e5_P"]) < 1e-2
+    ll = [float(r.getMessage().split(":")[1].strip().rstrip(".")) for r in caplog.records if "Log-likelihood" in r.getMessage()]
+    assert len(ll) == 1 and abs(ll[0] - float(d["hi_e5_loglik"])) / abs(float(d["hi_e5_loglik"])) < 1e-4
+    save_model(model, "demo_run", str(tmp_path))
+    write_outputs(Qs, "demo_run", 3, None, None, tmp_path, Ps)
+    sd = torch.load(tmp_path / "demo_run.pt", weights_only=True)
+    assert "V" in sd and not any(k.startswith("decoders") for k in sd)          # src/main.py:41
+    assert np.loadtxt(tmp_path / "demo_run.3.Q").shape == (int(d["N"]), 3)
+    # infer path: reload the saved encoder and recompute Q from raw genotypes (src/inference.py:54-77)
+    m2 = na.Q_P(int(d["Hd"]), 8, ks_list=[3], is_train=False).load_state_dict(sd, device=dev)
+    Gm = O.unpack2bit(d["G_packed"], int(d["M"]))
+    probs, _ = m2(torch.from_numpy(Gm))
+    assert mx(probs[0].cpu().numpy(), Qs[0]) < 1e-6
