@@ -1,0 +1,144 @@
+"""Thin command line with the reference's flags (entry.py:20-67): ``python -m neural_admixture_amd train|infer ...``.
+Reads BED input straight into the packed layout, runs the RSVD + GMM initialisation, trains on the MI355X engine and
+writes ``{name}.{K}.Q/.P``, ``{name}.pt`` and ``{name}_config.json`` exactly where the reference does
+(src/main.py:38-44, src/inference.py:91-92).  VCF/PGEN readers are not part of this build."""
+from __future__ import annotations
+
+import argparse
+import json
+import logging
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+logging.basicConfig(stream=sys.stdout, level=logging.INFO, format="%(message)s")
+log = logging.getLogger(__name__)
+
+
+def parse_train_args(argv):
+    p = argparse.ArgumentParser(prog="neural-admixture train", description="Rapid population clustering with autoencoders - training mode")
+    p.add_argument("--epochs", type=int, default=250)
+    p.add_argument("--batch_size", type=int, default=800)
+    p.add_argument("--learning_rate", type=float, default=20e-4)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--k", type=int)
+    p.add_argument("--min_k", type=int)
+    p.add_argument("--max_k", type=int)
+    p.add_argument("--hidden_size", type=int, default=1024)
+    p.add_argument("--save_dir", required=True, type=str)
+    p.add_argument("--data_path", required=True, type=str)
+    p.add_argument("--name", required=True, type=str)
+    p.add_argument("--supervised_loss_weight", type=float, default=100)
+    p.add_argument("--pops_path", type=str, default="")
+    p.add_argument("--n_components", type=int, default=8)
+    p.add_argument("--num_gpus", type=int, default=1)
+    p.add_argument("--threads", type=int, default=1)
+    return p.parse_args(argv)
+
+
+def parse_infer_args(argv):
+    p = argparse.ArgumentParser(prog="neural-admixture infer", description="Rapid population clustering with autoencoders - inference mode")
+    p.add_argument("--out_name", required=True, type=str)
+    p.add_argument("--save_dir", required=True, type=str)
+    p.add_argument("--data_path", required=True, type=str)
+    p.add_argument("--name", required=True, type=str)
+    p.add_argument("--batch_size", type=int, default=1024)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--num_gpus", type=int, default=1)
+    p.add_argument("--threads", type=int, default=1)
+    return p.parse_args(argv)
+
+
+def _read(path):
+    from .io import read_bed_packed
+    if ".bed" not in os.path.basename(path):
+        raise SystemExit("    Invalid format: this build reads PLINK .bed input (VCF/PGEN readers are the reference's own).")
+    log.info("    Input format is BED.")
+    data = read_bed_packed(path)
+    log.info(f"    Data contains {data.N} samples and {data.M} SNPs.")
+    return data
+
+
+def _train_worker(rank, args, num_gpus, data, V, t0):
+    from .train import train
+    from .io import save_model, write_outputs
+    if num_gpus > 1:                                        # src/utils.py:69-95
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(rank)
+        torch.distributed.init_process_group("nccl", init_method="env://", rank=rank, world_size=num_gpus)
+    master = rank == 0
+    device = torch.device(f"cuda:{rank}")
+    K = args.k
+    Ps, Qs, model = train(args.epochs, args.batch_size, args.learning_rate, K, args.seed, data, device, num_gpus, args.hidden_size,
+                          master, V, None, args.min_k, args.max_k, args.n_components)
+    if master:
+        save_model(model, args.name, args.save_dir)
+        write_outputs(Qs, args.name, K, args.min_k, args.max_k, args.save_dir, Ps)
+        log.info("    Q and P matrices saved." if K is not None else "    Q and P matrices saved for all K.")
+        log.info("")
+        log.info(f"    Total elapsed time: {time.time() - t0:.2f} seconds.")
+    if num_gpus > 1:
+        torch.distributed.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    assert argv and argv[0] in ("train", "infer"), 'Please provide either the argument "train" or "infer" to choose running mode.'
+    mode, t0 = argv[0], time.time()
+    if not torch.cuda.is_available():
+        raise SystemExit("neural_admixture_amd needs a ROCm GPU; use the reference for --num_gpus 0 (CPU) runs.")
+    if mode == "train":
+        args = parse_train_args(argv[1:])
+        assert args.epochs > 0 and args.batch_size > 0 and args.learning_rate > 0 and args.hidden_size > 0 and args.n_components > 0
+        if args.pops_path:
+            raise SystemExit("supervised mode (--pops_path) is not on the accelerated path yet")
+        if args.k is not None:
+            assert args.k > 1, "Please select K > 1."
+            log.info(f"    Running on K = {args.k}.")
+        elif args.min_k is not None and args.max_k is not None:
+            assert args.min_k > 1 and args.max_k > args.min_k
+            log.info(f"    Running from K={args.min_k} to K={args.max_k}.")
+        else:
+            raise ValueError("Please provide either --k or both --min_k and --max_k.")
+        num_gpus = max(1, min(args.num_gpus, torch.cuda.device_count()))
+        from .svd import RSVD
+        data = _read(args.data_path)
+        log.info("")
+        log.info("    Running SVD...")
+        V = RSVD(data, data.N, data.M, args.n_components, args.seed)
+        if num_gpus > 1:
+            data.packed.share_memory_()
+            torch.multiprocessing.spawn(_train_worker, args=(args, num_gpus, data, V, t0), nprocs=num_gpus)
+        else:
+            _train_worker(0, args, 1, data, V, t0)
+        return 0
+    args = parse_infer_args(argv[1:])
+    from .model import Q_P
+    from .io import write_outputs
+    with open(f"{args.save_dir}/{args.name}_config.json") as fb:
+        cfg = json.load(fb)
+    sd = torch.load(f"{args.save_dir}/{args.name}.pt", map_location="cpu", weights_only=True)
+    model = Q_P(int(cfg["hidden_size"]), int(cfg["num_features"]), ks_list=cfg["ks"], is_train=False)
+    model.load_state_dict(sd, device=torch.device("cuda:0"), max_batch=args.batch_size)
+    data = _read(args.data_path)
+    eng = model.engine
+    eng.pack_from_host(data)
+    idx = torch.arange(data.N, dtype=torch.int32, device=eng.device)
+    outs = [[] for _ in cfg["ks"]]
+    for s in range(0, data.N, args.batch_size):
+        bb = min(args.batch_size, data.N - s)
+        for h, q in enumerate(eng.infer_q(idx[s:s + bb], bb)):
+            outs[h].append(q.cpu().numpy())
+    Qs = [np.concatenate(o, axis=0) for o in outs]
+    K = cfg["ks"][0] if len(cfg["ks"]) == 1 else None
+    write_outputs(Qs, args.out_name, K, cfg["ks"][0], cfg["ks"][-1], args.save_dir)
+    log.info(f"    Total elapsed time: {time.time() - t0:.2f} seconds.")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -193,3 +193,26 @@ def test_read_bed_packed_demo_fixture(tmp_path):
     assert (pg.N, pg.M) == (int(d["N"]), int(d["M"]))
     assert np.array_equal(pg.packed.numpy()[:, :d["G_packed"].shape[1]], d["G_packed"])
     assert np.array_equal(pg.unpack_rows(3, 9), O.unpack2bit(d["G_packed"], int(d["M"]))[3:9])
+
+
+def test_rsvd_matches_reference_on_demo():
+    """8(f)-2: same Omega stream, QR/SVD steps and sign flip as src/svd.py:39-83 (host path, no GPU)."""
+    from neural_admixture_amd.svd import RSVD
+    from neural_admixture_amd.io import PackedGenotypes
+    d = np.load(f"{G}/demo_k3.npz")
+    Gm = O.unpack2bit(d["G_packed"], int(d["M"]))
+    V = RSVD(Gm, Gm.shape[0], Gm.shape[1], 8, int(d["seed"]), device=None)
+    assert V.shape == d["Vt"].shape and np.abs(V - d["Vt"]).max() < 1e-5
+    ld = d["G_packed"].shape[1] + (-d["G_packed"].shape[1]) % 16
+    pk = np.zeros((Gm.shape[0], ld), dtype=np.uint8)
+    pk[:, :d["G_packed"].shape[1]] = d["G_packed"]
+    V2 = RSVD(PackedGenotypes(torch.from_numpy(pk), Gm.shape[0], Gm.shape[1]), Gm.shape[0], Gm.shape[1], 8, int(d["seed"]), device=None)
+    assert np.abs(V2 - d["Vt"]).max() < 1e-5
+
+
+def test_cli_parsers_have_the_reference_flags():
+    from neural_admixture_amd.cli import parse_train_args, parse_infer_args
+    a = parse_train_args(["--save_dir", "o", "--data_path", "x.bed", "--name", "n", "--k", "3"])
+    assert (a.epochs, a.batch_size, a.learning_rate, a.seed, a.hidden_size, a.n_components) == (250, 800, 2e-3, 42, 1024, 8)   # entry.py:27-43
+    b = parse_infer_args(["--out_name", "o", "--save_dir", "s", "--data_path", "x.bed", "--name", "n"])
+    assert b.batch_size == 1024 and b.seed == 42                                                                           # entry.py:57-65

@@ -344,3 +344,23 @@ def test_train_boundary_on_demo_from_bed(tmp_path, caplog):
     Gm = O.unpack2bit(d["G_packed"], int(d["M"]))
     probs, _ = m2(torch.from_numpy(Gm))
     assert mx(probs[0].cpu().numpy(), Qs[0]) < 1e-6
+
+
+def test_cli_train_and_infer_demo(tmp_path):
+    """`python -m neural_admixture_amd train|infer` on the demo BED: RSVD (GPU, from packed) + GMM init + training +
+    outputs in the reference's file formats; infer reproduces Q from the saved encoder."""
+    from neural_admixture_amd import cli
+    _dev()
+    d = np.load(f"{G}/demo_k3.npz")
+    d["bed_bytes"].tofile(tmp_path / "demo.bed")
+    (tmp_path / "demo.fam").write_text("\n".join(["s"] * int(d["N"])) + "\n")
+    out = tmp_path / "out"
+    assert cli.main(["train", "--epochs", "5", "--k", "3", "--name", "run", "--data_path", str(tmp_path / "demo.bed"),
+                     "--save_dir", str(out), "--seed", "42", "--num_gpus", "1", "--threads", "1"]) == 0
+    Q = np.loadtxt(out / "run.3.Q")
+    P = np.loadtxt(out / "run.3.P")
+    assert Q.shape == (int(d["N"]), 3) and P.shape == (int(d["M"]), 3)
+    assert mx(Q, d["hi_e5_Q"]) < 5e-3 and mx(P, d["hi_e5_P"]) < 2e-2        # RSVD runs on the GPU here: V differs at 1e-6
+    assert (out / "run.pt").exists() and (out / "run_config.json").exists()
+    assert cli.main(["infer", "--name", "run", "--save_dir", str(out), "--out_name", "again", "--data_path", str(tmp_path / "demo.bed")]) == 0
+    assert mx(np.loadtxt(out / "again.3.Q"), Q) < 1e-6
