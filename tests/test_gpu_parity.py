@@ -364,3 +364,31 @@ def test_cli_train_and_infer_demo(tmp_path):
     assert (out / "run.pt").exists() and (out / "run_config.json").exists()
     assert cli.main(["infer", "--name", "run", "--save_dir", str(out), "--out_name", "again", "--data_path", str(tmp_path / "demo.bed")]) == 0
     assert mx(np.loadtxt(out / "again.3.Q"), Q) < 1e-6
+
+
+def test_ddp_step_on_rccl_world1_equals_plain_step():
+    """The RCCL code path (async all-reduce of the flat gradient views, stream waits, 1/world scaling) on a
+    one-rank NCCL group: must be bit-identical to the single-GPU step."""
+    import torch.distributed as dist
+    dev = _dev()
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 1000))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        Gm = O.synth_genotypes(70, 2300, 4, seed=11)
+        rng = np.random.default_rng(3)
+        p = O.make_params(3, (rng.standard_normal((2300, 8)) / 48).astype(np.float32), rng.uniform(0.1, 0.9, (5, 2300)).astype(np.float32), 64, [5])
+        e1, e2 = make_engine(Gm, p, 70), make_engine(Gm, p, 70)
+        idx = torch.arange(70, dtype=torch.int32, device=dev)
+        for _ in range(3):
+            e1.train_step(idx, 70, 2e-3, True)
+            e2.train_step_ddp(idx, 70, 2e-3, 1, True)
+        torch.cuda.synchronize()
+        assert torch.equal(e1.big, e2.big) and torch.equal(e1.small, e2.small)
+        assert e1.read_loss() == e2.read_loss()
+    finally:
+        if created:
+            dist.destroy_process_group()
