@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Wall-clock of full default runs (250 epochs, batch 800) on the 1000-Genomes-scale configs of BASELINE.json:
+c2 = 2504 samples x 600k SNPs, K=7 single head; c3 = same matrix, multi-head K=2..10.  Synthetic admixture-model
+genotypes generated on the device; RSVD (GPU, from packed) + GMM init + training + final Q + log-likelihood + writing
+.Q/.P, i.e. everything `neural-admixture train` does after reading the file.  Usage: full_run.py [c2|c3] [epochs]"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "c2"
+    epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 250
+    import neural_admixture_amd as na
+    from neural_admixture_amd._lib import lib, check, ptr
+    from neural_admixture_amd.io import PackedGenotypes, write_outputs, save_model
+    from neural_admixture_amd.layout import ModelLayout
+    from neural_admixture_amd.svd import RSVD
+    dev = torch.device("cuda:0")
+    N, M, Ktrue = 2504, 600_000, 7
+    ld = ModelLayout.row_stride(M)
+    torch.manual_seed(1234)
+    Fq = (0.5 * torch.distributions.Beta(torch.tensor(0.5), torch.tensor(0.5)).sample((Ktrue, M))).clamp(0.005, 0.5).float().to(dev)
+    Qt = torch.distributions.Dirichlet(torch.full((Ktrue,), 0.2)).sample((N,)).float().to(dev)
+    xp = torch.empty((N, ld), dtype=torch.uint8, device=dev)
+    check(lib.nadm_synth_packed(ptr(xp), N, 0, M, ld, ptr(Qt), ptr(Fq), Ktrue, 0.01, 1234, None))
+    torch.cuda.synchronize()
+    data = PackedGenotypes(xp.cpu(), N, M)
+    del xp
+    out = {"config": which, "N": N, "M": M, "epochs": epochs}
+    t0 = time.time()
+    V = RSVD(data, N, M, 8, 42)
+    out["rsvd_s"] = time.time() - t0
+    K, mn, mx = (7, None, None) if which == "c2" else (None, 2, 10)
+    t1 = time.time()
+    Ps, Qs, model = na.train(epochs, 800, 2e-3, K, 42, data, dev, 1, 1024, True, V, None, mn, mx, 8)
+    torch.cuda.synchronize()
+    out["train_call_s"] = time.time() - t1          # GMM init + pack/H2D + epochs + final Q + log-likelihood
+    with tempfile.TemporaryDirectory() as td:
+        t2 = time.time()
+        save_model(model, "run", td)
+        write_outputs(Qs, "run", K, mn, mx, td, Ps)
+        out["write_s"] = time.time() - t2
+    out["total_s"] = time.time() - t0
+    # epoch-loop-only timing: re-run the loop alone on the resident engine state
+    eng = model.engine
+    idx = torch.randperm(N, device=dev).to(torch.int32)
+    torch.cuda.synchronize()
+    t3 = time.time()
+    for _ in range(10):
+        for s in range(0, N, 800):
+            bb = min(800, N - s)
+            eng.train_step(idx[s:s + bb], bb, 2e-3, False)
+    torch.cuda.synchronize()
+    ep = (time.time() - t3) / 10
+    out["epoch_s"] = ep
+    out["genotypes_per_s_epoch_loop"] = N * M / ep
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
