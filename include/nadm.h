@@ -123,6 +123,15 @@ int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const float* dqpart
                  float* dZ, float* grad_small,
                  const float* losspart, int64_t n_loss, double* loss_acc, void* stream);
 
+/* ---- 8(f): supervised mode,  weight * CrossEntropyLoss(sum)(Q_0, labels)  (neural_admixture.py:293,470-473;
+ * the reference feeds the softmax OUTPUT of head 0 to CrossEntropyLoss, i.e. a second softmax; default weight 100).
+ * labels int32 [rows] = class per resident row (train.py:78-81 mapping), idx = the batch's rows (NULL: labels is
+ * already per batch row); n_classes must equal k (train.py:79 asserts it).  Call after head 0's nadm_decode_bce and
+ * before nadm_mlp_bwd: ADDS weight*(softmax(q_i) - onehot(y_i)) to chunk 0 of head 0's dQ slab (dqpart0 [.., b, kp])
+ * and writes the weighted loss to *loss_slot (one float that nadm_mlp_bwd's n_loss range should cover). */
+int nadm_supervised_ce(const float* Q, int32_t SP, int32_t k, int32_t kp, const int32_t* labels, const int32_t* idx,
+                       int32_t b, int32_t n_classes, float weight, float* dqpart0, float* loss_slot, void* stream);
+
 /* ---- a11: dV = X^T . dZ  (autograd of neural_admixture.py:172) --------------------------- */
 int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                     const float* dZ, int32_t CP, float* dV, void* stream);

@@ -10,7 +10,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnadm.so")
+LIB_PATH = os.environ.get("NADM_LIB") or os.path.join(_HERE, "csrc", "libnadm.so")   # NADM_LIB: another build of the same library
 
 MAX_HEADS = 32
 
@@ -48,6 +48,7 @@ def _load():
         "nadm_mlp_fwd": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]),
         "nadm_decode_bce": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
         "nadm_mlp_bwd": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]),
+        "nadm_supervised_ce": (C.c_int, [vp, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp]),
         "nadm_encode_bwd": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp]),
         "nadm_adam": (C.c_int, [vp, vp, vp, vp, i64, i64, f32, i32, f32, vp]),
         "nadm_synth_packed": (C.c_int, [vp, i64, i64, i64, i64, vp, vp, i32, f32, u64, vp]),

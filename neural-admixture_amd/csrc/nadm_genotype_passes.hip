@@ -497,10 +497,25 @@ __device__ __forceinline__ float row16_sum(float v) {     // sum over the 16 lan
     return v;
 }
 
+// Shape of the bf16 matrix-core pass-2 kernel (KP <= 8), tuned on MI355X with bench.py (b=800, M=500k, K=8; decode time
+// with / without the loss):  8 waves x 4 tiles, occupancy 2: 435 / 373 us;  8 x 2, occ. 4: 401 / 331;  4 x 2, occ. 4:
+// 400 / 334;  4 waves x 4 tiles at <= 168 VGPRs (3 blocks = 3 waves per SIMD, 42 KB LDS each): 388 / 310  <- default.
+#ifndef NADM_BF_WAVES
+#define NADM_BF_WAVES 4      // waves per block; chunk = WAVES * NTW * 16 SNPs
+#endif
+#ifndef NADM_BF_NTW
+#define NADM_BF_NTW 4        // 16-SNP tiles per wave (2 or 4)
+#endif
+#ifndef NADM_BF_TS
+#define NADM_BF_TS 64        // samples per LDS tile
+#endif
+#ifndef NADM_BF_WPE
+#define NADM_BF_WPE 3        // waves per SIMD the register allocator must leave room for
+#endif
 constexpr int mf_ts(int kp) { return kp <= 8 ? 64 : 32; }   // samples per LDS tile in the matrix-core kernel (LDS <= 64 KB)
-constexpr int mf_waves(int kp) { return 8; }   // 2 waves/SIMD with a 256-VGPR budget: latency is hidden by ILP across a wave's NTW independent tiles
+constexpr int mf_waves(int kp) { return kp <= 8 ? NADM_BF_WAVES : 8; }   // waves per block (kp <= 8: shared with the bf16 kernel so both write the same dQ slabs)
 constexpr int MF_RS_PAD = 16;       // LDS row stride of the X tile = row bytes + 16 (16 B aligned, de-phased banks)
-constexpr int mf_ntw(int kp) { return kp <= 8 ? 4 : 2; }            // 16-SNP tiles per wave (dP accumulators: NTW*4*KP regs <= 128)
+constexpr int mf_ntw(int kp) { return kp <= 8 ? NADM_BF_NTW : 2; }            // 16-SNP tiles per wave (dP accumulators: NTW*4*KP regs <= 128)
 constexpr int mf_chunk_snps(int kp) { return mf_waves(kp) * 16 * mf_ntw(kp); }
 
 // gradient w.r.t. the pre-clamp reconstruction and (optionally) the BCE loss term of one genotype.
@@ -751,10 +766,8 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast
 // max, rcp, compare/select and the conversions have no packed form.
 // Returns dR (gradient w.r.t. the pre-clamp reconstruction) and accumulates the BCE loss terms.
 // cf = float(code) with missing already mapped to 0, so x = cf/2.
-// loss uses one log per genotype: x=0 -> log(1-r), x=1 -> log r, x=.5 -> .5*log(r(1-r)); the -100 clamps of the
-// two separate terms can only bind when r is exactly 0 or 1, where the merged form gives the same value.
 template <bool LOSS>
-__device__ __forceinline__ f32x2_t bce_elem2(const float d0, const float d1, const uint32_t c0, const uint32_t c1, float& lossacc) {
+__device__ __forceinline__ f32x2_t bce_elem2(const float d0, const float d1, const uint32_t c0, const uint32_t c1, f32x2_t& lossacc) {
     const f32x2_t cf = {(float)c0, (float)c1};
     const f32x2_t r = {__builtin_amdgcn_fmed3f(d0, 0.f, 1.f), __builtin_amdgcn_fmed3f(d1, 0.f, 1.f)};
     const f32x2_t omr = (f32x2_t){1.f, 1.f} - r;
@@ -762,35 +775,40 @@ __device__ __forceinline__ f32x2_t bce_elem2(const float d0, const float d1, con
     const f32x2_t inv = {__builtin_amdgcn_rcpf(fmaxf(den.x, 1e-12f)), __builtin_amdgcn_rcpf(fmaxf(den.y, 1e-12f))};
     const f32x2_t g = (r - (f32x2_t){0.5f, 0.5f} * cf) * inv;
     if constexpr (LOSS) {
-        const float kLn2 = 0.69314718055994530942f;
-        const float t0 = (c0 == 2u) ? r.x : ((c0 == 1u) ? den.x : omr.x);
-        const float t1 = (c1 == 2u) ? r.y : ((c1 == 1u) ? den.y : omr.y);
-        const float w0 = (c0 == 1u) ? 0.5f * kLn2 : kLn2, w1 = (c1 == 1u) ? 0.5f * kLn2 : kLn2;
-        const float l0 = fmaxf(__builtin_amdgcn_logf(t0), -100.f / kLn2), l1 = fmaxf(__builtin_amdgcn_logf(t1), -100.f / kLn2);
-        lossacc = fmaf(-w0, l0, lossacc);
-        lossacc = fmaf(-w1, l1, lossacc);
+        // lossacc accumulates x*max(log2 r, c) + (1-x)*max(log2(1-r), c), c = -100/ln2 (the caller applies -ln2).
+        // Two logs and packed fmas, no compares/selects on the code: the select-based single-log form costs as many
+        // issue slots and its conditions keep ~60 more registers alive.
+        constexpr float kC = -100.f / 0.69314718055994530942f;
+        const f32x2_t l1 = {fmaxf(__builtin_amdgcn_logf(r.x), kC), fmaxf(__builtin_amdgcn_logf(r.y), kC)};
+        const f32x2_t l0 = {fmaxf(__builtin_amdgcn_logf(omr.x), kC), fmaxf(__builtin_amdgcn_logf(omr.y), kC)};
+        const f32x2_t x = (f32x2_t){0.5f, 0.5f} * cf;
+        lossacc = __builtin_elementwise_fma(x, l1, lossacc);
+        lossacc = __builtin_elementwise_fma((f32x2_t){1.f, 1.f} - x, l0, lossacc);
+        asm volatile("" : "+v"(lossacc));     // pin the accumulation here: otherwise LLVM sinks all the logs of a tile pair
+                                              // to the end of the loop body and keeps their 32 inputs alive (+60 VGPRs)
     }
     return (f32x2_t){(r.x == d0) ? g.x : 0.f, (r.y == d1) ? g.y : 0.f};
 }
 
-constexpr int BF_WAVES = 8;
-constexpr int BF_NTW = 4;
-constexpr int BF_TS = 64;
+constexpr int BF_WAVES = NADM_BF_WAVES;
+constexpr int BF_NTW = NADM_BF_NTW;     // 16-SNP tiles per wave
+constexpr int BF_TS = NADM_BF_TS;       // samples per LDS tile
 
 template <int KP, bool LOSS>
-__global__ __launch_bounds__(64 * BF_WAVES) void decode_bce_bf16_kernel(
+__global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(NADM_BF_WPE, NADM_BF_WPE))) void decode_bce_bf16_kernel(
     const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
     const float* __restrict__ P, const float* __restrict__ Q, int SP,
     float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart) {
     static_assert(KP <= 8, "one 8-wide k slot");
+    static_assert(BF_NTW == 4 || BF_NTW == 2, "tile bits are read as one 32- or 16-bit word");
     constexpr int NTW = BF_NTW, MF_WAVES = BF_WAVES, MF_TS = BF_TS;
     constexpr int RB = MF_WAVES * 4 * NTW;               // 128 packed bytes per row per block
     constexpr int RS = RB + MF_RS_PAD;
     constexpr int PPR = RB / 16;
     constexpr int NTHR = 64 * MF_WAVES;
-    __shared__ __attribute__((aligned(16))) uint8_t s_x[2][MF_TS * RS];
-    __shared__ __attribute__((aligned(16))) uint4 s_qr[2][MF_TS / 16][2][64];   // B operands of R^T per 16-sample tile
-    __shared__ __attribute__((aligned(16))) uint4 s_qd[2][MF_TS / 32][2][64];   // B operands of dP per 32-sample pair
+    __shared__ __attribute__((aligned(16))) uint8_t s_x[MF_TS * RS];
+    __shared__ __attribute__((aligned(16))) uint4 s_qr[MF_TS / 16][2][64];   // B operands of R^T per 16-sample tile
+    __shared__ __attribute__((aligned(16))) uint4 s_qd[MF_TS / 32][2][64];   // B operands of dP per 32-sample pair
     __shared__ __attribute__((aligned(16))) float s_dq[MF_WAVES][MF_TS * KP];
     __shared__ __attribute__((aligned(16))) uint16_t s_t[MF_WAVES][2][2][32 * 16];  // per wave: [SNP tile of the pair][hi / lo][32 samples][16 SNPs]
     __shared__ float s_loss[MF_WAVES];
@@ -803,8 +821,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) void decode_bce_bf16_kernel(
     auto snp_of = [&](int t, int ab, int r) -> int64_t { return snp_wave0 + 4 * NTW * ab + 4 * t + r; };
 
     // zero the operand slots that are never written (k-slots 2,3 of the second R MFMA; columns 8..15 of the second dP MFMA)
-    for (int e = tid; e < 2 * (MF_TS / 16) * 2 * 64; e += NTHR) (&s_qr[0][0][0][0])[e] = make_uint4(0, 0, 0, 0);
-    for (int e = tid; e < 2 * (MF_TS / 32) * 2 * 64; e += NTHR) (&s_qd[0][0][0][0])[e] = make_uint4(0, 0, 0, 0);
+    for (int e = tid; e < (MF_TS / 16) * 2 * 64; e += NTHR) (&s_qr[0][0][0])[e] = make_uint4(0, 0, 0, 0);
+    for (int e = tid; e < (MF_TS / 32) * 2 * 64; e += NTHR) (&s_qd[0][0][0])[e] = make_uint4(0, 0, 0, 0);
 
     // ---- resident A operands built from P ----
     uint4 pa_r1[NTW], pa_r2[NTW];            // R^T: lane (row = SNP n, slot a)
@@ -844,57 +862,67 @@ __global__ __launch_bounds__(64 * BF_WAVES) void decode_bce_bf16_kernel(
     f32x4 dpacc[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) dpacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float lossacc = 0.f;
+    f32x2_t lossacc = {0.f, 0.f};
 
     // ---- X / Q staging (same scheme as the f32 MFMA kernel: unconditional clamped loads, index one tile ahead) ----
     constexpr int NPIECE = MF_TS * PPR;
-    static_assert(NPIECE == NTHR && MF_TS * 8 == NTHR, "one X piece and one Q element per thread");
-    const int pr = tid / PPR, pc16 = tid % PPR;
+    constexpr int QPT = (MF_TS * 8 + NTHR - 1) / NTHR;     // Q elements staged per thread
+    static_assert(NPIECE <= NTHR && (MF_TS * 8) % QPT == 0 && NTHR % 8 == 0, "at most one X piece per thread");
+    const bool has_piece = tid < NPIECE, has_q = tid < MF_TS * 8 / QPT;
+    const int pr = has_piece ? tid / PPR : 0, pc16 = tid % PPR;
     const int64_t poff = byte0 + pc16 * 16;
     const bool pcol_ok = poff < ld;
     const int64_t poff_c = pcol_ok ? poff : 0;
     auto row_index = [&](int i0) -> int32_t { const int smp = i0 + pr; return idx[smp < b ? smp : b - 1]; };
     int32_t row_pref = row_index(0);
     uint4 stage;
-    float qstage;
-    const int qr = tid >> 3, qk = tid & 7;                 // this thread's Q element: row qr of the tile, column qk
+    float qstage[QPT];
+    const int qr0 = has_q ? tid >> 3 : 0, qk = tid & 7;    // this thread's Q elements: rows qr0 + j*NTHR/8 of the tile, column qk
     auto issue = [&](int i0) {
-        const int smp = i0 + qr < b ? i0 + qr : b - 1;
-        qstage = Q[(int64_t)smp * SP + (qk < KP ? qk : 0)];
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            const int qr = qr0 + j * (MF_TS / QPT);
+            const int smp = i0 + qr < b ? i0 + qr : b - 1;
+            qstage[j] = Q[(int64_t)smp * SP + (qk < KP ? qk : 0)];
+        }
         stage = *reinterpret_cast<const uint4*>(xp + (int64_t)row_pref * ld + poff_c);
         row_pref = row_index(i0 + MF_TS);
     };
-    auto commit = [&](int buf, int i0) {
+    auto commit = [&](int i0) {
         const bool ok = pcol_ok && (i0 + pr < b);
-        *reinterpret_cast<uint4*>(&s_x[buf][pr * RS + pc16 * 16]) = ok ? stage : make_uint4(0, 0, 0, 0);
-        // Q element -> bf16 pieces scattered into the MFMA operand images
-        const float v = (i0 + qr < b && qk < KP) ? qstage : 0.f;
-        uint32_t h, md, lo;
-        split3(v, h, md, lo);
-        const int st = qr >> 4, i = qr & 15;
-        uint16_t* r1 = reinterpret_cast<uint16_t*>(&s_qr[buf][st][0][0]) + qk;       // + lane*8 (uint16 units)
-        uint16_t* r2 = reinterpret_cast<uint16_t*>(&s_qr[buf][st][1][0]) + qk;
-        r1[(i) * 8] = (uint16_t)h;        r1[(i + 32) * 8] = (uint16_t)h;            // slots 0,2: Qh
-        r1[(i + 16) * 8] = (uint16_t)md;  r1[(i + 48) * 8] = (uint16_t)md;           // slots 1,3: Qm
-        r2[(i) * 8] = (uint16_t)lo;       r2[(i + 16) * 8] = (uint16_t)h;            // slots 0,1: Ql, Qh
-        const int pair = qr >> 5, within = qr & 31, q8 = within >> 3, e = within & 7;
-        uint16_t* d1 = reinterpret_cast<uint16_t*>(&s_qd[buf][pair][0][0]) + e;
-        uint16_t* d2 = reinterpret_cast<uint16_t*>(&s_qd[buf][pair][1][0]) + e;
-        d1[(q8 * 16 + qk) * 8] = (uint16_t)h;                                        // columns 0..7: Qh
-        d1[(q8 * 16 + qk + 8) * 8] = (uint16_t)md;                                   // columns 8..15: Qm
-        d2[(q8 * 16 + qk) * 8] = (uint16_t)lo;                                       // columns 0..7: Ql
+        if (has_piece) *reinterpret_cast<uint4*>(&s_x[pr * RS + pc16 * 16]) = ok ? stage : make_uint4(0, 0, 0, 0);
+        if (!has_q) return;
+#pragma unroll
+        for (int j = 0; j < QPT; ++j) {
+            // Q element -> bf16 pieces scattered into the MFMA operand images
+            const int qr = qr0 + j * (MF_TS / QPT);
+            const float v = (i0 + qr < b && qk < KP) ? qstage[j] : 0.f;
+            uint32_t h, md, lo;
+            split3(v, h, md, lo);
+            const int st = qr >> 4, i = qr & 15;
+            uint16_t* r1 = reinterpret_cast<uint16_t*>(&s_qr[st][0][0]) + qk;       // + lane*8 (uint16 units)
+            uint16_t* r2 = reinterpret_cast<uint16_t*>(&s_qr[st][1][0]) + qk;
+            r1[(i) * 8] = (uint16_t)h;        r1[(i + 32) * 8] = (uint16_t)h;            // slots 0,2: Qh
+            r1[(i + 16) * 8] = (uint16_t)md;  r1[(i + 48) * 8] = (uint16_t)md;           // slots 1,3: Qm
+            r2[(i) * 8] = (uint16_t)lo;       r2[(i + 16) * 8] = (uint16_t)h;            // slots 0,1: Ql, Qh
+            const int pair = qr >> 5, within = qr & 31, q8 = within >> 3, e = within & 7;
+            uint16_t* d1 = reinterpret_cast<uint16_t*>(&s_qd[pair][0][0]) + e;
+            uint16_t* d2 = reinterpret_cast<uint16_t*>(&s_qd[pair][1][0]) + e;
+            d1[(q8 * 16 + qk) * 8] = (uint16_t)h;                                        // columns 0..7: Qh
+            d1[(q8 * 16 + qk + 8) * 8] = (uint16_t)md;                                   // columns 8..15: Qm
+            d2[(q8 * 16 + qk) * 8] = (uint16_t)lo;                                       // columns 0..7: Ql
+        }
     };
 
     __syncthreads();                                        // zero fill visible before the first commit
     issue(0);
-    commit(0, 0);
+    commit(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 
     uint16_t* const tw = &s_t[wave][0][0][0];
     const int ntiles = (b + MF_TS - 1) / MF_TS;
     for (int tl = 0; tl < ntiles; ++tl) {
-        const int cur = tl & 1;
         const int i0 = tl * MF_TS;
         const int nt = min(MF_TS, b - i0);
         if (tl + 1 < ntiles) issue(i0 + MF_TS);
@@ -907,13 +935,15 @@ __global__ __launch_bounds__(64 * BF_WAVES) void decode_bce_bf16_kernel(
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const int st = 2 * p + s2;
-                    uint32_t w = *reinterpret_cast<const uint32_t*>(&s_x[cur][(16 * st + n) * RS + wave * 16 + 4 * a]);
+                    uint32_t w;                                         // the lane's NTW bytes: byte t = 4 SNPs of tile t
+                    if constexpr (NTW == 4) w = *reinterpret_cast<const uint32_t*>(&s_x[(16 * st + n) * RS + wave * 16 + 4 * a]);
+                    else w = *reinterpret_cast<const uint16_t*>(&s_x[(16 * st + n) * RS + wave * 8 + 2 * a]);
                     w &= ~((w & (w >> 1) & 0x55555555u) * 3u);         // missing (3) -> 0
                     bits[s2] = w;
-                    qb1[s2] = s_qr[cur][st][0][lane];
-                    qb2[s2] = s_qr[cur][st][1][lane];
+                    qb1[s2] = s_qr[st][0][lane];
+                    qb2[s2] = s_qr[st][1][lane];
                 }
-                const uint4 qd1 = s_qd[cur][p][0][lane], qd2 = s_qd[cur][p][1][lane];
+                const uint4 qd1 = s_qd[p][0][lane], qd2 = s_qd[p][1][lane];
                 f32x4 dq[2];
                 dq[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 dq[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -940,6 +970,9 @@ __global__ __launch_bounds__(64 * BF_WAVES) void decode_bce_bf16_kernel(
                             // transposition buffer of this SNP tile: T[t2][hl][sample 16*s2 + n][SNP 4a .. 4a+3]  (row = 16 bf16 = 32 B)
                             *reinterpret_cast<uint2*>(tw + (2 * t2 + 0) * 512 + (16 * s2 + n) * 16 + 4 * a) = make_uint2(hi[t2][0], hi[t2][1]);
                             *reinterpret_cast<uint2*>(tw + (2 * t2 + 1) * 512 + (16 * s2 + n) * 16 + 4 * a) = make_uint2(lo[t2][0], lo[t2][1]);
+#ifdef NADM_BF_SCHED
+                            __builtin_amdgcn_sched_barrier(0);
+#endif
                         }
                         // dQ^T of this sample tile: the lane's 8 dR values (2 tiles x 4 SNPs) are the B operand
                         const bf16x8 bh = as_bf16x8(make_uint4(hi[0][0], hi[0][1], hi[1][0], hi[1][1]));
@@ -985,7 +1018,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) void decode_bce_bf16_kernel(
             for (int w = 0; w < MF_WAVES; ++w) sm += s_dq[w][e];
             dqpart[(chunk * b + i0) * KP + e] = sm;
         }
-        if (tl + 1 < ntiles) commit(cur ^ 1, i0 + MF_TS);
+        if (tl + 1 < ntiles) commit(i0 + MF_TS);
         __syncthreads();
     }
 
@@ -1001,7 +1034,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) void decode_bce_bf16_kernel(
         }
     }
     if constexpr (LOSS) {
-        const float sl = wave_sum_lane63(lossacc);
+        const float sl = wave_sum_lane63(-0.69314718055994530942f * (lossacc.x + lossacc.y));
         if (lane == 63) s_loss[wave] = sl;
         __syncthreads();
         if (tid == 0) {

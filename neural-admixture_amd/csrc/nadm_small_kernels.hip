@@ -300,6 +300,42 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_kernel(nadm_heads_t hd, const f
 }
 
 // =================================================================================================
+// supervised_ce: weight * CrossEntropyLoss(sum) applied to the softmax OUTPUT of head 0 as logits
+// (neural_admixture.py:293,470-473).  One block; thread t takes samples t, t+256, ...
+//   loss_i = logsumexp(q_i) - q_i[y_i],  d/dq_ij = softmax(q_i)_j - [j == y_i]
+// The gradient is added to chunk 0 of head 0's dQ slab (mlp_bwd sums the chunks), the weighted loss
+// goes to one slot of the losspart array.  Fixed order -> deterministic.
+// =================================================================================================
+__global__ __launch_bounds__(256) void supervised_ce_kernel(const float* __restrict__ Q, int SP, int k, int kp,
+                                                           const int32_t* __restrict__ labels, const int32_t* __restrict__ idx,
+                                                           int b, float weight, float* __restrict__ dq0, float* __restrict__ loss_slot) {
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    for (int i = tid; i < b; i += 256) {
+        const float* q = Q + (int64_t)i * SP;
+        const int y = labels[idx ? idx[i] : i];
+        float qm = q[0];
+        for (int j = 1; j < k; ++j) qm = fmaxf(qm, q[j]);
+        float se = 0.f;
+        for (int j = 0; j < k; ++j) se += expf(q[j] - qm);
+        const float inv = 1.f / se;
+        float qy = 0.f;
+        for (int j = 0; j < k; ++j) {
+            const float sm = expf(q[j] - qm) * inv;
+            const float onehot = (j == y) ? 1.f : 0.f;
+            if (j == y) qy = q[j];
+            dq0[(int64_t)i * kp + j] += weight * (sm - onehot);
+        }
+        acc += (double)(qm + logf(se)) - (double)qy;
+    }
+    acc = wave_sum_all_f64(acc);
+    __shared__ double s_l[4];
+    if ((tid & 63) == 0) s_l[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) *loss_slot = (float)((double)weight * ((s_l[0] + s_l[1]) + (s_l[2] + s_l[3])));
+}
+
+// =================================================================================================
 // mlp_bwd_b: weight gradients, split over samples: grid (ceil(Hd/256), splits of SJ samples).
 //   dWk[k][h] = sum_i dL[i][k] H[i][h] ; dW1[h][c] = sum_i dHpre[i][h] Zn[i][c] ; db1[h] = sum_i dHpre[i][h]
 //   dbk[k] = sum_i dL[i][k] ; dg[c] = sum_i dgp[i][c]      (block x == 0)
@@ -691,6 +727,16 @@ extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const fl
     hipLaunchKernelGGL(mlp_bwd_b_kernel, dim3((hd->Hd + 255) / 256, splits), dim3(256), 0, st, *hd, b, Zn, H, dL, dHpre, dgp, small_part);
     hipLaunchKernelGGL(small_reduce_kernel, dim3((hd->n_small + 255) / 256), dim3(256), 0, st, small_part, splits, hd->n_small, grad_small);
     return check_launch("mlp_bwd");
+}
+
+extern "C" int nadm_supervised_ce(const float* Q, int32_t SP, int32_t k, int32_t kp, const int32_t* labels, const int32_t* idx,
+                                  int32_t b, int32_t n_classes, float weight, float* dqpart0, float* loss_slot, void* stream) {
+    if (!Q || !labels || !dqpart0 || !loss_slot) return fail("nadm_supervised_ce: null pointer");
+    if (b <= 0) return fail("nadm_supervised_ce: empty batch");
+    if (k <= 0 || k > kp || kp > SP) return fail("nadm_supervised_ce: need 0 < k <= kp <= SP");
+    if (n_classes != k) return fail("nadm_supervised_ce: number of classes must equal K");   // train.py:79
+    hipLaunchKernelGGL(supervised_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, Q, SP, k, kp, labels, idx, b, weight, dqpart0, loss_slot);
+    return check_launch("supervised_ce");
 }
 
 extern "C" int nadm_adam(float* param, const float* grad, float* m, float* v, int64_t n, int64_t clamp_from, float lr,

@@ -46,7 +46,9 @@ class Engine:
         self.H, self.Q = z(b * L.Hd), z(b * L.SP)
         self.dL, self.dHpre, self.dgp, self.dZ = z(b * L.SP), z(b * L.Hd), z(b * L.CP), z(b * L.CP)
         self.dqpart = z(L.dq_offsets(b)[1])
-        self.losspart = z(L.n_loss)
+        self.losspart = z(L.n_loss + 1)                  # last slot: supervised term (nadm_supervised_ce)
+        self.labels: Optional[torch.Tensor] = None      # int32 [rows], supervised mode only
+        self.n_classes, self.sup_weight = 0, 0.0
         self.small_part = z(int(lib.nadm_sample_splits(b)) * L.n_small)
         self.loss_acc = torch.zeros(2, dtype=torch.float64, device=device)
         self.xp: Optional[torch.Tensor] = None          # packed genotypes [rows, ld]
@@ -95,6 +97,17 @@ class Engine:
             check(lib.nadm_pack2bit_host(ptr(src), ptr(stage), e - s, M, self.ld), "pack2bit_host")
             xp[s:e].copy_(stage[: e - s], non_blocking=False)
         self.xp = xp
+
+    def set_labels(self, labels, n_classes: int, weight: float = 100.0) -> None:
+        """Supervised mode (neural_admixture.py:460-474): class index per RESIDENT row (same order as xp)."""
+        lab = torch.as_tensor(np.asarray(labels), dtype=torch.int32)
+        if lab.dim() != 1 or (self.xp is not None and lab.numel() != self.xp.shape[0]):
+            raise RuntimeError("labels must be one class index per resident genotype row")
+        if len(self.lay.ks) != 1 or int(n_classes) != self.lay.ks[0]:
+            raise RuntimeError(f"supervised mode needs a single head with K == number of classes ({n_classes})")
+        if lab.numel() and (int(lab.min()) < 0 or int(lab.max()) >= int(n_classes)):
+            raise RuntimeError("label out of range")
+        self.labels, self.n_classes, self.sup_weight = lab.to(self.device), int(n_classes), float(weight)
 
     # ------------------------------------------------------------------ parameters
     def load_params(self, V_MC: np.ndarray, P_SM: np.ndarray, small: np.ndarray) -> None:
@@ -159,11 +172,17 @@ class Engine:
                 C.c_void_p(self.dqpart.data_ptr() + dq_offs[h] * fsz),
                 C.c_void_p(self.losspart.data_ptr() + loss_offs[h] * fsz), 1 if with_loss else 0, st), "decode_bce")
         if ev: ev[1].record()
+        n_loss = L.n_loss
+        if self.labels is not None:
+            check(lib.nadm_supervised_ce(ptr(self.Q), L.SP, L.ks[0], L.kp[0], ptr(self.labels), ptr(idx), b, self.n_classes,
+                                         self.sup_weight, ptr(self.dqpart), C.c_void_p(self.losspart.data_ptr() + L.n_loss * fsz),
+                                         st), "supervised_ce")
+            n_loss += 1
         if on_decoder_done is not None:
             on_decoder_done()
         check(lib.nadm_mlp_bwd(C.byref(L.heads), ptr(self.small), ptr(self.dqpart), L.M, b, ptr(self.Z), ptr(self.rinv), ptr(self.Zn),
                                ptr(self.H), ptr(self.Q), ptr(self.dL), ptr(self.dHpre), ptr(self.dgp), ptr(self.small_part),
-                               ptr(self.dZ), ptr(self.gsmall), ptr(self.losspart), L.n_loss if with_loss else 0,
+                               ptr(self.dZ), ptr(self.gsmall), ptr(self.losspart), n_loss if with_loss else 0,
                                ptr(self.loss_acc), st), "mlp_bwd")
         ev = self._timed("encode_bwd")
         check(lib.nadm_encode_bwd(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self.dZ), L.CP, ptr(self.gbig), st), "encode_bwd")

@@ -127,6 +127,7 @@ class NeuralAdmixture:
         self.global_batch = int(batch_size)
         self.batch_size = int(batch_size) // num_gpus if num_gpus > 0 else int(batch_size)   # :287
         self.lr = float(learning_rate)
+        self.supervised_loss_weight = float(supervised_loss_weight)
         self.loss_mode = loss_mode       # "logged": loss only on epochs that print it (:416); "always": every step
         self.epoch_losses: dict = {}
 
@@ -140,8 +141,6 @@ class NeuralAdmixture:
     def launch_training(self, P, data, hidden_size, num_features, V, M, N, pops=None):
         """P torch [sum(ks), M]; data uint8 CPU [N,M] (unpacked; this method packs the rank's rows);
         V torch [M,C].  Returns (Qs, Ps, model) like neural_admixture.py:392,530 (numpy lists on master)."""
-        if pops is not None:
-            raise NotImplementedError("supervised mode (pops) is not on the accelerated path yet")
         from torch.utils.data import RandomSampler
         from torch.utils.data.distributed import DistributedSampler
         world, rank = self._world()
@@ -164,6 +163,10 @@ class NeuralAdmixture:
             n_local = N
             generator = torch.Generator().manual_seed(self.seed)     # neural_admixture.py:283
             sampler = RandomSampler(range(N), generator=generator)
+        if pops is not None:                               # supervised mode (:352-356, :434-474): labels follow the rows
+            y = torch.as_tensor(pops).detach().cpu().numpy().astype(np.int64)
+            eng.set_labels(y if shard is None else y[shard], self.ks_list[0], self.supervised_loss_weight)
+        log_every = 5 if pops is None else 2               # :416 vs :457
 
         if self.master:
             log.info("")
@@ -172,7 +175,7 @@ class NeuralAdmixture:
         b = self.batch_size
         seq = torch.arange(n_local, dtype=torch.int32, device=dev)
         for epoch in range(self.epochs):
-            logged = (epoch % 5 == 0)
+            logged = (epoch % log_every == 0)
             with_loss = logged or self.loss_mode == "always"
             if world > 1:
                 order = seq                                # rows are stored in shard order

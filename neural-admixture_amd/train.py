@@ -38,25 +38,52 @@ def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_comp
     return np.concatenate(Ps, axis=0)
 
 
+def supervised_init(data_np, pops, K: int):
+    """Supervised mode (train.py:74-83): population names -> class indices in sorted order, and
+    P_init [K,M] = per-class mean of the RAW codes (0,1,2, missing 3; not halved, not clipped -- the first
+    restrict_P brings it into [0,1]).  ``data_np``: uint8 [N,M] or an io.PackedGenotypes."""
+    names = sorted(np.unique([a for a in pops]))
+    if K is None or len(names) != K:
+        raise AssertionError(f"Number of ancestries in training ground truth ({len(names)}) is not equal to the value of K ({K})")
+    lut = {a: i for i, a in enumerate(names)}
+    y = np.asarray([lut[a] for a in pops], dtype=np.int64)
+    N, M = data_np.shape
+    if len(y) != N:
+        raise RuntimeError("pops must hold one population label per sample")
+    rows = data_np.unpack_rows if hasattr(data_np, "unpack_rows") else (lambda s, e: data_np[s:e])
+    sums = np.zeros((K, M), dtype=np.float64)
+    for i in range(0, N, 1024):
+        blk, yb = rows(i, min(N, i + 1024)), y[i:i + 1024]
+        for k in range(K):
+            if np.any(yb == k):
+                sums[k] += blk[yb == k].sum(axis=0, dtype=np.float64)
+    P = (sums / np.bincount(y, minlength=K)[:, None]).astype(np.float32)
+    return y, P
+
+
 def train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int, data: torch.Tensor, device: torch.device,
           num_gpus: int, hidden_size: int, master: bool, V: np.ndarray, pops, min_k: int = None, max_k: int = None,
           n_components: int = None):
     """See module docstring.  ``data`` uint8 [N,M] CPU tensor (or an ``io.PackedGenotypes``, e.g. from
     ``io.read_bed_packed``); ``V`` numpy [C,M] (RSVD output,
     svd.py:83); returns Ps (list of [M,k] float32), Qs (list of [N,k] float32), model."""
-    if pops is not None:
-        raise NotImplementedError("supervised mode (pops) is not on the accelerated path yet")
     if device.type != "cuda":
         raise RuntimeError("neural_admixture_amd.train requires a ROCm GPU device; the CPU path is the reference's own")
     N, M = data.shape
     if n_components is None:
         n_components = V.shape[0]
     total_K = K if K is not None else sum(range(min_k, max_k + 1))
-    if master:
+    y_num = None
+    if master and pops is None:
         log.info("")
         log.info("    Running Gaussian Mixture in PCA subspace...")
         log.info("")
         P = gmm_p_init(data if hasattr(data, "unpack_rows") else data.numpy(), V, K, min_k, max_k, n_components, seed)
+    elif master:
+        log.info("")
+        log.info("    Running Supervised Mode...")
+        log.info("")
+        y_num, P = supervised_init(data if hasattr(data, "unpack_rows") else data.numpy(), pops, K)
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
     if num_gpus > 1 and dist.is_available() and dist.is_initialized():
@@ -64,9 +91,15 @@ def train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int,
             P_init = torch.as_tensor(P, dtype=torch.float32, device=device).contiguous()
             Vt = torch.as_tensor(V.T, dtype=torch.float32, device=device).contiguous()
             log.info("    Broadcasting to all GPUs...")
+            if pops is not None:
+                pops = torch.as_tensor(y_num, dtype=torch.int64, device=device)
         else:
             P_init = torch.empty((total_K, M), dtype=torch.float32, device=device)
             Vt = torch.empty((M, n_components), dtype=torch.float32, device=device)
+            if pops is not None:
+                pops = torch.empty(len(pops), dtype=torch.int64, device=device)
+        if pops is not None:
+            dist.broadcast(pops, src=0)        # train.py:107-108
         dist.broadcast(P_init, src=0)          # train.py:109
         dist.broadcast(Vt, src=0)              # train.py:110
         dist.barrier()
@@ -75,6 +108,8 @@ def train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int,
     else:
         P_init = torch.as_tensor(P, dtype=torch.float32).contiguous()
         Vt = torch.as_tensor(V.T, dtype=torch.float32).contiguous()
+        if pops is not None:
+            pops = torch.as_tensor(y_num, dtype=torch.int64)
 
     model = NeuralAdmixture(K, epochs, batch_size, learning_rate, device, seed, num_gpus, master, None, min_k, max_k)
     Qs, Ps, raw = model.launch_training(P_init, data, hidden_size, Vt.shape[1], Vt, M, N, pops)

@@ -218,8 +218,26 @@ def bce_sum(R: np.ndarray, X: np.ndarray) -> float:
     return float(-(X.astype(np.float64) * l1 + (1.0 - X.astype(np.float64)) * l0).sum())
 
 
-def step_grads(p: Params, G: np.ndarray):
-    """One forward+backward on batch G uint8 [b,M].  Returns (loss, grads dict keyed like
+SUPERVISED_WEIGHT = 100.0   # supervised_loss_weight default, neural_admixture.py:249
+
+
+def supervised_p_init(G: np.ndarray, y: np.ndarray, K: int) -> np.ndarray:
+    """P init of supervised mode, [K,M]: per-class mean of the RAW uint8 codes (0,1,2 and 3 for missing; not
+    halved, not clipped) -- model/train.py:82."""
+    return np.vstack([G[y == k].astype(np.float32).mean(axis=0) for k in range(K)]).astype(np.float32)
+
+
+def labels_from_pops(pops) -> np.ndarray:
+    """Population names -> class indices in sorted-unique order (model/train.py:78-81)."""
+    names = sorted(np.unique(np.asarray(list(pops))))
+    lut = {a: i for i, a in enumerate(names)}
+    return np.asarray([lut[a] for a in pops], dtype=np.int64)
+
+
+def step_grads(p: Params, G: np.ndarray, labels: Optional[np.ndarray] = None):
+    """One forward+backward on batch G uint8 [b,M].  With ``labels`` (int [b]) the supervised term
+    100 * CrossEntropyLoss(sum)(Q_0, labels) is added -- applied to the softmax OUTPUT of head 0 as if it were
+    logits (neural_admixture.py:470-473: out[1][0] is probs[0]).  Returns (loss, grads dict keyed like
     Params.tensors(), aux dict with Z/Q).  Closed form of the autograd graph of
     neural_admixture.py:157-177 + :94-97 (clamp, mask on the pre-clamp value, inclusive bounds)
     + BCE backward (r-x)/max(r(1-r),1e-12)."""
@@ -239,6 +257,17 @@ def step_grads(p: Params, G: np.ndarray):
         dR[(Rraw < 0) | (Rraw > 1)] = 0
         grads[f"P{h}"] = (dR.T @ Q).astype(F32)
         dQ = (dR @ P).astype(F32)
+        if labels is not None and h == 0:
+            # CE(sum) on q as logits: loss = sum_i logsumexp(q_i) - q_i[y_i]; d/dq = softmax(q_i) - onehot
+            qm = Q.max(axis=1, keepdims=True)
+            e = np.exp(Q - qm, dtype=F32)
+            se = e.sum(axis=1, keepdims=True, dtype=F32)
+            lse = (qm + np.log(se, dtype=F32))[:, 0]
+            rows = np.arange(Q.shape[0])
+            loss += SUPERVISED_WEIGHT * float((lse.astype(np.float64) - Q[rows, labels].astype(np.float64)).sum())
+            gce = (e / se).astype(F32)
+            gce[rows, labels] -= F32(1)
+            dQ = (dQ + F32(SUPERVISED_WEIGHT) * gce).astype(F32)
         dL = (Q * (dQ - (dQ * Q).sum(axis=1, keepdims=True, dtype=F32))).astype(F32)
         grads[f"Wk{h}"] = (dL.T @ H).astype(F32)
         grads[f"bk{h}"] = dL.sum(axis=0, dtype=F32)
@@ -290,7 +319,7 @@ class Adam:
 # Whole run  (neural_admixture.py:324-392)
 # --------------------------------------------------------------------------------------------
 def train_run(G: np.ndarray, params: Params, epochs: int, batch_size: int, lr: float, seed: int,
-              world: int = 1, record_orders: Optional[list] = None):
+              world: int = 1, record_orders: Optional[list] = None, labels: Optional[np.ndarray] = None):
     """Full training loop on uint8 G [N,M].  ``world>1`` emulates DDP: per-rank batch =
     batch_size//world (neural_admixture.py:287), DistributedSampler shards, gradients averaged over
     ranks (DDP mean all-reduce, :317), per-rank losses summed only for logging.
@@ -308,7 +337,7 @@ def train_run(G: np.ndarray, params: Params, epochs: int, batch_size: int, lr: f
         acc = 0.0
         if world == 1:
             for idx in batches(perm, b_local):
-                loss, grads, _ = step_grads(params, G[idx])
+                loss, grads, _ = step_grads(params, G[idx], None if labels is None else labels[idx])
                 opt.step(params, grads)
                 acc += loss
         else:
@@ -316,7 +345,8 @@ def train_run(G: np.ndarray, params: Params, epochs: int, batch_size: int, lr: f
             for s in range(len(shards[0])):
                 gsum, l0 = None, 0.0
                 for r in range(world):
-                    loss, grads, _ = step_grads(params, G[shards[r][s]])
+                    loss, grads, _ = step_grads(params, G[shards[r][s]],
+                                                None if labels is None else labels[shards[r][s]])
                     if r == 0:
                         l0 = loss
                     gsum = grads if gsum is None else {k: gsum[k] + grads[k] for k in grads}

@@ -41,7 +41,8 @@ class OracleEngine(Engine):
 
     def backward(self, idx, b, with_loss=True, on_decoder_done=None):
         L, h = self.lay, self.lay.heads
-        loss, g, _ = O.step_grads(self._params(), self.G[self._idx])
+        lab = None if self.labels is None else self.labels.numpy().astype(np.int64)[self._idx]
+        loss, g, _ = O.step_grads(self._params(), self.G[self._idx], lab)
         big = np.zeros(L.n_big, dtype=np.float32)
         big[: L.M * L.CP].reshape(L.M, L.CP)[:, : L.C] = g["V"]
         for i, k in enumerate(L.ks):

@@ -115,7 +115,7 @@ def case_bce_elementwise():
     np.savez_compressed(os.path.join(OUT, "bce_elementwise.npz"), r_raw=rr, x=xx, loss=per.detach().numpy(), grad=rt.grad.numpy())
 
 
-def one_step_case(name, N, M, ks, Hd, C, seed, edge=False, steps=3, lr=2e-3):
+def one_step_case(name, N, M, ks, Hd, C, seed, edge=False, steps=3, lr=2e-3, sup=False):
     G = synth(N, M, max(ks), seed=seed + 1, missing=0.03)
     rng = np.random.default_rng(seed + 2)
     V0 = (rng.standard_normal((M, C)) / math.sqrt(M)).astype(np.float32)
@@ -129,6 +129,11 @@ def one_step_case(name, N, M, ks, Hd, C, seed, edge=False, steps=3, lr=2e-3):
         P0[:, :40] = 0.0
         P0[:, 40:60] = rng.uniform(0.999, 1.0, size=(S, 20)).astype(np.float32)
     out = dict(G=G, V0=V0, P0=P0, ks=np.asarray(ks), Hd=Hd, seed=seed, lr=lr)
+    if sup:   # supervised term of neural_admixture.py:470-473 on head 0
+        labels = rng.integers(0, ks[0], size=N)
+        out["labels"] = labels
+        ce = torch.nn.CrossEntropyLoss(reduction="sum")
+        yt = torch.tensor(labels, dtype=torch.int64)
     with precision("hi"):
         torch.manual_seed(seed)
         model = Q_P(Hd, C, V=torch.tensor(V0), P=torch.tensor(P0), ks_list=list(ks))
@@ -140,6 +145,8 @@ def one_step_case(name, N, M, ks, Hd, C, seed, edge=False, steps=3, lr=2e-3):
             opt.zero_grad(set_to_none=True)
             (recs, probs), X = model(Gt)
             loss = sum(loss_fn(rec, X) for rec in recs)
+            if sup:
+                loss = loss + 100 * ce(probs[0], yt)
             loss.backward()
             out[f"loss{s}"] = np.float64(loss.item())
             if s == 0:
@@ -299,6 +306,40 @@ def case_ddp(world=2):
     print("ddp", world, losses0[:2], losses0[-1])
 
 
+def case_supervised():
+    """Supervised mode through the reference's own train() (model/train.py:74-83 P init from class means of
+    the raw codes; neural_admixture.py:460-474 loss = BCE + 100 * CrossEntropy(sum) on the softmax output)."""
+    from neural_admixture.model.train import train as ref_train
+    N, M, K, Hd, C, b, ep, seed, lr = 240, 1024, 4, 128, 8, 100, 3, 13, 2e-3
+    G = synth(N, M, K, seed=77, missing=0.02)
+    rng = np.random.default_rng(9)
+    names = np.asarray(["POP_C", "POP_A", "POP_D", "POP_B"])
+    pops = names[rng.integers(0, K, size=N)]
+    Vt = (rng.standard_normal((C, M)) / math.sqrt(M)).astype(np.float32)
+    out = dict(G_packed=pack_rule(G), N=N, M=M, K=K, Hd=Hd, b=b, epochs=ep, seed=seed, lr=lr, Vt=Vt, pops=pops)
+    for mode in ("hi", "med"):
+        step_losses = []
+        orig = NeuralAdmixture._run_step_supervised
+
+        def wrapped(self, x, y, _orig=orig, _sl=step_losses):
+            loss = _orig(self, x, y)
+            _sl.append(float(loss.item()))
+            return loss
+        NeuralAdmixture._run_step_supervised = wrapped
+        try:
+            with precision(mode):
+                torch.manual_seed(seed)
+                Ps, Qs, model = ref_train(ep, b, lr, K, seed, torch.tensor(G), torch.device("cpu"), 0, Hd, True,
+                                          Vt.copy(), list(pops), None, None, C)
+        finally:
+            NeuralAdmixture._run_step_supervised = orig
+        sd = state_np(model)
+        out[f"{mode}_Q"], out[f"{mode}_P"], out[f"{mode}_V"] = Qs[0], Ps[0], sd["V"]
+        out[f"{mode}_losses"] = np.asarray(step_losses)
+        print("supervised", mode, step_losses[:2], step_losses[-1])
+    np.savez_compressed(os.path.join(OUT, "supervised_k4.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     case_pack()
@@ -311,4 +352,6 @@ if __name__ == "__main__":
     case_multihead_run()
     case_ddp(2)
     case_demo()
+    case_supervised()
+    one_step_case("one_step_supervised", 64, 509, [5], 64, 8, seed=8, sup=True)
     print("done ->", OUT)

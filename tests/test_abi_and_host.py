@@ -216,3 +216,32 @@ def test_cli_parsers_have_the_reference_flags():
     assert (a.epochs, a.batch_size, a.learning_rate, a.seed, a.hidden_size, a.n_components) == (250, 800, 2e-3, 42, 1024, 8)   # entry.py:27-43
     b = parse_infer_args(["--out_name", "o", "--save_dir", "s", "--data_path", "x.bed", "--name", "n"])
     assert b.batch_size == 1024 and b.seed == 42                                                                           # entry.py:57-65
+
+
+def test_supervised_host_logic_against_oracle_and_reference():
+    """Supervised mode on the CPU test double: train.supervised_init (label mapping + class-mean P init) and the
+    trainer's label plumbing (labels follow the sampled rows) reproduce the oracle's supervised run, which
+    tests/test_oracle_golden.py pins against the reference's own train()."""
+    from neural_admixture_amd.model import NeuralAdmixture
+    from neural_admixture_amd.train import supervised_init
+    from tests.fake_engine import OracleEngine
+    from oracle import nadm_oracle as O
+    d = np.load(os.path.join(G, "supervised_k4.npz"))
+    N, M, K, Hd = int(d["N"]), int(d["M"]), int(d["K"]), int(d["Hd"])
+    Gm = O.unpack2bit(d["G_packed"], M)
+    pops = [str(a) for a in d["pops"]]
+    y, P0 = supervised_init(Gm, pops, K)
+    assert np.array_equal(y, O.labels_from_pops(pops))
+    assert np.abs(P0 - O.supervised_p_init(Gm, y, K)).max() < 1e-6
+    with pytest.raises(AssertionError):
+        supervised_init(Gm, pops, K + 1)
+    V = np.ascontiguousarray(d["Vt"].T)
+    tr = NeuralAdmixture(K, 1, int(d["b"]), float(d["lr"]), torch.device("cpu"), int(d["seed"]), 0, True, None, None, None,
+                         loss_mode="always")
+    tr.engine_cls = OracleEngine
+    Qs, Ps, _ = tr.launch_training(torch.from_numpy(P0), torch.from_numpy(Gm), Hd, 8, torch.from_numpy(V), M, N, torch.from_numpy(y))
+    p = O.make_params(int(d["seed"]), V, P0, Hd, [K])
+    p, Qo, losses = O.train_run(Gm, p, 1, int(d["b"]), float(d["lr"]), int(d["seed"]), labels=y)
+    assert abs(tr.epoch_losses[0] - losses[0]) / losses[0] < 1e-5
+    assert np.abs(Qs[0] - Qo[0]).max() < 1e-4 and np.abs(Ps[0] - p.P[0]).max() < 1e-4
+    assert abs(d["hi_losses"][0] - 126760.66) < 1.0         # the fixture this is anchored on

@@ -98,7 +98,8 @@ def test_pack_unpack_bit_exact():
         assert np.array_equal(ud.cpu().numpy(), Gm & 3)
 
 
-@pytest.mark.parametrize("name", ["one_step_k3", "one_step_multihead", "one_step_k8_h1024", "one_step_edge"])
+@pytest.mark.parametrize("name", ["one_step_k3", "one_step_multihead", "one_step_k8_h1024", "one_step_edge",
+                                  "one_step_supervised"])
 def test_one_step_against_reference_fixture(name):
     """Loss, every gradient and 3 Adam steps against tensors captured from the reference's autograd."""
     d = np.load(f"{G}/{name}.npz")
@@ -108,6 +109,8 @@ def test_one_step_against_reference_fixture(name):
     b = Gm.shape[0]
     e = make_engine(Gm, p, b)
     idx = torch.arange(b, dtype=torch.int32, device=e.device)
+    if "labels" in d.files:                 # supervised term: BCE + 100 * CE(sum) on head 0's softmax output
+        e.set_labels(d["labels"], ks[0], 100.0)
     edge = name.endswith("edge")
     gtol = 3e-3 if edge else 2e-5
     for s in range(3):
@@ -344,6 +347,50 @@ def test_train_boundary_on_demo_from_bed(tmp_path, caplog):
     Gm = O.unpack2bit(d["G_packed"], int(d["M"]))
     probs, _ = m2(torch.from_numpy(Gm))
     assert mx(probs[0].cpu().numpy(), Qs[0]) < 1e-6
+
+
+def test_train_boundary_supervised_vs_reference():
+    """Supervised mode through train(..., pops=[names]) against the reference's own train() on the same inputs
+    (tests/golden/supervised_k4.npz): label mapping, raw-code class-mean P init, BCE + 100*CE.  Step 0 is a
+    rounding-level pin; later steps are compared at the reference's own fp32-vs-bf16 self-distance (the init
+    saturates most of R, see tests/test_oracle_golden.py::test_supervised_run)."""
+    import neural_admixture_amd as na
+    from neural_admixture_amd.model import NeuralAdmixture
+    dev = _dev()
+    d = np.load(f"{G}/supervised_k4.npz")
+    N, M, K, Hd = int(d["N"]), int(d["M"]), int(d["K"]), int(d["Hd"])
+    Gm = O.unpack2bit(d["G_packed"], M)
+    pops = [str(a) for a in d["pops"]]
+    data = torch.from_numpy(Gm)
+    # step-level: the trainer with loss on every step
+    from neural_admixture_amd.train import supervised_init
+    y, P0 = supervised_init(Gm, pops, K)
+    assert np.array_equal(y, O.labels_from_pops(pops)) and mx(P0, O.supervised_p_init(Gm, y, K)) < 1e-6
+    tr = NeuralAdmixture(K, 1, int(d["b"]), float(d["lr"]), dev, int(d["seed"]), 1, True, None, None, None, loss_mode="always")
+    tr.launch_training(torch.from_numpy(P0), data, Hd, 8, torch.from_numpy(np.ascontiguousarray(d["Vt"].T)), M, N,
+                       torch.from_numpy(y))
+    ref, med = d["hi_losses"], d["med_losses"]
+    assert abs(tr.epoch_losses[0] - ref[:3].sum()) / ref[:3].sum() < max(3 * abs(med[:3].sum() - ref[:3].sum()) / ref[:3].sum(), 5e-3)
+    # one step exactly
+    e = tr.engine_cls(M, 8, Hd, [K], dev, N)
+    from neural_admixture_amd.model import init_encoder_weights
+    e.load_params(np.ascontiguousarray(d["Vt"].T), P0, init_encoder_weights(int(d["seed"]), 8, Hd, [K]))
+    e.pack_from_host(data)
+    e.set_labels(y, K)
+    g = torch.Generator().manual_seed(int(d["seed"]))
+    order = np.asarray(list(iter(torch.utils.data.RandomSampler(range(N), generator=g))), dtype=np.int32)[: int(d["b"])]
+    idx = torch.from_numpy(order).to(dev)
+    e.forward(idx, len(order)); e.backward(idx, len(order), True)
+    assert abs(e.read_loss()[1] - ref[0]) / ref[0] < 5e-6
+    # the boundary call itself
+    Ps, Qs, model = na.train(int(d["epochs"]), int(d["b"]), float(d["lr"]), K, int(d["seed"]), data, dev, 1, Hd, True,
+                             d["Vt"], pops, None, None, 8)
+    selfQ = mx(d["med_Q"], d["hi_Q"])
+    assert Ps[0].shape == (M, K) and Qs[0].shape == (N, K)
+    assert mx(Qs[0], d["hi_Q"]) < max(2 * selfQ, 0.05)
+    assert float(Ps[0].min()) >= 0.0 and float(Ps[0].max()) <= 1.0
+    with pytest.raises(AssertionError):                      # train.py:79
+        na.train(1, 100, 2e-3, K + 1, 1, data, dev, 1, Hd, True, d["Vt"], pops, None, None, 8)
 
 
 def test_cli_train_and_infer_demo(tmp_path):

@@ -43,7 +43,8 @@ def test_bce_elementwise_semantics():
     assert np.allclose(grad, d["grad"], rtol=2e-6, atol=0)
 
 
-@pytest.mark.parametrize("name", ["one_step_k3", "one_step_multihead", "one_step_k8_h1024", "one_step_edge"])
+@pytest.mark.parametrize("name", ["one_step_k3", "one_step_multihead", "one_step_k8_h1024", "one_step_edge",
+                                  "one_step_supervised"])
 def test_one_step(name):
     d = np.load(f"{G}/{name}.npz")
     ks = [int(k) for k in d["ks"]]
@@ -58,7 +59,7 @@ def test_one_step(name):
     gtol = 3e-3 if edge else 1e-5      # edge: r within 1e-3 of 1 amplifies GEMM rounding ~1e4x
     opt = O.Adam(p, float(d["lr"]))
     for s in range(3):
-        loss, grads, aux = O.step_grads(p, d["G"])
+        loss, grads, aux = O.step_grads(p, d["G"], d["labels"] if "labels" in d.files else None)
         assert abs(loss - float(d[f"loss{s}"])) / float(d[f"loss{s}"]) < 2e-6
         if s == 0:
             assert mx(aux["Z"], d["Z0"]) < 2e-6
@@ -138,3 +139,30 @@ def test_demo_c1(ep):
         ll = O.loglikelihood(Gm, p.P[0], Qs[0])
         assert abs(ll - float(d["hi_e5_loglik"])) / abs(float(d["hi_e5_loglik"])) < 1e-7
         assert abs(O.hudson_fst(p.P[0][:, 1], p.P[0][:, 0]) - d["hi_e5_fst"][1, 0]) < 1e-5
+
+
+def test_supervised_run():
+    """Supervised mode through the reference's own train(): label mapping, class-mean P init (raw codes, values
+    up to 3, train.py:82), BCE + 100*CE.  The init puts most r at the clamp, where one rounding flips the
+    gradient mask of an element whose gradient is ~1e3..1e12, so after the first step the reference differs from
+    ITSELF by 2e-3 in loss between its fp32 and bf16 runs; only step 0 is a rounding-level pin."""
+    d = np.load(f"{G}/supervised_k4.npz")
+    N, M, K, Hd = int(d["N"]), int(d["M"]), int(d["K"]), int(d["Hd"])
+    Gm = O.unpack2bit(d["G_packed"], M)
+    y = O.labels_from_pops(d["pops"])
+    assert sorted(set(y.tolist())) == list(range(K))
+    P0 = O.supervised_p_init(Gm, y, K)
+    assert P0.max() > 1.0                                  # raw codes, not allele frequencies
+    p = O.make_params(int(d["seed"]), np.ascontiguousarray(d["Vt"].T), P0, Hd, [K])
+    order = O.EpochOrder(N, int(d["seed"]))
+    opt = O.Adam(p, float(d["lr"]))
+    ls = []
+    for _ in range(int(d["epochs"])):
+        for idx in O.batches(order.next_epoch(), int(d["b"])):
+            loss, g, _ = O.step_grads(p, Gm[idx], y[idx])
+            opt.step(p, g)
+            ls.append(loss)
+    ls, ref, med = np.asarray(ls), d["hi_losses"], d["med_losses"]
+    assert abs(ls[0] - ref[0]) / ref[0] < 2e-6
+    self_noise = np.abs(med - ref) / ref
+    assert np.all(np.abs(ls - ref) / ref < np.maximum(3 * self_noise, 5e-3))
