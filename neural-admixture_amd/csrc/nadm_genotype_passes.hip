@@ -519,7 +519,7 @@ constexpr int mf_ntw(int kp) { return kp <= 8 ? NADM_BF_NTW : 2; }            //
 constexpr int mf_chunk_snps(int kp) { return mf_waves(kp) * 16 * mf_ntw(kp); }
 
 // gradient w.r.t. the pre-clamp reconstruction and (optionally) the BCE loss term of one genotype.
-// cf = float(code) with missing already mapped to 0, so x = cf/2.
+// x = genotype/2 with missing already mapped to 0 (fp4_pair below).
 // loss uses one log: x=0 -> log(1-r), x=1 -> log r, x=.5 -> .5*log(r(1-r)); the -100 clamps of the two
 // separate terms can only bind when r is exactly 0 or 1, where the merged form gives the same value.
 template <bool LOSS>
@@ -765,15 +765,14 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast
 // (tools/ubench_ops.hip), v_pk_{add,mul,fma}_f32 included, so packing halves the price of every add/mul/fma;
 // max, rcp, compare/select and the conversions have no packed form.
 // Returns dR (gradient w.r.t. the pre-clamp reconstruction) and accumulates the BCE loss terms.
-// cf = float(code) with missing already mapped to 0, so x = cf/2.
+// x = genotype/2 with missing already mapped to 0 (fp4_pair below).
 template <bool LOSS>
-__device__ __forceinline__ f32x2_t bce_elem2(const float d0, const float d1, const uint32_t c0, const uint32_t c1, f32x2_t& lossacc) {
-    const f32x2_t cf = {(float)c0, (float)c1};
+__device__ __forceinline__ f32x2_t bce_elem2(const float d0, const float d1, const f32x2_t x, f32x2_t& lossacc) {
     const f32x2_t r = {__builtin_amdgcn_fmed3f(d0, 0.f, 1.f), __builtin_amdgcn_fmed3f(d1, 0.f, 1.f)};
     const f32x2_t omr = (f32x2_t){1.f, 1.f} - r;
     const f32x2_t den = omr * r;
     const f32x2_t inv = {__builtin_amdgcn_rcpf(fmaxf(den.x, 1e-12f)), __builtin_amdgcn_rcpf(fmaxf(den.y, 1e-12f))};
-    const f32x2_t g = (r - (f32x2_t){0.5f, 0.5f} * cf) * inv;
+    const f32x2_t g = (r - x) * inv;
     if constexpr (LOSS) {
         // lossacc accumulates x*max(log2 r, c) + (1-x)*max(log2(1-r), c), c = -100/ln2 (the caller applies -ln2).
         // Two logs and packed fmas, no compares/selects on the code: the select-based single-log form costs as many
@@ -781,13 +780,23 @@ __device__ __forceinline__ f32x2_t bce_elem2(const float d0, const float d1, con
         constexpr float kC = -100.f / 0.69314718055994530942f;
         const f32x2_t l1 = {fmaxf(__builtin_amdgcn_logf(r.x), kC), fmaxf(__builtin_amdgcn_logf(r.y), kC)};
         const f32x2_t l0 = {fmaxf(__builtin_amdgcn_logf(omr.x), kC), fmaxf(__builtin_amdgcn_logf(omr.y), kC)};
-        const f32x2_t x = (f32x2_t){0.5f, 0.5f} * cf;
         lossacc = __builtin_elementwise_fma(x, l1, lossacc);
         lossacc = __builtin_elementwise_fma((f32x2_t){1.f, 1.f} - x, l0, lossacc);
         asm volatile("" : "+v"(lossacc));     // pin the accumulation here: otherwise LLVM sinks all the logs of a tile pair
                                               // to the end of the loop body and keeps their 32 inputs alive (+60 VGPRs)
     }
     return (f32x2_t){(r.x == d0) ? g.x : 0.f, (r.y == d1) ? g.y : 0.f};
+}
+
+// Two genotypes -> two floats in ONE instruction: a nibble 00cc read as FP4 (E2M1) is exactly cc/2 (0, .5, 1), so
+// v_cvt_scalef32_pk_f32_fp4 on byte `sel` of a word whose nibbles hold one 2-bit code each yields x for both.
+__device__ __forceinline__ f32x2_t fp4_pair(const uint32_t w, const int sel) {
+    switch (sel) {
+        case 0: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 0);
+        case 1: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 1);
+        case 2: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 2);
+        default: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 3);
+    }
 }
 
 constexpr int BF_WAVES = NADM_BF_WAVES;
@@ -818,7 +827,10 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     const int64_t chunk = blockIdx.x;
     const int64_t byte0 = chunk * RB;
     const int64_t snp_wave0 = chunk * (MF_WAVES * 16 * NTW) + wave * (16 * NTW);
-    auto snp_of = [&](int t, int ab, int r) -> int64_t { return snp_wave0 + 4 * NTW * ab + 4 * t + r; };
+    // MFMA row 4*ab + r of tile t holds SNP code sigma(r) = {0,2,1,3}[r] of the lane group's byte t: registers (0,1) of an
+    // accumulator are then the codes in the low/high nibble of (byte & 0x33), registers (2,3) those of ((byte >> 2) & 0x33)
+    // -- the pairing fp4_pair() converts with one instruction.
+    auto snp_of = [&](int t, int ab, int r) -> int64_t { return snp_wave0 + 4 * NTW * ab + 4 * t + (((r & 1) << 1) | (r >> 1)); };
 
     // zero the operand slots that are never written (k-slots 2,3 of the second R MFMA; columns 8..15 of the second dP MFMA)
     for (int e = tid; e < (MF_TS / 16) * 2 * 64; e += NTHR) (&s_qr[0][0][0])[e] = make_uint4(0, 0, 0, 0);
@@ -930,7 +942,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
 #pragma unroll 1
         for (int p = 0; p < MF_TS / 32; ++p) {
             if (i0 + 32 * p < b) {                                     // block-uniform
-                uint32_t bits[2];
+                uint32_t even[2], odd[2];                              // nibble = one 2-bit code: codes 0,2 / 1,3 of each byte
                 uint4 qb1[2], qb2[2];
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -939,7 +951,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                     if constexpr (NTW == 4) w = *reinterpret_cast<const uint32_t*>(&s_x[(16 * st + n) * RS + wave * 16 + 4 * a]);
                     else w = *reinterpret_cast<const uint16_t*>(&s_x[(16 * st + n) * RS + wave * 8 + 2 * a]);
                     w &= ~((w & (w >> 1) & 0x55555555u) * 3u);         // missing (3) -> 0
-                    bits[s2] = w;
+                    even[s2] = w & 0x33333333u;
+                    odd[s2] = (w >> 2) & 0x33333333u;
                     qb1[s2] = s_qr[st][0][lane];
                     qb2[s2] = s_qr[st][1][lane];
                 }
@@ -958,10 +971,9 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                             f32x4 D = (f32x4){0.f, 0.f, 0.f, 0.f};
                             D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r1[t]), as_bf16x8(qb1[s2]), D, 0, 0, 0);
                             D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r2[t]), as_bf16x8(qb2[s2]), D, 0, 0, 0);
-                            const uint32_t cb = bits[s2] >> (8 * t);
 #pragma unroll
                             for (int h2 = 0; h2 < 2; ++h2) {
-                                const f32x2_t dR = bce_elem2<LOSS>(D[2 * h2], D[2 * h2 + 1], (cb >> (4 * h2)) & 3u, (cb >> (4 * h2 + 2)) & 3u, lossacc);
+                                const f32x2_t dR = bce_elem2<LOSS>(D[2 * h2], D[2 * h2 + 1], fp4_pair(h2 ? odd[s2] : even[s2], t), lossacc);
                                 const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector(dR, bf16x2_t));
                                 hi[t2][h2] = hp;
                                 const f32x2_t rem = dR - (f32x2_t){__uint_as_float(hp << 16), __uint_as_float(hp & 0xFFFF0000u)};
@@ -1005,7 +1017,11 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                 for (int s2 = 0; s2 < 2; ++s2) {
                     float o[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = dq[s2][r] + __shfl_xor(dq[s2][r], 32, 64);
+                    for (int r = 0; r < 4; ++r) {                      // v_permlane32_swap: both halves of the wave see lo and hi
+                        const uint32_t u = __float_as_uint(dq[s2][r]);
+                        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                        o[r] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                    }
                     if (a < 2 && 4 * a < KP)
                         *reinterpret_cast<float4*>(&s_dq[wave][(16 * (2 * p + s2) + n) * KP + 4 * a]) = make_float4(o[0], o[1], o[2], o[3]);
                 }

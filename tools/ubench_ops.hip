@@ -28,6 +28,9 @@ __global__ __launch_bounds__(256) void k(float* out, long long* cyc, float c, fl
             if (MODE == 10) v[j] = (float)(__float_as_uint(v[j]) & 0xffu);    // v_cvt_f32_ubyte0
             if (MODE == 11) u[j] = u[j] << sh;
             if (MODE == 12) v[j] = 1.0f - v[j];
+            if (MODE == 13) { f32x2 r = __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(u[j], 1.0f, 1); u[j] = __float_as_uint(r.x) + __float_as_uint(r.y); }   // + 1 v_add
+            if (MODE == 14) u[j] = __builtin_amdgcn_perm(u[j], u[(j + 1) & 7], 0x07060302u);
+            if (MODE == 15) u[j] = u[j] + (unsigned)sh;
         }
     }
     long long t1 = __builtin_readcyclecounter();
@@ -52,5 +55,6 @@ int main() {
     run<4>("v_med3_f32", 8, out, cyc); run<5>("v_rcp_f32", 8, out, cyc); run<6>("v_log_f32", 8, out, cyc); run<7>("v_cmp_eq + v_cndmask (2 instr)", 8, out, cyc);
     run<8>("v_cvt_pk_bf16_f32", 8, out, cyc); run<9>("v_lshr + v_and / v_bfe", 8, out, cyc); run<10>("v_and + v_cvt_f32_ubyte0", 8, out, cyc);
     run<11>("v_lshlrev_b32", 8, out, cyc); run<12>("v_sub_f32 (1 - x)", 8, out, cyc);
+    run<13>("v_cvt_scalef32_pk_f32_fp4 + v_add_u32", 8, out, cyc); run<14>("v_perm_b32", 8, out, cyc); run<15>("v_add_u32", 8, out, cyc);
     return 0;
 }
