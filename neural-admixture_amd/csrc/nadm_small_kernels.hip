@@ -6,6 +6,7 @@
 #include "../../include/nadm.h"
 #include "nadm_host.h"
 #include <math.h>
+#include <stdlib.h>
 #include <array>
 #include <thread>
 #include <vector>
@@ -295,6 +296,324 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_kernel(nadm_heads_t hd, const f
             const double tot = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]);
             loss_acc[0] += tot;          // running (epoch) sum
             loss_acc[1] = tot;           // last step
+        }
+    }
+}
+
+// =================================================================================================
+// Fast variants for Hd <= 256*MLP_JMAX, C <= 8 (the defaults: Hd = 1024, C = 8).  Same math and the same
+// fixed reduction orders per output, but organised around latency: the kernels above walk the weight
+// matrices in short dependent batches of loads (a dozen L2 round trips each); here thread t owns hidden
+// units t, t+256, ... -- its W1 rows, Wk columns and activations stay in registers, every weight load of
+// a phase is issued before the first use, and sums over the hidden dimension are thread-partials ->
+// DPP wave sums -> 4-wave combine.
+// =================================================================================================
+constexpr int MLP_JMAX = 8;     // hidden units per thread: JH = 4 (Hd <= 1024) or 8 (Hd <= 2048)
+constexpr int MLP_KT = 8;       // head columns per pass of the hidden-dimension reductions
+
+template <int SB, int JH>
+__global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, const float* __restrict__ small,
+                                                           const float* __restrict__ zpart, int64_t n_chunks, int b,
+                                                           float* __restrict__ Z, float* __restrict__ rinv,
+                                                           float* __restrict__ Zn, float* __restrict__ H,
+                                                           float* __restrict__ Q) {
+    __shared__ __attribute__((aligned(16))) float s_grp[1024];
+    __shared__ float s_zn[SB * 8];
+    __shared__ float s_red[4][SB * MLP_KT];
+    extern __shared__ __attribute__((aligned(16))) float s_logit[];      // [SB][SP]
+    const int C = hd.C, CP = hd.CP, Hd = hd.Hd, SP = hd.SP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * SB;
+    const int ns = min(SB, b - i0);
+    const int row = SB * CP;
+
+    // ---- weights of this thread's hidden units: issued first, consumed after the Z reduction ----
+    const float* W1 = small + hd.w1_off;
+    const float* b1 = small + hd.b1_off;
+    float w1[JH][8], bb[JH];
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {
+        const int h = tid + 256 * j;
+        bb[j] = h < Hd ? b1[h] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) w1[j][c] = (h < Hd && c < C) ? W1[h * C + c] : 0.f;
+    }
+    // ---- Z = sum over chunks (same scheme as mlp_fwd_kernel) ----
+    {
+        const int row4 = row / 4;
+        const int G = 256 / row4;
+        const int e4 = tid % row4, g = tid / row4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < G && e4 * 4 < ns * CP) {
+            const float4* src = reinterpret_cast<const float4*>(zpart + (int64_t)i0 * CP) + e4;
+            const int64_t stride4 = (int64_t)b * CP / 4;
+#pragma unroll 8
+            for (int64_t ch = g; ch < n_chunks; ch += G) {
+                const float4 v = src[ch * stride4];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+        }
+        reinterpret_cast<float4*>(s_grp)[tid] = a;
+        __syncthreads();
+        if (tid < row) {
+            float t = 0.f;
+            for (int gg = 0; gg < G; ++gg) t += s_grp[(gg * row4 + tid / 4) * 4 + (tid & 3)];
+            s_zn[tid] = t;
+        }
+        __syncthreads();
+    }
+    if (tid < ns) {
+        float* z = s_zn + tid * CP;
+        float ms = 0.f;
+        for (int c = 0; c < C; ++c) ms = fmaf(z[c], z[c], ms);
+        const float ri = 1.0f / sqrtf(ms / (float)C + 1e-8f);
+        const int64_t i = i0 + tid;
+        rinv[i] = ri;
+        for (int c = 0; c < CP; ++c) {
+            const float zz = z[c];
+            Z[i * CP + c] = zz;
+            const float zn = (c < C) ? zz * ri * small[hd.g_off + c] : 0.f;
+            Zn[i * CP + c] = zn;
+            z[c] = zn;
+        }
+    }
+    __syncthreads();
+    // ---- hidden layer, kept in registers ----
+    float hv[JH][SB];
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {
+        const int h = tid + 256 * j;
+#pragma unroll
+        for (int s = 0; s < SB; ++s) {
+            float a = bb[j];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) a = fmaf(s_zn[s * CP + (c < CP ? c : 0)], w1[j][c], a);     // w1 = 0 beyond C
+            a = fmaxf(a, 0.f);
+            hv[j][s] = h < Hd ? a : 0.f;
+            if (h < Hd && s < ns) H[(int64_t)(i0 + s) * Hd + h] = a;
+        }
+    }
+    // ---- head logits, MLP_KT columns per pass ----
+    for (int hh = 0; hh < hd.n_heads; ++hh) {
+        const float* Wk = small + hd.wk_off[hh];
+        const float* bk = small + hd.bk_off[hh];
+        const int K = hd.k[hh];
+        for (int k0 = 0; k0 < K; k0 += MLP_KT) {
+            float wk[JH][MLP_KT];
+#pragma unroll
+            for (int j = 0; j < JH; ++j) {
+                const int h = tid + 256 * j;
+#pragma unroll
+                for (int kk = 0; kk < MLP_KT; ++kk) wk[j][kk] = (h < Hd && k0 + kk < K) ? Wk[(k0 + kk) * Hd + h] : 0.f;
+            }
+            float acc[SB][MLP_KT];
+#pragma unroll
+            for (int s = 0; s < SB; ++s)
+#pragma unroll
+                for (int kk = 0; kk < MLP_KT; ++kk) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int j = 0; j < JH; ++j) a = fmaf(hv[j][s], wk[j][kk], a);
+                    acc[s][kk] = a;
+                }
+            __syncthreads();                                  // s_red free (previous pass consumed)
+#pragma unroll
+            for (int s = 0; s < SB; ++s)
+#pragma unroll
+                for (int kk = 0; kk < MLP_KT; ++kk) {
+                    const float t = wave_sum_lane63(acc[s][kk]);
+                    if (lane == 63) s_red[wave][s * MLP_KT + kk] = t;
+                }
+            __syncthreads();
+            if (tid < SB * MLP_KT) {
+                const int s = tid / MLP_KT, kk = tid % MLP_KT;
+                if (k0 + kk < K)
+                    s_logit[s * SP + hd.qoff[hh] + k0 + kk] = ((s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid])) + bk[k0 + kk];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- softmax per (sample, head) ----
+    if (tid < ns * hd.n_heads) {
+        const int s = tid / hd.n_heads, hh = tid % hd.n_heads;
+        const int k = hd.k[hh], kp = hd.kp[hh], o = hd.qoff[hh];
+        float* lg = s_logit + s * SP + o;
+        float mx = -INFINITY;
+        for (int j = 0; j < k; ++j) mx = fmaxf(mx, lg[j]);
+        float sum = 0.f;
+        for (int j = 0; j < k; ++j) { const float e = expf(lg[j] - mx); lg[j] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < kp; ++j) Q[(int64_t)(i0 + s) * SP + o + j] = (j < k) ? lg[j] * inv : 0.f;
+    }
+}
+
+template <int SB, int JH>
+__global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, const float* __restrict__ small,
+                                                             const float* __restrict__ dqpart, DqChunks dq_chunks, int b,
+                                                             const float* __restrict__ Z, const float* __restrict__ rinv,
+                                                             const float* __restrict__ H, const float* __restrict__ Q,
+                                                             float* __restrict__ dL, float* __restrict__ dHpre,
+                                                             float* __restrict__ dgp, float* __restrict__ dZ,
+                                                             const float* __restrict__ losspart, int64_t n_loss,
+                                                             double* __restrict__ loss_acc) {
+    __shared__ __attribute__((aligned(16))) float s_grp[1024];
+    __shared__ float s_dzn[SB * 8];
+    __shared__ float s_red[4][SB * 8];
+    extern __shared__ __attribute__((aligned(16))) float s_dl[];         // [SB][SP]
+    const int C = hd.C, CP = hd.CP, Hd = hd.Hd, SP = hd.SP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * SB;
+    const int ns = min(SB, b - i0);
+
+    // ---- this thread's hidden units: forward activations (relu mask) and W1 rows, issued first ----
+    const float* W1 = small + hd.w1_off;
+    float hact[JH][SB], w1[JH][8];
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {
+        const int h = tid + 256 * j;
+#pragma unroll
+        for (int s = 0; s < SB; ++s) hact[j][s] = (h < Hd && s < ns) ? H[(int64_t)(i0 + s) * Hd + h] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) w1[j][c] = (h < Hd && c < C) ? W1[h * C + c] : 0.f;
+    }
+    // ---- dQ = sum over chunks, per head ----
+    {
+        int64_t base = 0;
+        for (int hh = 0; hh < hd.n_heads; ++hh) {
+            const int kp = hd.kp[hh];
+            const int row = SB * kp, row4 = row / 4;
+            const int64_t nch = dq_chunks.n[hh];
+            const int G = 256 / row4;
+            const int e4 = tid % row4, g = tid / row4;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g < G && e4 * 4 < ns * kp) {
+                const float4* src = reinterpret_cast<const float4*>(dqpart + base + (int64_t)i0 * kp) + e4;
+                const int64_t stride4 = (int64_t)b * kp / 4;
+#pragma unroll 16
+                for (int64_t ch = g; ch < nch; ch += G) {
+                    const float4 v = src[ch * stride4];
+                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                }
+            }
+            reinterpret_cast<float4*>(s_grp)[tid] = a;
+            __syncthreads();
+            if (tid < row) {
+                float t = 0.f;
+                for (int gg = 0; gg < G; ++gg) t += s_grp[(gg * row4 + tid / 4) * 4 + (tid & 3)];
+                s_dl[(tid / kp) * SP + hd.qoff[hh] + (tid % kp)] = t;
+            }
+            __syncthreads();
+            base += nch * b * kp;
+        }
+    }
+    // ---- softmax backward per (sample, head) ----
+    if (tid < SB * hd.n_heads) {
+        const int s = tid / hd.n_heads, hh = tid % hd.n_heads;
+        const int k = hd.k[hh], kp = hd.kp[hh], o = hd.qoff[hh];
+        float* dl = s_dl + s * SP + o;
+        if (s < ns) {
+            const float* q = Q + (int64_t)(i0 + s) * SP + o;
+            float dot = 0.f;
+            for (int j = 0; j < k; ++j) dot = fmaf(dl[j], q[j], dot);
+            for (int j = 0; j < kp; ++j) {
+                const float v = (j < k) ? q[j] * (dl[j] - dot) : 0.f;
+                dl[j] = v;
+                dL[(int64_t)(i0 + s) * SP + o + j] = v;
+            }
+        } else {
+            for (int j = 0; j < kp; ++j) dl[j] = 0.f;
+        }
+    }
+    __syncthreads();
+    // ---- dH (relu-masked) in registers: head columns in passes of MLP_KT, accumulation order = head, column ----
+    float dh[JH][SB];
+#pragma unroll
+    for (int j = 0; j < JH; ++j)
+#pragma unroll
+        for (int s = 0; s < SB; ++s) dh[j][s] = 0.f;
+    for (int hh = 0; hh < hd.n_heads; ++hh) {
+        const float* Wk = small + hd.wk_off[hh];
+        const int K = hd.k[hh], o = hd.qoff[hh];
+        for (int k0 = 0; k0 < K; k0 += MLP_KT) {
+            float wk[JH][MLP_KT];
+#pragma unroll
+            for (int j = 0; j < JH; ++j) {
+                const int h = tid + 256 * j;
+#pragma unroll
+                for (int kk = 0; kk < MLP_KT; ++kk) wk[j][kk] = (h < Hd && k0 + kk < K) ? Wk[(k0 + kk) * Hd + h] : 0.f;
+            }
+#pragma unroll
+            for (int kk = 0; kk < MLP_KT; ++kk) {
+                float dls[SB];
+#pragma unroll
+                for (int s = 0; s < SB; ++s) dls[s] = (k0 + kk < K) ? s_dl[s * SP + o + k0 + kk] : 0.f;
+#pragma unroll
+                for (int j = 0; j < JH; ++j)
+#pragma unroll
+                    for (int s = 0; s < SB; ++s) dh[j][s] = fmaf(dls[s], wk[j][kk], dh[j][s]);
+            }
+        }
+    }
+    float part[SB][8];
+#pragma unroll
+    for (int s = 0; s < SB; ++s)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) part[s][c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {
+        const int h = tid + 256 * j;
+#pragma unroll
+        for (int s = 0; s < SB; ++s) {
+            const float v = hact[j][s] > 0.f ? dh[j][s] : 0.f;
+            if (h < Hd && s < ns) dHpre[(int64_t)(i0 + s) * Hd + h] = v;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) part[s][c] = fmaf(v, w1[j][c], part[s][c]);
+        }
+    }
+    // ---- dZn[s][c] = sum_h dHpre[s][h] W1[h][c] ----
+#pragma unroll
+    for (int s = 0; s < SB; ++s)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float t = wave_sum_lane63(part[s][c]);
+            if (lane == 63) s_red[wave][s * 8 + c] = t;
+        }
+    __syncthreads();
+    if (tid < SB * 8) s_dzn[tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+    __syncthreads();
+    if (tid < ns) {
+        const int64_t i = i0 + tid;
+        const float ri = rinv[i];
+        const float* g = small + hd.g_off;
+        const float* dzn = s_dzn + tid * 8;
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) dot = fmaf(dzn[c] * g[c], Z[i * CP + c], dot);
+        const float mean_tz = dot / (float)C;
+        const float ri3 = ri * ri * ri;
+        for (int c = 0; c < CP; ++c) {
+            float dz = 0.f, dgv = 0.f;
+            if (c < C) {
+                const float z = Z[i * CP + c];
+                dz = ri * (dzn[c] * g[c]) - z * ri3 * mean_tz;
+                dgv = dzn[c] * z * ri;
+            }
+            dZ[i * CP + c] = dz;
+            dgp[i * CP + c] = dgv;
+        }
+    }
+    // ---- loss (block 0 only) ----
+    if (blockIdx.x == 0 && n_loss > 0) {
+        double a = 0.0;
+        for (int64_t e = tid; e < n_loss; e += 256) a += (double)losspart[e];
+        a = wave_sum_all_f64(a);
+        __shared__ double s_l[4];
+        __syncthreads();
+        if ((tid & 63) == 0) s_l[tid >> 6] = a;
+        __syncthreads();
+        if (tid == 0) {
+            const double tot = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]);
+            loss_acc[0] += tot;
+            loss_acc[1] = tot;
         }
     }
 }
@@ -693,7 +1012,14 @@ extern "C" int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const fl
                             float* Z, float* rinv, float* Zn, float* H, float* Q, void* stream) {
     if (!hd || !small || !zpart || !Z || !rinv || !Zn || !H || !Q) return fail("nadm_mlp_fwd: null pointer");
     if (b <= 0) return fail("nadm_mlp_fwd: empty batch");
-    if (hd->Hd <= 2048) {
+    if (hd->Hd <= 256 * MLP_JMAX && hd->C <= 8 && !getenv("NADM_MLP_GENERIC")) {
+        const dim3 grid((b + MLP_SB - 1) / MLP_SB);
+        const size_t lds = (size_t)MLP_SB * hd->SP * 4;
+        if (hd->Hd <= 1024)
+            hipLaunchKernelGGL((mlp_fwd_fast_kernel<MLP_SB, 4>), grid, dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q);
+        else
+            hipLaunchKernelGGL((mlp_fwd_fast_kernel<MLP_SB, 8>), grid, dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q);
+    } else if (hd->Hd <= 2048) {
         const size_t lds = (size_t)(1024 + MLP_SB * (hd->CP + hd->Hd + hd->SP)) * 4;
         hipLaunchKernelGGL((mlp_fwd_kernel<MLP_SB>), dim3((b + MLP_SB - 1) / MLP_SB), dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q);
     } else {
@@ -714,7 +1040,16 @@ extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const fl
     hipStream_t st = (hipStream_t)stream;
     DqChunks dqc;
     for (int h = 0; h < NADM_MAX_HEADS; ++h) dqc.n[h] = h < hd->n_heads ? nadm_decode_chunks(M, hd->kp[h]) : 0;
-    if (hd->Hd <= 2048) {
+    if (hd->Hd <= 256 * MLP_JMAX && hd->C <= 8 && !getenv("NADM_MLP_GENERIC")) {
+        const dim3 grid((b + MLP_SB - 1) / MLP_SB);
+        const size_t lds = (size_t)MLP_SB * hd->SP * 4;
+        if (hd->Hd <= 1024)
+            hipLaunchKernelGGL((mlp_bwd_a_fast_kernel<MLP_SB, 4>), grid, dim3(256), lds, st, *hd, small, dqpart, dqc, b, Z, rinv, H, Q, dL, dHpre, dgp, dZ,
+                               losspart, n_loss, loss_acc);
+        else
+            hipLaunchKernelGGL((mlp_bwd_a_fast_kernel<MLP_SB, 8>), grid, dim3(256), lds, st, *hd, small, dqpart, dqc, b, Z, rinv, H, Q, dL, dHpre, dgp, dZ,
+                               losspart, n_loss, loss_acc);
+    } else if (hd->Hd <= 2048) {
         const size_t lds = (size_t)(1024 + MLP_SB * (hd->SP + hd->CP + hd->Hd)) * 4;
         hipLaunchKernelGGL((mlp_bwd_a_kernel<MLP_SB>), dim3((b + MLP_SB - 1) / MLP_SB), dim3(256), lds, st, *hd, small, dqpart, dqc, b, Z, rinv, H, Q,
                            dL, dHpre, dgp, dZ, losspart, n_loss, loss_acc);

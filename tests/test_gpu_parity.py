@@ -196,6 +196,35 @@ def test_step_against_oracle_random_shapes(N, M, ks, Hd, C, seed):
         assert not gp[:, k:].any()
 
 
+def test_fast_and_generic_mlp_kernels_agree(monkeypatch):
+    """nadm_mlp_fwd / nadm_mlp_bwd pick register-resident kernels for Hd <= 2048, C <= 8 and the generic ones otherwise
+    (NADM_MLP_GENERIC forces the latter): same outputs up to the summation order over the hidden dimension."""
+    rng = np.random.default_rng(21)
+    for Hd, ks in ((1024, [8]), (1536, [2, 3, 4, 5]), (96, [11])):
+        N, M, C = 37, 900, 8
+        Gm = O.synth_genotypes(N, M, max(ks), seed=5)
+        V0 = (rng.standard_normal((M, C)) / np.sqrt(M)).astype(np.float32)
+        P0 = rng.uniform(0.02, 0.98, size=(sum(ks), M)).astype(np.float32)
+        p = O.make_params(3, V0, P0, Hd, ks)
+        outs = []
+        for generic in (False, True):
+            if generic:
+                monkeypatch.setenv("NADM_MLP_GENERIC", "1")
+            else:
+                monkeypatch.delenv("NADM_MLP_GENERIC", raising=False)
+            e = make_engine(Gm, p, N)
+            idx = torch.arange(N, dtype=torch.int32, device=e.device)
+            e.forward(idx, N)
+            e.backward(idx, N, True)
+            torch.cuda.synchronize()
+            outs.append((e.Q.cpu().numpy().copy(), e.H.cpu().numpy().copy(), e.dZ.cpu().numpy().copy(), e.gsmall.cpu().numpy().copy(),
+                         e.read_loss()[1]))
+        monkeypatch.delenv("NADM_MLP_GENERIC", raising=False)
+        for a, g in zip(outs[0][:4], outs[1][:4]):
+            assert mx(a, g) <= 2e-5 * max(1.0, float(np.abs(g).max()))
+        assert abs(outs[0][4] - outs[1][4]) <= 1e-6 * abs(outs[1][4])
+
+
 def test_without_loss_gives_same_gradients():
     Gm = O.synth_genotypes(50, 2100, 4, seed=5)
     rng = np.random.default_rng(1)
