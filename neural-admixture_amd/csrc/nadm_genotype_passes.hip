@@ -133,6 +133,10 @@ constexpr int EM_WAVES = 8;
 constexpr int EM_SLICE = 256;                         // SNPs per wave
 constexpr int EM_CHUNK_SNPS = EM_WAVES * EM_SLICE;    // 2048
 constexpr int EM_TILES_PER_BLOCK = 13;                // 208 samples per block (grid.y)
+#ifndef NADM_EM_D
+#define NADM_EM_D 4
+#endif
+constexpr int EM_D = NADM_EM_D;                       // X tiles in flight per lane
 
 __device__ __forceinline__ uint32_t bf16_trunc_bits(float v) { return __float_as_uint(v) & 0xFFFF0000u; }
 
@@ -143,6 +147,7 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
     static_assert(CP <= 8, "two MFMA column groups hold hi|mid and lo|0");
     __shared__ uint32_t s_lut[16];
     __shared__ __attribute__((aligned(16))) float s_z[2][EM_WAVES][16 * 8];
+    __shared__ float s_out[EM_TILES_PER_BLOCK][16 * 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int64_t chunk = blockIdx.x;
@@ -190,49 +195,69 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
 
     const int64_t byte_off = chunk * (EM_CHUNK_SNPS / 4) + wave * (EM_SLICE / 4) + 16 * q;
     const bool col_ok = byte_off < ld;
-    auto row_of = [&](int tile) -> int64_t {
+    // all loads are unconditional with clamped addresses (a load inside a divergent branch makes the compiler wait for
+    // every outstanding load, which would serialise the prefetch ring); invalid rows / columns are zeroed at use
+    const int64_t byte_off_c = col_ok ? byte_off : 0;
+    auto row_of = [&](int tile) -> int32_t {
         const int smp = tile * 16 + i;
-        return (tile < tile_end && smp < b) ? (int64_t)idx[smp] : -1;
+        return idx[smp < b ? smp : b - 1];
     };
-    auto load_row = [&](int64_t row) -> uint4 {
-        if (row >= 0 && col_ok) return *reinterpret_cast<const uint4*>(xp + row * ld + byte_off);
-        return make_uint4(0, 0, 0, 0);
-    };
-    int64_t row_next = row_of(tile_begin + 1);
-    uint4 cur = load_row(row_of(tile_begin));
+    auto load_row = [&](int32_t row) -> uint4 { return *reinterpret_cast<const uint4*>(xp + (int64_t)row * ld + byte_off_c); };
+    // EM_D - 1 tiles of loads in flight ahead of the compute (a 16-sample tile is ~0.3 us of work per wave, much less
+    // than the latency of the dependent idx -> row loads); the row index of the tile after those is fetched too.
+    uint4 st[EM_D];
+    int32_t rown[EM_D];                                       // row index ring: tiles tile+EM_D-1 .. tile+2*EM_D-2 (loads retire in order)
+#pragma unroll
+    for (int d = 0; d < EM_D - 1; ++d) rown[d] = row_of(tile_begin + d);
+#pragma unroll
+    for (int d = 0; d < EM_D - 1; ++d) {
+        st[d] = load_row(rown[d]);
+        rown[(d + EM_D - 1) % EM_D] = row_of(tile_begin + d + EM_D - 1);
+    }
 
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-        const uint4 nxt = load_row(row_next);
-        row_next = row_of(tile + 2);
-        const uint32_t raw[4] = {cur.x, cur.y, cur.z, cur.w};
-        f32x4_t d1 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, d2 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int tile0 = tile_begin; tile0 < tile_end; tile0 += EM_D) {
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
-            const uint32_t h16 = (raw[s8 >> 1] >> (16 * (s8 & 1))) & 0xFFFFu;
-            uint32_t aw[4];
+        for (int u = 0; u < EM_D; ++u) {
+            const int tile = tile0 + u;
+            if (tile < tile_end) {                                // block-uniform
+                st[(u + EM_D - 1) % EM_D] = load_row(rown[(u + EM_D - 1) % EM_D]);
+                rown[(u + 2 * EM_D - 2) % EM_D] = row_of(tile + 2 * EM_D - 2);
+                const bool ok = col_ok && (tile * 16 + i < b);
+                const uint4 cur = st[u];
+                const uint32_t raw[4] = {ok ? cur.x : 0u, ok ? cur.y : 0u, ok ? cur.z : 0u, ok ? cur.w : 0u};
+                f32x4_t d1 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, d2 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int p4 = 0; p4 < 4; ++p4) aw[p4] = s_lut[(h16 >> (4 * p4)) & 15u];
-            const bf16x8 av = __builtin_bit_cast(bf16x8, make_uint4(aw[0], aw[1], aw[2], aw[3]));
-            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1[s8], d1, 0, 0, 0);
-            d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b2[s8], d2, 0, 0, 0);
+                for (int s8 = 0; s8 < 8; ++s8) {
+                    const uint32_t h16 = (raw[s8 >> 1] >> (16 * (s8 & 1))) & 0xFFFFu;
+                    uint32_t aw[4];
+#pragma unroll
+                    for (int p4 = 0; p4 < 4; ++p4) aw[p4] = s_lut[(h16 >> (4 * p4)) & 15u];
+                    const bf16x8 av = __builtin_bit_cast(bf16x8, make_uint4(aw[0], aw[1], aw[2], aw[3]));
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1[s8], d1, 0, 0, 0);
+                    d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b2[s8], d2, 0, 0, 0);
+                }
+                // D rows = samples 4q + r, column = i: fold [hi | mid] + [lo | 0] -> columns 0..7
+                const int buf = tile & 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float u2 = d1[r] + d2[r];
+                    u2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u2), 0x128 /*row_ror:8*/, 0xf, 0xf, false));
+                    if (i < 8) s_z[buf][wave][(4 * q + r) * 8 + i] = u2;
+                }
+                __syncthreads();
+                if (tid < 128) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < EM_WAVES; ++w) sum += s_z[buf][w][tid];
+                    s_out[tile - tile_begin][tid] = sum;          // stored after the loop: a global store inside this branch
+                }                                                 // would make every later wait a wait for ALL loads in flight
+            }
         }
-        // D rows = samples 4q + r, column = i: fold [hi | mid] + [lo | 0] -> columns 0..7
-        const int buf = tile & 1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float u = d1[r] + d2[r];
-            u += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u), 0x128 /*row_ror:8*/, 0xf, 0xf, false));
-            if (i < 8) s_z[buf][wave][(4 * q + r) * 8 + i] = u;
-        }
-        __syncthreads();
-        if (tid < 128) {
-            float sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < EM_WAVES; ++w) sum += s_z[buf][w][tid];
-            const int smp = tile * 16 + (tid >> 3), c = tid & 7;
-            if (smp < b && c < CP) zpart[(chunk * b + smp) * CP + c] = sum;
-        }
-        cur = nxt;
+    }
+    __syncthreads();
+    for (int e = tid; e < (tile_end - tile_begin) * 128; e += 512) {
+        const int smp = tile_begin * 16 + (e >> 3), c = e & 7;
+        if (smp < b && c < CP) zpart[(chunk * b + smp) * CP + c] = (&s_out[0][0])[e];
     }
 }
 
@@ -874,6 +899,11 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     f32x4 dpacc[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) dpacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef NADM_ABL_DUP_MFMA
+    f32x4 dpacc2[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) dpacc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
     f32x2_t lossacc = {0.f, 0.f};
 
     // ---- X / Q staging (same scheme as the f32 MFMA kernel: unconditional clamped loads, index one tile ahead) ----
@@ -1010,6 +1040,14 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                         dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd1), dpacc[t], 0, 0, 0);
                         dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd2), dpacc[t], 0, 0, 0);
                         dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(qd1), dpacc[t], 0, 0, 0);
+#ifdef NADM_ABL_DUP_MFMA   // timing experiment only: does extra matrix-pipe work cost wall time?
+                        dpacc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd1), dpacc2[t], 0, 0, 0);
+                        dpacc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd2), dpacc2[t], 0, 0, 0);
+                        dpacc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(qd1), dpacc2[t], 0, 0, 0);
+                        dpacc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(qd2), dpacc2[t], 0, 0, 0);
+                        dpacc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd1), dpacc2[t], 0, 0, 0);
+                        dpacc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd2), dpacc2[t], 0, 0, 0);
+#endif
                     }
                 }
                 // dQ^T rows k (hi part + lo part) and k+8 (mid part) sit 32 lanes apart: fold, lanes a<2 store
@@ -1044,6 +1082,9 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = dpacc[t][r];
+#ifdef NADM_ABL_DUP_MFMA
+            v += 1e-30f * dpacc2[t][r];
+#endif
             v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /*row_ror:8*/, 0xf, 0xf, false));
             const int64_t m = snp_of(t, a, r);
             if (n < KP && m < M) dP[m * KP + n] = v;
@@ -1082,6 +1123,10 @@ constexpr int EB_G = 2;                   // 64-SNP groups per wave
 constexpr int EB_COLS = 4 * EB_G * 16;    // packed byte columns per block (128)
 constexpr int EB_CS = 36;                 // LDS stride of one byte column (32 rows + pad: conflict-free)
 constexpr int EB_CHUNK_SNPS = EB_COLS * 4;
+#ifndef NADM_EB_D
+#define NADM_EB_D 4
+#endif
+constexpr int EB_D = NADM_EB_D;             // X tiles in flight per thread (global loads issued EB_D - 1 tiles ahead)
 
 template <int CP>
 __global__ __launch_bounds__(256) void encode_bwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
@@ -1106,28 +1151,28 @@ __global__ __launch_bounds__(256) void encode_bwd_mfma_kernel(const uint8_t* __r
     const bool lcol_ok = loff < ld;
     const int64_t loff_c = lcol_ok ? loff : 0;
     auto row_idx = [&](int i0, int k) -> int32_t { const int smp = i0 + 4 * rg + k; return idx[smp < b ? smp : b - 1]; };
-    int32_t rows_pref[4];
+    // Loads run EB_D - 1 tiles ahead of the compute: one 32-sample tile is only ~0.3 us of work per wave, far less than
+    // the latency of the dependent idx -> row loads, so a single tile of prefetch leaves every wave waiting on memory.
+    // Row indices are fetched a further EB_D - 1 tiles ahead of the X loads that use them: vector-memory loads retire in
+    // order, so waiting for an index loaded right before would also wait for every X tile in flight.
+    int32_t rows[EB_D][4];
+    uint32_t xw[EB_D][4];
+    float zst[EB_D];                                          // one dZ element of a coming tile per thread: sample tid>>3, column tid&7
+    const int zr = tid >> 3, zc = tid & 7;
+    auto fetch_rows = [&](int i0, int32_t (&rw)[4]) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) rows_pref[k] = row_idx(0, k);
-    uint32_t xw[4];
-    float zst[8];                                             // wave 0: dZ values of the next tile for its A operand slot
-    auto issue = [&](int i0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) xw[k] = *reinterpret_cast<const uint32_t*>(xp + (int64_t)rows_pref[k] * ld + loff_c);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) rows_pref[k] = row_idx(i0 + EB_TS, k);
-        if (wave == 0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int smp = i0 + 8 * q + e;
-                zst[e] = dZ[(int64_t)(smp < b ? smp : b - 1) * CP + ((mcol & 7) < CP ? (mcol & 7) : 0)];
-            }
-        }
+        for (int k = 0; k < 4; ++k) rw[k] = row_idx(i0, k);
     };
-    auto commit = [&](int buf, int i0) {
+    auto issue = [&](int i0, const int32_t (&rw)[4], uint32_t (&xs)[4], float& zs) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xs[k] = *reinterpret_cast<const uint32_t*>(xp + (int64_t)rw[k] * ld + loff_c);
+        const int smp = i0 + zr;
+        zs = dZ[(int64_t)(smp < b ? smp : b - 1) * CP + (zc < CP ? zc : 0)];      // unconditional (no divergent branch around loads)
+    };
+    auto commit = [&](int buf, int i0, const uint32_t (&xs)[4], const float zs) {
         uint32_t d[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = (lcol_ok && i0 + 4 * rg + k < b) ? xw[k] : 0u;
+        for (int k = 0; k < 4; ++k) d[k] = (lcol_ok && i0 + 4 * rg + k < b) ? xs[k] : 0u;
         // 4x4 byte transpose: e[c] = byte c of rows 0..3
         const uint32_t t01l = __builtin_amdgcn_perm(d[1], d[0], 0x05010400u);   // d0.b0 d1.b0 d0.b1 d1.b1
         const uint32_t t01h = __builtin_amdgcn_perm(d[1], d[0], 0x07030602u);   // d0.b2 d1.b2 d0.b3 d1.b3
@@ -1142,29 +1187,20 @@ __global__ __launch_bounds__(256) void encode_bwd_mfma_kernel(const uint8_t* __r
         *reinterpret_cast<uint32_t*>(base + EB_CS) = e1;
         *reinterpret_cast<uint32_t*>(base + 2 * EB_CS) = e2;
         *reinterpret_cast<uint32_t*>(base + 3 * EB_CS) = e3;
-        if (wave == 0) {
-            uint32_t w1[4], w2[4];
-#pragma unroll
-            for (int dd = 0; dd < 4; ++dd) {
-                uint32_t p1[2], p2[2];
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int e = 2 * dd + hh;
-                    const float v = (i0 + 8 * q + e < b && (mcol & 7) < CP) ? zst[e] : 0.f;
-                    const uint32_t hi = bf16_trunc_bits(v);
-                    const float r1 = v - __uint_as_float(hi);
-                    const uint32_t mid = bf16_trunc_bits(r1);
-                    const float r2 = r1 - __uint_as_float(mid);
-                    const uint32_t lo = bf16_trunc_bits(r2);
-                    p1[hh] = (mcol >= 8 ? mid : hi) >> 16;
-                    p2[hh] = mcol >= 8 ? 0u : (lo >> 16);
-                }
-                w1[dd] = p1[0] | (p1[1] << 16);
-                w2[dd] = p2[0] | (p2[1] << 16);
-            }
-            s_a[buf][0][lane] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
-            s_a[buf][1][lane] = make_uint4(w2[0], w2[1], w2[2], w2[3]);
-        }
+        // dZ element (sample zr, column zc) -> bf16 hi/mid/lo scattered into the A operand images:
+        // lane (mcol = zc [+8 for mid], q = zr>>3), element zr&7 of its 8 k-values
+        const float v = (i0 + zr < b && zc < CP) ? zs : 0.f;
+        const uint32_t hi = bf16_trunc_bits(v);
+        const float r1 = v - __uint_as_float(hi);
+        const uint32_t mid = bf16_trunc_bits(r1);
+        const float r2 = r1 - __uint_as_float(mid);
+        const uint32_t lo = bf16_trunc_bits(r2);
+        uint16_t* a1 = reinterpret_cast<uint16_t*>(&s_a[buf][0][0]) + (zr & 7);
+        uint16_t* a2 = reinterpret_cast<uint16_t*>(&s_a[buf][1][0]) + (zr & 7);
+        const int ln = 16 * (zr >> 3) + zc;
+        a1[ln * 8] = (uint16_t)(hi >> 16);
+        a1[(ln + 8) * 8] = (uint16_t)(mid >> 16);
+        a2[ln * 8] = (uint16_t)(lo >> 16);
     };
 
     f32x4 acc1[EB_G][4], acc2[EB_G][4];
@@ -1173,36 +1209,53 @@ __global__ __launch_bounds__(256) void encode_bwd_mfma_kernel(const uint8_t* __r
 #pragma unroll
         for (int j = 0; j < 4; ++j) { acc1[g][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[g][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    issue(0);
-    commit(0, 0);
+    // prologue: tiles 0 .. EB_D-2 in flight (indices are clamped, so issuing past the batch is harmless), tile 0 committed
+    for (int e = tid; e < 2 * 2 * 64; e += 256) (&s_a[0][0][0])[e] = make_uint4(0, 0, 0, 0);     // rows 8..15 of the lo image stay zero
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < EB_D - 1; ++d) fetch_rows(d * EB_TS, rows[d]);
+#pragma unroll
+    for (int d = 0; d < EB_D - 1; ++d) {
+        issue(d * EB_TS, rows[d], xw[d], zst[d]);
+        fetch_rows((d + EB_D - 1) * EB_TS, rows[(d + EB_D - 1) % EB_D]);        // tiles EB_D-1 .. 2*EB_D-3
+    }
+    commit(0, 0, xw[0], zst[0]);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 
     const int ntiles = (b + EB_TS - 1) / EB_TS;
-    for (int tl = 0; tl < ntiles; ++tl) {
-        const int cur = tl & 1;
-        const int i0 = tl * EB_TS;
-        if (tl + 1 < ntiles) issue(i0 + EB_TS);
-        const bf16x8 a1 = __builtin_bit_cast(bf16x8, s_a[cur][0][lane]);
-        const bf16x8 a2 = __builtin_bit_cast(bf16x8, s_a[cur][1][lane]);
+    for (int tl0 = 0; tl0 < ntiles; tl0 += EB_D) {
 #pragma unroll
-        for (int g = 0; g < EB_G; ++g) {
-            const uint8_t* colp = &s_xt[cur][(wave * (16 * EB_G) + g * 16 + mcol) * EB_CS + 8 * q];
-            const uint32_t w0 = *reinterpret_cast<const uint32_t*>(colp);        // samples 8q..8q+3 of this byte column
-            const uint32_t w1 = *reinterpret_cast<const uint32_t*>(colp + 4);    // samples 8q+4..8q+7
+        for (int u = 0; u < EB_D; ++u) {
+            const int tl = tl0 + u;
+            if (tl < ntiles) {                                    // block-uniform
+                const int cur = tl & 1;
+                const int i0 = tl * EB_TS;
+                // tile tl+EB_D-1: its indices were fetched EB_D-1 iterations ago; fetch those of tile tl+2*EB_D-2 now
+                issue(i0 + (EB_D - 1) * EB_TS, rows[(u + EB_D - 1) % EB_D], xw[(u + EB_D - 1) % EB_D], zst[(u + EB_D - 1) % EB_D]);
+                fetch_rows(i0 + (2 * EB_D - 2) * EB_TS, rows[(u + 2 * EB_D - 2) % EB_D]);
+                const bf16x8 a1 = __builtin_bit_cast(bf16x8, s_a[cur][0][lane]);
+                const bf16x8 a2 = __builtin_bit_cast(bf16x8, s_a[cur][1][lane]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint32_t t0 = (w0 >> (2 * j)) & 0x03030303u, t1 = (w1 >> (2 * j)) & 0x03030303u;
-                t0 |= t0 >> 6; t1 |= t1 >> 6;
-                t0 |= t0 >> 12; t1 |= t1 >> 12;
-                const uint2 lo = s_lut[t0 & 0xFFu], hi = s_lut[t1 & 0xFFu];
-                const bf16x8 bv = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-                acc1[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bv, acc1[g][j], 0, 0, 0);
-                acc2[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bv, acc2[g][j], 0, 0, 0);
+                for (int g = 0; g < EB_G; ++g) {
+                    const uint8_t* colp = &s_xt[cur][(wave * (16 * EB_G) + g * 16 + mcol) * EB_CS + 8 * q];
+                    const uint32_t w0 = *reinterpret_cast<const uint32_t*>(colp);        // samples 8q..8q+3 of this byte column
+                    const uint32_t w1 = *reinterpret_cast<const uint32_t*>(colp + 4);    // samples 8q+4..8q+7
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        uint32_t t0 = (w0 >> (2 * j)) & 0x03030303u, t1 = (w1 >> (2 * j)) & 0x03030303u;
+                        t0 |= t0 >> 6; t1 |= t1 >> 6;
+                        t0 |= t0 >> 12; t1 |= t1 >> 12;
+                        const uint2 lo = s_lut[t0 & 0xFFu], hi = s_lut[t1 & 0xFFu];
+                        const bf16x8 bv = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                        acc1[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bv, acc1[g][j], 0, 0, 0);
+                        acc2[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bv, acc2[g][j], 0, 0, 0);
+                    }
+                }
+                if (tl + 1 < ntiles) commit(cur ^ 1, i0 + EB_TS, xw[(u + 1) % EB_D], zst[(u + 1) % EB_D]);
+                __syncthreads();
             }
         }
-        if (tl + 1 < ntiles) commit(cur ^ 1, i0 + EB_TS);
-        __syncthreads();
     }
 
     // ---- fold hi + mid + lo: rows c and c+8 sit 32 lanes apart; lanes with 4*(lane>>4) < CP store ----
