@@ -146,7 +146,8 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
                                                               const float* __restrict__ V, float* __restrict__ zpart) {
     static_assert(CP <= 8, "two MFMA column groups hold hi|mid and lo|0");
     __shared__ uint32_t s_lut[16];
-    __shared__ __attribute__((aligned(16))) float s_z[2][EM_WAVES][16 * 8];
+    static_assert(EM_D * 128 == 64 * EM_WAVES, "one output element per thread in the cross-wave combine");
+    __shared__ __attribute__((aligned(16))) float s_z[2][EM_WAVES][EM_D][16 * 8];
     __shared__ float s_out[EM_TILES_PER_BLOCK][16 * 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
     }
 
     for (int tile0 = tile_begin; tile0 < tile_end; tile0 += EM_D) {
+        const int buf = ((tile0 - tile_begin) / EM_D) & 1;
 #pragma unroll
         for (int u = 0; u < EM_D; ++u) {
             const int tile = tile0 + u;
@@ -237,20 +239,25 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
                     d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b2[s8], d2, 0, 0, 0);
                 }
                 // D rows = samples 4q + r, column = i: fold [hi | mid] + [lo | 0] -> columns 0..7
-                const int buf = tile & 1;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float u2 = d1[r] + d2[r];
                     u2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(u2), 0x128 /*row_ror:8*/, 0xf, 0xf, false));
-                    if (i < 8) s_z[buf][wave][(4 * q + r) * 8 + i] = u2;
+                    if (i < 8) s_z[buf][wave][u][(4 * q + r) * 8 + i] = u2;
                 }
-                __syncthreads();
-                if (tid < 128) {
-                    float sum = 0.f;
+            }
+        }
+        // one barrier per EM_D tiles: thread -> (tile u = tid >> 7, element tid & 127) sums the 8 waves' partials; the
+        // result stays in LDS and is stored after the loop (a global store in this loop would make later waits drain
+        // every load in flight)
+        __syncthreads();
+        {
+            const int u = tid >> 7, e = tid & 127;
+            if (tile0 + u < tile_end) {
+                float sum = 0.f;
 #pragma unroll
-                    for (int w = 0; w < EM_WAVES; ++w) sum += s_z[buf][w][tid];
-                    s_out[tile - tile_begin][tid] = sum;          // stored after the loop: a global store inside this branch
-                }                                                 // would make every later wait a wait for ALL loads in flight
+                for (int w = 0; w < EM_WAVES; ++w) sum += s_z[buf][w][u][e];
+                s_out[tile0 + u - tile_begin][e] = sum;
             }
         }
     }
