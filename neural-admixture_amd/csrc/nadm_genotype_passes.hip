@@ -132,7 +132,7 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int EM_WAVES = 8;
 constexpr int EM_SLICE = 256;                         // SNPs per wave
 constexpr int EM_CHUNK_SNPS = EM_WAVES * EM_SLICE;    // 2048
-constexpr int EM_TILES_PER_BLOCK = 13;                // 208 samples per block (grid.y)
+constexpr int EM_TILES_PER_BLOCK = 28;                // upper bound of 16-sample tiles per block (grid.y splits the batch)
 #ifndef NADM_EM_D
 #define NADM_EM_D 4
 #endif
@@ -143,7 +143,7 @@ __device__ __forceinline__ uint32_t bf16_trunc_bits(float v) { return __float_as
 template <int CP>
 __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
                                                               const int32_t* __restrict__ idx, int b, int64_t M,
-                                                              const float* __restrict__ V, float* __restrict__ zpart) {
+                                                              const float* __restrict__ V, float* __restrict__ zpart, int tiles_per_block) {
     static_assert(CP <= 8, "two MFMA column groups hold hi|mid and lo|0");
     __shared__ uint32_t s_lut[16];
     static_assert(EM_D * 128 == 64 * EM_WAVES, "one output element per thread in the cross-wave combine");
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
     const int i = lane & 15, q = lane >> 4;
     const int64_t chunk = blockIdx.x;
     const int64_t slice0 = chunk * EM_CHUNK_SNPS + wave * EM_SLICE;
-    const int tile_begin = blockIdx.y * EM_TILES_PER_BLOCK;
-    const int tile_end = min((b + 15) / 16, tile_begin + EM_TILES_PER_BLOCK);
+    const int tile_begin = blockIdx.y * tiles_per_block;
+    const int tile_end = min((b + 15) / 16, tile_begin + tiles_per_block);
     if (tid < 16) {
         const uint32_t lo = tid & 3, hi = tid >> 2;
         const uint32_t blo = lo == 1 ? 0x3F00u : (lo == 2 ? 0x3F80u : 0u);
@@ -1382,9 +1382,20 @@ extern "C" int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx
     const size_t lds = (size_t)rpb * ENC_LDW * 4;
     hipStream_t st = (hipStream_t)stream;
     if (CP <= 8 && use_mfma_encode()) {
-        dim3 g2((unsigned)nadm_encode_chunks(M), (unsigned)(((b + 15) / 16 + EM_TILES_PER_BLOCK - 1) / EM_TILES_PER_BLOCK)), b2(512);
-        if (CP == 4) hipLaunchKernelGGL((encode_fwd_mfma_kernel<4>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart);
-        else hipLaunchKernelGGL((encode_fwd_mfma_kernel<8>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart);
+        // Every block first splits its 2048 x CP slice of V into bf16 operands (about as much work as 12 sample tiles), so
+        // a block should see many tiles; but ~2 blocks per CU are needed to fill the chip.  grid.y = as few batch splits as
+        // give >= 512 blocks (never fewer than 4 tiles per block, at most EM_TILES_PER_BLOCK).
+        const int64_t chunks = nadm_encode_chunks(M);
+        const int ntiles = (b + 15) / 16;
+        int64_t gy = (512 + chunks - 1) / chunks;
+        if (gy > (ntiles + 3) / 4) gy = (ntiles + 3) / 4;
+        if (gy < 1) gy = 1;
+        int tpb = (int)((ntiles + gy - 1) / gy);
+        if (tpb > EM_TILES_PER_BLOCK) tpb = EM_TILES_PER_BLOCK;
+        gy = (ntiles + tpb - 1) / tpb;
+        dim3 g2((unsigned)chunks, (unsigned)gy), b2(512);
+        if (CP == 4) hipLaunchKernelGGL((encode_fwd_mfma_kernel<4>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb);
+        else hipLaunchKernelGGL((encode_fwd_mfma_kernel<8>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb);
         return check_launch("encode_fwd_mfma");
     }
     const bool wide = use_mfma_encode();      // VALU fallback for CP > 8 keeps the 2048-SNP chunking

@@ -11,6 +11,6 @@ for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_I
   rm -rf /tmp/pmc_$i
   (cd /tmp && rocprofv3 --pmc $set -d /tmp/pmc_$i -o run -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > /tmp/pmc_$i.log 2>&1)
   db=$(find /tmp/pmc_$i -name "*.db" | head -1)
-  python $R/tools/pmc_summary.py $db decode_bce > gpurun_out/pmc_sq_$i.txt 2>&1 || tail -5 /tmp/pmc_$i.log
+  python $R/tools/pmc_summary.py $db ${PMC_KERNEL:-decode_bce} > gpurun_out/pmc_sq_$i.txt 2>&1 || tail -5 /tmp/pmc_$i.log
   cat gpurun_out/pmc_sq_$i.txt
 done
