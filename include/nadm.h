@@ -99,6 +99,12 @@ int nadm_bed_to_packed(const uint8_t* bed, int64_t N, int64_t M, uint8_t* out_ho
 int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                     const float* V, int32_t CP, float* zpart, void* stream);
 
+/* ---- 8(f)-3: init-time PCA projection  X_pca = (G/2).V  with a MISSING call counted as 1.5 --------------
+ * (train.py:49-55: `batch.astype(np.float32)/2 @ V.T` on the raw codes, no masking; feeds the sklearn GMM.)
+ * Same kernel, buffers and partial-sum layout as nadm_encode_fwd; CP <= 8 only. */
+int nadm_pca_project(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                     const float* V, int32_t CP, float* zpart, void* stream);
+
 /* ---- a6-a8: RMSNorm + Linear/ReLU + per-head Linear + softmax (neural_admixture.py:173-176) */
 int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const float* zpart, int64_t n_chunks, int32_t b,
                  float* Z, float* rinv, float* Zn, float* H, float* Q, void* stream);
@@ -142,6 +148,11 @@ int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b
  * >= clamp_from are clamped to [0,1] after the update (pass n for "no clamp"). */
 int nadm_adam(float* param, const float* grad, float* m, float* v, int64_t n, int64_t clamp_from,
               float lr, int32_t step, float grad_scale, void* stream);
+
+/* ---- 8(f)-4: ADMIXTURE-compatible text output ------------------------------------------------------------
+ * np.savetxt(path, A, delimiter=' ') for a float32 host matrix, byte for byte ('%.18e' of the value widened to
+ * double, src/utils.py:56-66); multi-threaded.  a [rows, cols] with row stride row_stride (elements). */
+int nadm_savetxt_f32(const char* path, const float* a, int64_t rows, int64_t cols, int64_t row_stride);
 
 /* ---- measurement helpers ------------------------------------------------------------------ */
 /* Synthetic admixture-model genotypes written directly as packed bytes:

@@ -143,7 +143,8 @@ __device__ __forceinline__ uint32_t bf16_trunc_bits(float v) { return __float_as
 template <int CP>
 __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
                                                               const int32_t* __restrict__ idx, int b, int64_t M,
-                                                              const float* __restrict__ V, float* __restrict__ zpart, int tiles_per_block) {
+                                                              const float* __restrict__ V, float* __restrict__ zpart, int tiles_per_block,
+                                                              uint32_t missing_bf16) {
     static_assert(CP <= 8, "two MFMA column groups hold hi|mid and lo|0");
     __shared__ uint32_t s_lut[16];
     static_assert(EM_D * 128 == 64 * EM_WAVES, "one output element per thread in the cross-wave combine");
@@ -157,8 +158,10 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
     const int tile_end = min((b + 15) / 16, tile_begin + tiles_per_block);
     if (tid < 16) {
         const uint32_t lo = tid & 3, hi = tid >> 2;
-        const uint32_t blo = lo == 1 ? 0x3F00u : (lo == 2 ? 0x3F80u : 0u);
-        const uint32_t bhi = hi == 1 ? 0x3F00u : (hi == 2 ? 0x3F80u : 0u);
+        // bf16 of code/2; a missing call (3) is 0 in the model (neural_admixture.py:170) and 1.5 = 0x3FC0 in the
+        // init-time PCA projection (train.py:52), selected by the caller
+        const uint32_t blo = lo == 1 ? 0x3F00u : (lo == 2 ? 0x3F80u : (lo == 3 ? missing_bf16 : 0u));
+        const uint32_t bhi = hi == 1 ? 0x3F00u : (hi == 2 ? 0x3F80u : (hi == 3 ? missing_bf16 : 0u));
         s_lut[tid] = blo | (bhi << 16);
     }
     // ---- B operands: V rows of this wave's slice, split hi/mid/lo, for the 8 k-steps ----
@@ -1372,8 +1375,8 @@ static int enc_rows_per_block(int b) {
     return ((per + 63) / 64) * 64;
 }
 
-extern "C" int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                               const float* V, int32_t CP, float* zpart, void* stream) {
+static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                           const float* V, int32_t CP, float* zpart, void* stream, uint32_t missing_bf16) {
     if (!xp || !idx || !V || !zpart) return fail("nadm_encode_fwd: null pointer");
     if (b <= 0 || M <= 0) return fail("nadm_encode_fwd: empty batch or M");
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_encode_fwd: ld must be a multiple of 16 and >= ceil(M/4)");
@@ -1394,8 +1397,8 @@ extern "C" int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx
         if (tpb > EM_TILES_PER_BLOCK) tpb = EM_TILES_PER_BLOCK;
         gy = (ntiles + tpb - 1) / tpb;
         dim3 g2((unsigned)chunks, (unsigned)gy), b2(512);
-        if (CP == 4) hipLaunchKernelGGL((encode_fwd_mfma_kernel<4>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb);
-        else hipLaunchKernelGGL((encode_fwd_mfma_kernel<8>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb);
+        if (CP == 4) hipLaunchKernelGGL((encode_fwd_mfma_kernel<4>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16);
+        else hipLaunchKernelGGL((encode_fwd_mfma_kernel<8>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16);
         return check_launch("encode_fwd_mfma");
     }
     const bool wide = use_mfma_encode();      // VALU fallback for CP > 8 keeps the 2048-SNP chunking
@@ -1423,6 +1426,17 @@ extern "C" int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx
 #undef ENC_LAUNCH
 #undef ENC_CASE
     return check_launch("encode_fwd");
+}
+
+extern "C" int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                               const float* V, int32_t CP, float* zpart, void* stream) {
+    return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0u);
+}
+
+extern "C" int nadm_pca_project(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                                const float* V, int32_t CP, float* zpart, void* stream) {
+    if (CP > 8 || !use_mfma_encode()) return fail("nadm_pca_project: only the matrix-core pass (CP <= 8) has the missing = 1.5 variant");
+    return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0x3FC0u);
 }
 
 extern "C" int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,

@@ -6,6 +6,7 @@
 #include "../../include/nadm.h"
 #include "nadm_host.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <array>
 #include <thread>
@@ -1072,6 +1073,48 @@ extern "C" int nadm_supervised_ce(const float* Q, int32_t SP, int32_t k, int32_t
     if (n_classes != k) return fail("nadm_supervised_ce: number of classes must equal K");   // train.py:79
     hipLaunchKernelGGL(supervised_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, Q, SP, k, kp, labels, idx, b, weight, dqpart0, loss_slot);
     return check_launch("supervised_ce");
+}
+
+// np.savetxt(path, A, delimiter=' ') for a float32 matrix, byte for byte: numpy formats every element with
+// '%.18e' applied to the value widened to double, one row per line, '\n' line ends (reference: src/utils.py:56-66).
+// Rows are formatted by std::threads into per-thread buffers and written in order.
+extern "C" int nadm_savetxt_f32(const char* path, const float* a, int64_t rows, int64_t cols, int64_t row_stride) {
+    if (!path || (!a && rows * cols > 0)) return fail("nadm_savetxt_f32: null pointer");
+    if (rows < 0 || cols < 0 || row_stride < cols) return fail("nadm_savetxt_f32: bad shape");
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail("nadm_savetxt_f32: cannot open output file");
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)(hw ? (hw > 32 ? 32 : hw) : 4);
+    const int64_t block_rows = 2048;                      // rows per thread per round
+    std::vector<std::vector<char>> bufs(nt);
+    bool ok = true;
+    for (int64_t r0 = 0; r0 < rows && ok; r0 += block_rows * nt) {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) {
+            const int64_t b0 = r0 + t * block_rows, b1 = b0 + block_rows < rows ? b0 + block_rows : rows;
+            bufs[t].clear();
+            if (b0 >= rows) continue;
+            th.emplace_back([&, t, b0, b1] {
+                std::vector<char>& o = bufs[t];
+                o.resize((size_t)(b1 - b0) * (size_t)(cols * 26 + 1));
+                char* w = o.data();
+                for (int64_t r = b0; r < b1; ++r) {
+                    const float* row = a + r * row_stride;
+                    for (int64_t c = 0; c < cols; ++c) {
+                        w += snprintf(w, 27, "%.18e", (double)row[c]);
+                        *w++ = (c + 1 < cols) ? ' ' : '\n';
+                    }
+                    if (cols == 0) *w++ = '\n';
+                }
+                o.resize((size_t)(w - o.data()));
+            });
+        }
+        for (auto& x : th) x.join();
+        for (int t = 0; t < nt && ok; ++t)
+            if (!bufs[t].empty() && fwrite(bufs[t].data(), 1, bufs[t].size(), f) != bufs[t].size()) ok = false;
+    }
+    if (fclose(f) != 0) ok = false;
+    return ok ? 0 : fail("nadm_savetxt_f32: write failed");
 }
 
 extern "C" int nadm_adam(float* param, const float* grad, float* m, float* v, int64_t n, int64_t clamp_from, float lr,

@@ -12,9 +12,22 @@ def write_outputs(Qs, run_name: str, K, min_k, max_k, out_path, Ps=None) -> None
     out_path.mkdir(parents=True, exist_ok=True)
     ks = [K] if K is not None else list(range(min_k, max_k + 1))
     for i, k in enumerate(ks):
-        np.savetxt(out_path / f"{run_name}.{k}.Q", Qs[i], delimiter=' ')
+        savetxt(out_path / f"{run_name}.{k}.Q", Qs[i])
         if Ps is not None:
-            np.savetxt(out_path / f"{run_name}.{k}.P", Ps[i], delimiter=' ')
+            savetxt(out_path / f"{run_name}.{k}.P", Ps[i])
+
+
+def savetxt(path, a) -> None:
+    """``np.savetxt(path, a, delimiter=' ')``; float32 matrices go through the native multi-threaded writer
+    (nadm_savetxt_f32, byte-identical output, ~20x faster on a 600k x K matrix)."""
+    import ctypes as C
+    from ._lib import lib, check
+    a = np.asarray(a)
+    if a.dtype != np.float32 or a.ndim != 2:
+        np.savetxt(path, a, delimiter=' ')
+        return
+    a = np.ascontiguousarray(a)
+    check(lib.nadm_savetxt_f32(str(path).encode(), C.c_void_p(a.ctypes.data), a.shape[0], a.shape[1], a.shape[1]), "savetxt")
 
 
 def save_model(model, name: str, save_dir: str) -> None:
@@ -41,6 +54,25 @@ class PackedGenotypes:
         for i in range(4):
             out[:, :, i] = (pk >> (2 * i)) & 3
         return out.reshape(pk.shape[0], -1)[:, : self.M]
+
+
+def packed_chunks(data, ld: int, chunk_rows: int = 4096):
+    """Yield (start, end, packed uint8 CPU tensor [end-start, ld]) over the rows of ``data`` (uint8 [N,M] CPU tensor /
+    array, or PackedGenotypes), packing on the host when needed (nadm_pack2bit_host)."""
+    from ._lib import lib, check, ptr
+    N = data.shape[0]
+    if hasattr(data, "packed"):
+        for s in range(0, N, chunk_rows):
+            yield s, min(N, s + chunk_rows), data.packed[s:s + chunk_rows]
+        return
+    t = data if torch.is_tensor(data) else torch.from_numpy(np.ascontiguousarray(data))
+    M = t.shape[1]
+    for s in range(0, N, chunk_rows):
+        e = min(N, s + chunk_rows)
+        out = torch.empty((e - s, ld), dtype=torch.uint8)
+        src = t[s:e].contiguous()
+        check(lib.nadm_pack2bit_host(ptr(src), ptr(out), e - s, M, ld), "pack2bit_host")
+        yield s, e, out
 
 
 def read_bed_packed(path: str) -> PackedGenotypes:

@@ -18,16 +18,44 @@ logging.basicConfig(stream=sys.stdout, level=logging.INFO, format="%(message)s")
 log = logging.getLogger(__name__)
 
 
-def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_components: int, seed: int) -> np.ndarray:
+def pca_project_gpu(data, V_CM: np.ndarray, device: torch.device, chunk_rows: int = 4096) -> np.ndarray:
+    """X_pca [N, C] float32 = (G/2) @ V.T with a missing call counted as 1.5 (train.py:49-55), computed by the pass-1
+    kernel (nadm_pca_project) from 2-bit packed rows streamed to the GPU ``chunk_rows`` at a time."""
+    from ._lib import lib, check, ptr
+    from .layout import ModelLayout
+    from .io import packed_chunks
+    C_, M = V_CM.shape
+    N = data.shape[0]
+    ld, CP = ModelLayout.row_stride(M), 8
+    Vd = torch.zeros((M, CP), dtype=torch.float32, device=device)
+    Vd[:, :C_] = torch.as_tensor(np.ascontiguousarray(V_CM.T), dtype=torch.float32).to(device)
+    chunks = int(lib.nadm_encode_chunks(M))
+    zpart = torch.empty(chunks * min(N, chunk_rows) * CP, dtype=torch.float32, device=device)
+    idx = torch.arange(min(N, chunk_rows), dtype=torch.int32, device=device)
+    out = np.empty((N, C_), dtype=np.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    for s, e, pk in packed_chunks(data, ld, chunk_rows):
+        xp = pk.to(device)
+        check(lib.nadm_pca_project(ptr(xp), ld, ptr(idx), e - s, M, ptr(Vd), CP, ptr(zpart), st), "pca_project")
+        out[s:e] = zpart[: chunks * (e - s) * CP].view(chunks, e - s, CP).sum(dim=0)[:, :C_].cpu().numpy()
+    return out
+
+
+def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_components: int, seed: int,
+               device: Optional[torch.device] = None) -> np.ndarray:
     """P_init [sum(ks), M] = clip(GMM means @ V, 5e-6, 1-5e-6) in the PCA subspace (train.py:49-68).
     Note the projection keeps missing (3) as 1.5, exactly like the reference (train.py:52).
-    ``data_np``: uint8 [N,M] array or an io.PackedGenotypes (decoded 1024 rows at a time)."""
+    ``data_np``: uint8 [N,M] array or an io.PackedGenotypes.  With a GPU ``device`` and n_components <= 8 the
+    projection runs on the GPU (pca_project_gpu); otherwise on the host, 1024 rows at a time like the reference."""
     from sklearn.mixture import GaussianMixture
     N = data_np.shape[0]
-    rows = data_np.unpack_rows if hasattr(data_np, "unpack_rows") else (lambda s, e: data_np[s:e])
-    X_pca = np.zeros((N, n_components), dtype=np.float32)
-    for i in range(0, N, 1024):
-        X_pca[i:i + 1024] = (rows(i, min(N, i + 1024)).astype(np.float32) / 2) @ V_CM.T
+    if device is not None and device.type == "cuda" and n_components <= 8:
+        X_pca = pca_project_gpu(data_np, V_CM, device)
+    else:
+        rows = data_np.unpack_rows if hasattr(data_np, "unpack_rows") else (lambda s, e: data_np[s:e])
+        X_pca = np.zeros((N, n_components), dtype=np.float32)
+        for i in range(0, N, 1024):
+            X_pca[i:i + 1024] = (rows(i, min(N, i + 1024)).astype(np.float32) / 2) @ V_CM.T
     X_pca = X_pca.astype("float64")
     ks = [K] if K is not None else list(range(min_k, max_k + 1))
     Ps = []
@@ -78,7 +106,7 @@ def train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int,
         log.info("")
         log.info("    Running Gaussian Mixture in PCA subspace...")
         log.info("")
-        P = gmm_p_init(data if hasattr(data, "unpack_rows") else data.numpy(), V, K, min_k, max_k, n_components, seed)
+        P = gmm_p_init(data if hasattr(data, "unpack_rows") else data.numpy(), V, K, min_k, max_k, n_components, seed, device)
     elif master:
         log.info("")
         log.info("    Running Supervised Mode...")

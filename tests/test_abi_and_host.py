@@ -245,3 +245,25 @@ def test_supervised_host_logic_against_oracle_and_reference():
     assert abs(tr.epoch_losses[0] - losses[0]) / losses[0] < 1e-5
     assert np.abs(Qs[0] - Qo[0]).max() < 1e-4 and np.abs(Ps[0] - p.P[0]).max() < 1e-4
     assert abs(d["hi_losses"][0] - 126760.66) < 1.0         # the fixture this is anchored on
+
+
+def test_native_savetxt_matches_numpy_bytes(tmp_path):
+    """io.savetxt / nadm_savetxt_f32 writes exactly what np.savetxt(delimiter=' ') writes (the .Q/.P format,
+    src/utils.py:56-66), including zeros, negative zero, denormals and the largest floats."""
+    from neural_admixture_amd.io import savetxt, write_outputs
+    rng = np.random.default_rng(0)
+    for shape in ((1000, 7), (3, 1), (0, 4), (5000, 3)):
+        A = (rng.standard_normal(shape) * 10.0 ** rng.integers(-38, 38, size=shape)).astype(np.float32)
+        if A.size > 6:
+            A.flat[:7] = [0.0, -0.0, 1.0, 5e-6, np.finfo(np.float32).max, np.finfo(np.float32).tiny, 1e-45]
+        np.savetxt(tmp_path / "ref.txt", A, delimiter=' ')
+        savetxt(tmp_path / "nat.txt", A)
+        assert (tmp_path / "ref.txt").read_bytes() == (tmp_path / "nat.txt").read_bytes()
+    Q = rng.dirichlet(np.ones(3), size=50).astype(np.float32)
+    P = rng.uniform(size=(200, 3)).astype(np.float32)
+    write_outputs([Q], "run", 3, None, None, tmp_path, [P])
+    np.savetxt(tmp_path / "q.txt", Q, delimiter=' ')
+    assert (tmp_path / "run.3.Q").read_bytes() == (tmp_path / "q.txt").read_bytes()
+    assert np.array_equal(np.loadtxt(tmp_path / "run.3.P", dtype=np.float32), P)
+    savetxt(tmp_path / "f64.txt", Q.astype(np.float64))                 # other dtypes: numpy path
+    assert np.allclose(np.loadtxt(tmp_path / "f64.txt"), Q)

@@ -422,6 +422,27 @@ def test_train_boundary_supervised_vs_reference():
         na.train(1, 100, 2e-3, K + 1, 1, data, dev, 1, Hd, True, d["Vt"], pops, None, None, 8)
 
 
+def test_pca_projection_on_gpu_counts_missing_as_one_and_a_half():
+    """train.pca_project_gpu (nadm_pca_project) = (G/2) @ V.T on the raw codes, missing (3) -> 1.5, as the reference's
+    init-time projection (train.py:49-55); from a uint8 matrix and from PackedGenotypes, several row chunks."""
+    from neural_admixture_amd.train import pca_project_gpu
+    from neural_admixture_amd.io import PackedGenotypes
+    from neural_admixture_amd.layout import ModelLayout
+    dev = _dev()
+    rng = np.random.default_rng(3)
+    for N, M, C in ((300, 5003, 8), (37, 129, 5)):
+        Gm = O.synth_genotypes(N, M, 4, seed=9, missing=0.05)
+        assert (Gm == 3).any()
+        V = (rng.standard_normal((C, M)) / np.sqrt(M)).astype(np.float32)
+        ref = (Gm.astype(np.float64) / 2) @ V.T.astype(np.float64)
+        a = pca_project_gpu(torch.from_numpy(Gm), V, dev, chunk_rows=128)
+        ld = ModelLayout.row_stride(M)
+        pk = np.zeros((N, ld), dtype=np.uint8)
+        pk[:, :(M + 3) // 4] = O.pack2bit(Gm)
+        b2 = pca_project_gpu(PackedGenotypes(torch.from_numpy(pk), N, M), V, dev, chunk_rows=1000)
+        assert a.shape == (N, C) and mx(a, ref) < 2e-6 * max(1.0, float(np.abs(ref).max())) and np.array_equal(a, b2)
+
+
 def test_cli_train_and_infer_demo(tmp_path):
     """`python -m neural_admixture_amd train|infer` on the demo BED: RSVD (GPU, from packed) + GMM init + training +
     outputs in the reference's file formats; infer reproduces Q from the saved encoder."""

@@ -39,10 +39,30 @@ def main():
     V = RSVD(data, N, M, 8, 42)
     out["rsvd_s"] = time.time() - t0
     K, mn, mx = (7, None, None) if which == "c2" else (None, 2, 10)
+    # phase timers inside train(): wrap the module-level helpers it calls
+    import importlib
+    tr_mod = importlib.import_module("neural_admixture_amd.train")
+    eng_mod = importlib.import_module("neural_admixture_amd.engine")
+    phases = {}
+
+    def timed(name, fn):
+        def w(*a, **k):
+            torch.cuda.synchronize()
+            t = time.time()
+            r = fn(*a, **k)
+            torch.cuda.synchronize()
+            phases[name] = phases.get(name, 0.0) + time.time() - t
+            return r
+        return w
+    tr_mod.gmm_p_init = timed("gmm_init_s", tr_mod.gmm_p_init)
+    tr_mod.loglikelihood_packed = timed("loglik_s", tr_mod.loglikelihood_packed)
+    eng_mod.Engine.pack_from_host = timed("pack_h2d_s", eng_mod.Engine.pack_from_host)
+    eng_mod.Engine.load_params = timed("load_params_s", eng_mod.Engine.load_params)
     t1 = time.time()
     Ps, Qs, model = na.train(epochs, 800, 2e-3, K, 42, data, dev, 1, 1024, True, V, None, mn, mx, 8)
     torch.cuda.synchronize()
     out["train_call_s"] = time.time() - t1          # GMM init + pack/H2D + epochs + final Q + log-likelihood
+    out["train_phases"] = phases
     with tempfile.TemporaryDirectory() as td:
         t2 = time.time()
         save_model(model, "run", td)
