@@ -100,10 +100,16 @@ int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b
                     const float* V, int32_t CP, float* zpart, void* stream);
 
 /* ---- 8(f)-3: init-time PCA projection  X_pca = (G/2).V  with a MISSING call counted as 1.5 --------------
- * (train.py:49-55: `batch.astype(np.float32)/2 @ V.T` on the raw codes, no masking; feeds the sklearn GMM.)
+ * (train.py:49-55: `batch.astype(np.float32)/2 @ V.T` on the raw codes, no masking; feeds the sklearn GMM.  Also the
+ * first tall-skinny product of the randomized SVD, src/svd.py:52,62 -> utils_c/rsvd.pyx multiply_A_omega.)
  * Same kernel, buffers and partial-sum layout as nadm_encode_fwd; CP <= 8 only. */
 int nadm_pca_project(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                      const float* V, int32_t CP, float* zpart, void* stream);
+/* Transposed product with the same convention,  out [M,CP] = (G/2)^T . Y  for the rows idx[0..b), Y [b,CP]: the second
+ * tall-skinny product of the randomized SVD (src/svd.py:60,77 -> utils_c/rsvd.pyx multiply_QT_A; A = raw codes = 2 * G/2).
+ * Same kernel as nadm_encode_bwd; CP <= 8 only. */
+int nadm_pca_project_t(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                       const float* Y, int32_t CP, float* out, void* stream);
 
 /* ---- a6-a8: RMSNorm + Linear/ReLU + per-head Linear + softmax (neural_admixture.py:173-176) */
 int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const float* zpart, int64_t n_chunks, int32_t b,

@@ -1141,7 +1141,8 @@ constexpr int EB_D = NADM_EB_D;             // X tiles in flight per thread (glo
 template <int CP>
 __global__ __launch_bounds__(256) void encode_bwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
                                                               const int32_t* __restrict__ idx, int b, int64_t M,
-                                                              const float* __restrict__ dZ, float* __restrict__ dV) {
+                                                              const float* __restrict__ dZ, float* __restrict__ dV,
+                                                              uint32_t missing_bf16) {
     static_assert(CP <= 8, "hi|mid and lo|0 share the 16 MFMA rows");
     __shared__ __attribute__((aligned(16))) uint8_t s_xt[2][EB_COLS * EB_CS];
     __shared__ __attribute__((aligned(16))) uint4 s_a[2][2][64];
@@ -1150,8 +1151,8 @@ __global__ __launch_bounds__(256) void encode_bwd_mfma_kernel(const uint8_t* __r
     const int mcol = lane & 15, q = lane >> 4;
     const int64_t chunk = blockIdx.x;
     const int64_t byte0 = chunk * EB_COLS;
-    {   // byte of four 2-bit codes -> 4 bf16 (x = code/2, missing -> 0)
-        auto bf = [](uint32_t c) -> uint32_t { return c == 1 ? 0x3F00u : (c == 2 ? 0x3F80u : 0u); };
+    {   // byte of four 2-bit codes -> 4 bf16 (x = code/2; missing -> 0 in the model, 1.5 in the init-time products)
+        auto bf = [missing_bf16](uint32_t c) -> uint32_t { return c == 1 ? 0x3F00u : (c == 2 ? 0x3F80u : (c == 3 ? missing_bf16 : 0u)); };
         const uint32_t t = tid;
         s_lut[tid] = make_uint2(bf(t & 3) | (bf((t >> 2) & 3) << 16), bf((t >> 4) & 3) | (bf(t >> 6) << 16));
     }
@@ -1469,8 +1470,8 @@ extern "C" int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx
     }
 }
 
-extern "C" int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                               const float* dZ, int32_t CP, float* dV, void* stream) {
+static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                           const float* dZ, int32_t CP, float* dV, void* stream, uint32_t missing_bf16) {
     if (!xp || !idx || !dZ || !dV) return fail("nadm_encode_bwd: null pointer");
     if (b <= 0 || M <= 0) return fail("nadm_encode_bwd: empty batch or M");
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_encode_bwd: ld must be a multiple of 16 and >= ceil(M/4)");
@@ -1478,8 +1479,8 @@ extern "C" int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx
     hipStream_t st = (hipStream_t)stream;
     if (CP <= 8 && use_mfma_encode()) {
         dim3 g2((unsigned)((M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS));
-        if (CP == 4) hipLaunchKernelGGL((encode_bwd_mfma_kernel<4>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV);
-        else hipLaunchKernelGGL((encode_bwd_mfma_kernel<8>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV);
+        if (CP == 4) hipLaunchKernelGGL((encode_bwd_mfma_kernel<4>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV, missing_bf16);
+        else hipLaunchKernelGGL((encode_bwd_mfma_kernel<8>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV, missing_bf16);
         return check_launch("encode_bwd_mfma");
     }
     switch (CP) {
@@ -1492,4 +1493,15 @@ extern "C" int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx
         default: return fail("nadm_encode_bwd: unsupported CP (4,8,12,16,24,32)");
     }
     return check_launch("encode_bwd");
+}
+
+extern "C" int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                               const float* dZ, int32_t CP, float* dV, void* stream) {
+    return encode_bwd_impl(xp, ld, idx, b, M, dZ, CP, dV, stream, 0u);
+}
+
+extern "C" int nadm_pca_project_t(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                                  const float* Y, int32_t CP, float* out, void* stream) {
+    if (CP > 8 || !use_mfma_encode()) return fail("nadm_pca_project_t: only the matrix-core pass (CP <= 8) has the missing = 1.5 variant");
+    return encode_bwd_impl(xp, ld, idx, b, M, Y, CP, out, stream, 0x3FC0u);
 }

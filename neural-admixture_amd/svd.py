@@ -4,9 +4,10 @@ with QR; QR; B = Q^T.A; SVD(B); sign flip (svd.py:16-37); returns Vt[:k] [k,M] f
 codes (0,1,2,3 with missing kept as 3, no centering), exactly like the reference.
 
 The two tall-skinny products that the reference runs as naive Cython triple loops on the CPU
-(src/utils_c/rsvd.pyx:16-50) run here on the GPU straight from the 2-bit packed matrix: rows are decoded
-chunk-wise in HBM (nadm_unpack2bit) and multiplied with torch (plumbing, init-time only).  Without a GPU the same
-code runs through numpy on the host."""
+(src/utils_c/rsvd.pyx:16-50) run here on the GPU straight from the 2-bit packed matrix with the pass-1 / pass-3
+matrix-core kernels (nadm_pca_project / nadm_pca_project_t: genotype/2 with missing = 1.5, i.e. half the raw code,
+fp32-exact bf16 splitting), eight of the k' columns per launch.  Without a GPU the same algorithm runs through
+torch/numpy on the host (unpacked chunks)."""
 from __future__ import annotations
 
 import logging
@@ -26,7 +27,8 @@ def svd_flip(V: np.ndarray, U: np.ndarray) -> np.ndarray:
 
 
 class _Rows:
-    """Chunked access to the raw code matrix A [N,M] as float32, from uint8 [N,M] or io.PackedGenotypes."""
+    """Access to the raw code matrix A [N,M] from uint8 [N,M] or io.PackedGenotypes: resident 2-bit packed in HBM when a
+    GPU is given (products through the HIP kernels), float32 row chunks on the host otherwise."""
 
     def __init__(self, data, device):
         self.dev = device
@@ -34,18 +36,65 @@ class _Rows:
         self.N, self.M = data.shape
         self.data = data
         self.xp = None
-        if self.packed and device is not None and device.type == "cuda":
-            self.xp = data.packed.to(device)
+        if device is not None and device.type == "cuda":
+            from .io import packed_chunks
+            from .layout import ModelLayout
+            ld = ModelLayout.row_stride(self.M)
+            if self.packed:
+                self.xp = data.packed.to(device)
+            else:
+                self.xp = torch.empty((self.N, ld), dtype=torch.uint8, device=device)
+                for s, e, pk in packed_chunks(data, ld, 8192):
+                    self.xp[s:e].copy_(pk)
+            self.ld = ld
 
     def chunk(self, s, e):
-        if self.xp is not None:
-            from ._lib import lib, check, ptr
-            out = torch.empty((e - s, self.M), dtype=torch.uint8, device=self.dev)
-            check(lib.nadm_unpack2bit(ptr(self.xp[s:e]), ptr(out), e - s, self.M, self.xp.shape[1], None), "unpack2bit")
-            return out.float()
         a = self.data.unpack_rows(s, e) if self.packed else np.asarray(self.data[s:e])
-        t = torch.from_numpy(np.ascontiguousarray(a))
-        return (t.to(self.dev) if self.dev is not None else t).float()
+        return torch.from_numpy(np.ascontiguousarray(a)).float()
+
+    # ---- GPU products (A = 2 * (G/2 with missing 1.5)) ----
+    def a_times(self, B_np, rows: int = 8192, keep_on_device: bool = False):
+        """[N,M] @ [M,kp] -> [N,kp]   (B: numpy array or a tensor already on the device)"""
+        from ._lib import lib, check, ptr
+        N, M, dev = self.N, self.M, self.dev
+        kp = B_np.shape[1]
+        chunks = int(lib.nadm_encode_chunks(M))
+        rb = min(N, rows)
+        zpart = torch.empty(chunks * rb * 8, dtype=torch.float32, device=dev)
+        idx = torch.arange(N, dtype=torch.int32, device=dev)
+        Bd = B_np if torch.is_tensor(B_np) else torch.from_numpy(np.ascontiguousarray(B_np, dtype=np.float32)).to(dev)
+        out = torch.empty((N, kp), dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        for g in range(0, kp, 8):
+            w = min(8, kp - g)
+            Vd = torch.zeros((M, 8), dtype=torch.float32, device=dev)
+            Vd[:, :w] = Bd[:, g:g + w]
+            for s in range(0, N, rb):
+                e = min(N, s + rb)
+                check(lib.nadm_pca_project(ptr(self.xp), self.ld, ptr(idx[s:e]), e - s, M, ptr(Vd), 8, ptr(zpart), st), "pca_project")
+                out[s:e, g:g + w] = zpart[: chunks * (e - s) * 8].view(chunks, e - s, 8).sum(dim=0)[:, :w]
+        out *= 2.0
+        return out if keep_on_device else out.cpu().numpy()
+
+    def qt_times(self, Q_nk, keep_on_device: bool = False):
+        """Q [N,kp] (numpy or device tensor) -> Q^T @ A as its TRANSPOSE [M,kp] when kept on the device (the layout the next
+        product consumes), as [kp,M] numpy otherwise."""
+        from ._lib import lib, check, ptr
+        N, M, dev = self.N, self.M, self.dev
+        kp = Q_nk.shape[1]
+        idx = torch.arange(N, dtype=torch.int32, device=dev)
+        Qd = Q_nk if torch.is_tensor(Q_nk) else torch.from_numpy(np.ascontiguousarray(Q_nk, dtype=np.float32)).to(dev)      # [N,kp]
+        out = torch.empty((M, kp), dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        for g in range(0, kp, 8):
+            w = min(8, kp - g)
+            Y = torch.zeros((N, 8), dtype=torch.float32, device=dev)
+            Y[:, :w] = Qd[:, g:g + w]
+            o = torch.empty((M, 8), dtype=torch.float32, device=dev)
+            check(lib.nadm_pca_project_t(ptr(self.xp), self.ld, ptr(idx), N, M, ptr(Y), 8, ptr(o), st), "pca_project_t")
+            out[:, g:g + w] = o[:, :w]
+        out *= 2.0
+        return out if keep_on_device else np.ascontiguousarray(out.t().cpu().numpy())
 
 
 def RSVD(A_uint8, N: int, M: int, k: int = 8, seed: int = 42, oversampling: int = 10, power_iterations: int = 2,
@@ -60,20 +109,37 @@ def RSVD(A_uint8, N: int, M: int, k: int = 8, seed: int = 42, oversampling: int 
         kp = max(k + oversampling, 20)
         t0 = time.time()
         Omega = rng.standard_normal(size=(M, kp), dtype=np.float32)
-        to_dev = (lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)) if device is not None else (lambda x: torch.from_numpy(np.ascontiguousarray(x)))
+
+        if src.xp is not None:
+            # GPU path: everything after Omega stays in HBM.  QR through torch (rocSOLVER); the final SVD of the wide
+            # B [k',M] is taken from the QR of its transpose: B^T = Q2 R2  ->  B = (U S W^T) Q2^T with U S W^T = svd(R2^T).
+            Y = src.a_times(Omega, keep_on_device=True)
+            for _ in range(power_iterations):
+                Qy, _ = torch.linalg.qr(Y, mode="reduced")
+                Bt = src.qt_times(Qy, keep_on_device=True)                 # [M,k']
+                Y = src.a_times(Bt, keep_on_device=True)
+            Q, _ = torch.linalg.qr(Y, mode="reduced")
+            Bt = src.qt_times(Q, keep_on_device=True)                      # B^T [M,k']
+            Q2, R2 = torch.linalg.qr(Bt, mode="reduced")                   # [M,k'], [k',k']
+            Ut, St, Wt = np.linalg.svd(R2.t().cpu().numpy().astype(np.float64), full_matrices=False)
+            Vt = (torch.from_numpy(Wt.astype(np.float32)).to(device) @ Q2.t())[:k]
+            signs = np.sign(Ut[np.argmax(np.abs(Ut), axis=0), np.arange(Ut.shape[1])])[:k]
+            Vt = (Vt * torch.from_numpy(signs.astype(np.float32)).to(device)[:, None]).cpu().numpy()
+            log.info(f"    Total time SVD: {time.time() - t0:.4f}s")
+            return np.ascontiguousarray(Vt.astype(np.float32))
 
         def A_times(B_np):          # [N,M] @ [M,kp] -> [N,kp]   (rsvd.pyx multiply_A_omega)
-            B = to_dev(B_np)
-            return torch.cat([src.chunk(s, min(N, s + rows)) @ B for s in range(0, N, rows)], dim=0).cpu().numpy()
+            B = torch.from_numpy(np.ascontiguousarray(B_np))
+            return torch.cat([src.chunk(s, min(N, s + rows)) @ B for s in range(0, N, rows)], dim=0).numpy()
 
         def QT_times_A(Q_np):       # [kp,N] @ [N,M] -> [kp,M]   (rsvd.pyx multiply_QT_A)
-            QT = to_dev(Q_np)
+            QT = torch.from_numpy(np.ascontiguousarray(Q_np))
             acc = None
             for s in range(0, N, rows):
                 e = min(N, s + rows)
                 part = QT[:, s:e] @ src.chunk(s, e)
                 acc = part if acc is None else acc + part
-            return acc.cpu().numpy()
+            return acc.numpy()
 
         Y = A_times(Omega)
         for _ in range(power_iterations):

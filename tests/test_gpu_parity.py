@@ -443,6 +443,34 @@ def test_pca_projection_on_gpu_counts_missing_as_one_and_a_half():
         assert a.shape == (N, C) and mx(a, ref) < 2e-6 * max(1.0, float(np.abs(ref).max())) and np.array_equal(a, b2)
 
 
+def test_rsvd_through_hip_kernels_matches_reference_vt():
+    """svd.RSVD with both tall-skinny products on the pass-1 / pass-3 kernels (nadm_pca_project / _t, raw codes incl.
+    missing = 3) against the V the reference's own RSVD produced on the demo matrix (tests/golden/demo_k3.npz), from
+    the packed matrix and from the uint8 matrix; plus the two products alone against float64."""
+    from neural_admixture_amd.svd import RSVD, _Rows
+    from neural_admixture_amd.io import PackedGenotypes
+    from neural_admixture_amd.layout import ModelLayout
+    dev = _dev()
+    d = np.load(f"{G}/demo_k3.npz")
+    N, M = int(d["N"]), int(d["M"])
+    Gm = O.unpack2bit(d["G_packed"], M)
+    ld = ModelLayout.row_stride(M)
+    pk = np.zeros((N, ld), dtype=np.uint8)
+    pk[:, :(M + 3) // 4] = d["G_packed"]
+    for data in (PackedGenotypes(torch.from_numpy(pk), N, M), torch.from_numpy(Gm)):
+        Vt = RSVD(data, N, M, 8, int(d["seed"]), device=dev)
+        assert Vt.shape == (8, M) and mx(Vt, d["Vt"]) < 5e-6
+    rng = np.random.default_rng(1)
+    Gs = O.synth_genotypes(333, 4099, 3, seed=2, missing=0.04)
+    rows = _Rows(torch.from_numpy(Gs), dev)
+    B = rng.standard_normal((4099, 20)).astype(np.float32)
+    QT = rng.standard_normal((20, 333)).astype(np.float32)
+    A64 = Gs.astype(np.float64)
+    r1, r2 = A64 @ B.astype(np.float64), QT.astype(np.float64) @ A64
+    assert mx(rows.a_times(B, rows=100), r1) < 2e-6 * np.abs(r1).max()
+    assert mx(rows.qt_times(np.ascontiguousarray(QT.T)), r2) < 2e-6 * np.abs(r2).max()
+
+
 def test_cli_train_and_infer_demo(tmp_path):
     """`python -m neural_admixture_amd train|infer` on the demo BED: RSVD (GPU, from packed) + GMM init + training +
     outputs in the reference's file formats; infer reproduces Q from the saved encoder."""
