@@ -885,9 +885,13 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
         const uint4 H = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
         const uint4 Md = make_uint4(md[0] | (md[1] << 16), md[2] | (md[3] << 16), md[4] | (md[5] << 16), md[6] | (md[7] << 16));
         const uint4 Lo = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
-        const uint4 Z = make_uint4(0, 0, 0, 0);
-        pa_r1[t] = (a < 2) ? H : Md;                      // slots [Ph Ph Pm Pm]
-        pa_r2[t] = (a == 0) ? H : ((a == 1) ? Lo : Z);    // slots [Ph Pl 0 0]
+        // lane-group dependent choice of the piece, written as mask blends: a ?: on whole uint4 values is turned into a
+        // table in scratch memory indexed by the lane group (64 B of scratch stores + loads per tile and thread)
+        const uint32_t m01 = a < 2 ? 0xFFFFFFFFu : 0u, m0 = a == 0 ? 0xFFFFFFFFu : 0u, m1 = a == 1 ? 0xFFFFFFFFu : 0u;
+        pa_r1[t] = make_uint4((H.x & m01) | (Md.x & ~m01), (H.y & m01) | (Md.y & ~m01), (H.z & m01) | (Md.z & ~m01),
+                              (H.w & m01) | (Md.w & ~m01));                                  // slots [Ph Ph Pm Pm]
+        pa_r2[t] = make_uint4((H.x & m0) | (Lo.x & m1), (H.y & m0) | (Lo.y & m1), (H.z & m0) | (Lo.z & m1),
+                              (H.w & m0) | (Lo.w & m1));                                     // slots [Ph Pl 0 0]
     }
     uint4 pa_q1[NTW / 2], pa_q2[NTW / 2];    // dQ^T: lane (row = k-row n: 0-7 hi / 8-15 mid, slot a = 8 SNPs of the tile pair)
 #pragma unroll
@@ -1076,17 +1080,25 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
             }
         }
         __syncthreads();
-        for (int e = tid; e < nt * KP; e += NTHR) {
-            float sm = 0.f;
+        for (int e4 = tid; e4 < nt * KP / 4; e4 += NTHR) {          // 16 B per lane: the tile's slab rows are contiguous
+            float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int w = 0; w < MF_WAVES; ++w) sm += s_dq[w][e];
-            dqpart[(chunk * b + i0) * KP + e] = sm;
+            for (int w = 0; w < MF_WAVES; ++w) {
+                const float4 v = *reinterpret_cast<const float4*>(&s_dq[w][4 * e4]);
+                sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+            }
+            *reinterpret_cast<float4*>(dqpart + (chunk * b + i0) * KP + 4 * e4) = sm;
         }
         if (tl + 1 < ntiles) commit(i0 + MF_TS);
         __syncthreads();
     }
 
     // ---- dP: columns 0..7 (hi + lo parts) and 8..15 (mid part) fold with a rotate by 8 inside the 16-lane row ----
+    // The block's dP rows are one contiguous [chunk SNPs x KP] slab: staged through LDS (the transposition buffers are free
+    // now) and written as full 16 B / lane rows instead of 32 B pieces scattered over rows.
+    static_assert(sizeof(s_t) >= (size_t)MF_WAVES * 16 * NTW * KP * sizeof(float), "dP staging fits the transposition buffers");
+    float* const s_dp = reinterpret_cast<float*>(&s_t[0][0][0][0]);
+    const int64_t snp_blk0 = chunk * (MF_WAVES * 16 * NTW);
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
 #pragma unroll
@@ -1096,8 +1108,15 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
             v += 1e-30f * dpacc2[t][r];
 #endif
             v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /*row_ror:8*/, 0xf, 0xf, false));
-            const int64_t m = snp_of(t, a, r);
-            if (n < KP && m < M) dP[m * KP + n] = v;
+            if (n < KP) s_dp[(int)(snp_of(t, a, r) - snp_blk0) * KP + n] = v;
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int ROW4 = KP / 4;                                  // float4 per SNP row
+        for (int e = tid; e < MF_WAVES * 16 * NTW * ROW4; e += NTHR) {
+            const int64_t m = snp_blk0 + e / ROW4;
+            if (m < M) *reinterpret_cast<float4*>(dP + m * KP + 4 * (e % ROW4)) = *reinterpret_cast<const float4*>(s_dp + 4 * e);
         }
     }
     if constexpr (LOSS) {
