@@ -155,6 +155,15 @@ int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b
 int nadm_adam(float* param, const float* grad, float* m, float* v, int64_t n, int64_t clamp_from,
               float lr, int32_t step, float grad_scale, void* stream);
 
+/* ---- 8(f)-3: log-likelihood report from the packed matrix (src/utils_c/utils.pyx:15-40, called train.py:134-146) -----
+ * partial[b] (b < nadm_loglik_blocks(M), double, device) = sum over the block's 1024 SNPs and all `rows` rows of
+ * g*log(rec) + (2-g)*log1p(-rec) over non-missing calls, rec = clip(Q_i.P_j, eps, 1-eps), g = clip(code, eps, 2-eps), all
+ * in float64 like the reference.  P [M,K] float32 (unpadded, the returned Ps[i]), Q [rows, >=K] float32 with row stride
+ * q_stride, both on the device; K <= 16.  The caller adds the partials (fixed order). */
+int64_t nadm_loglik_blocks(int64_t M);
+int nadm_loglik(const uint8_t* xp, int64_t ld, int64_t rows, int64_t M, const float* P, const float* Q, int32_t K,
+                int32_t q_stride, double eps, double* partial, void* stream);
+
 /* ---- 8(f)-4: ADMIXTURE-compatible text output ------------------------------------------------------------
  * np.savetxt(path, A, delimiter=' ') for a float32 host matrix, byte for byte ('%.18e' of the value widened to
  * double, src/utils.py:56-66); multi-threaded.  a [rows, cols] with row stride row_stride (elements). */

@@ -620,6 +620,69 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
 }
 
 // =================================================================================================
+// loglik: the reference's post-training report (src/utils_c/utils.pyx:15-40) from the packed matrix,
+//   sum over non-missing (i,j) of g*log(rec) + (2-g)*log1p(-rec),  rec = clip(sum_k Q[i,k] P[j,k], eps, 1-eps),
+//   g = clip(code, eps, 2-eps), everything in float64 like the Cython loop (P and Q are the float32 results
+//   widened, train.py:137-139).  block = 256 threads = 256 byte columns = 1024 SNPs; thread t keeps the K
+//   frequencies of its 4 SNPs in registers (doubles), rows stream through with Q tiles broadcast from LDS.
+//   Per-thread double accumulators, fixed-order block reduction, one partial per block (summed by the caller).
+// =================================================================================================
+template <int KP>
+__global__ __launch_bounds__(256) void loglik_kernel(const uint8_t* __restrict__ xp, int64_t ld, int64_t rows, int64_t M,
+                                                     const float* __restrict__ P, const float* __restrict__ Q, int K, int qstride,
+                                                     double eps, double* __restrict__ partial) {
+    constexpr int RT = 64;                                   // rows per Q tile
+    __shared__ double s_q[RT * KP];
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x;
+    const int64_t col = (int64_t)blockIdx.x * 256 + tid;     // byte column
+    const bool col_ok = col * 4 < M;
+    double p[4][KP];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t m = col * 4 + j;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) p[j][k] = (m < M && k < K) ? (double)P[m * K + k] : 0.0;
+    }
+    const double gval[3] = {eps, 1.0, 2.0 - eps};
+    double acc = 0.0;
+    for (int64_t r0 = 0; r0 < rows; r0 += RT) {
+        const int nr = (int)(rows - r0 < RT ? rows - r0 : RT);
+        __syncthreads();
+        for (int e = tid; e < nr * KP; e += 256) {
+            const int r = e / KP, k = e % KP;
+            s_q[e] = k < K ? (double)Q[(r0 + r) * qstride + k] : 0.0;
+        }
+        __syncthreads();
+        if (col_ok) {
+            for (int r = 0; r < nr; ++r) {
+                const uint32_t byte = xp[(r0 + r) * ld + col];
+                double rec[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    const double q = s_q[r * KP + k];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rec[j] = fma(q, p[j][k], rec[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t c = (byte >> (2 * j)) & 3u;
+                    if (c != 3u && col * 4 + j < M) {
+                        const double rr = fmax(eps, fmin(rec[j], 1.0 - eps));
+                        const double g = gval[c];
+                        acc += g * log(rr) + (2.0 - g) * log1p(-rr);
+                    }
+                }
+            }
+        }
+    }
+    acc = wave_sum_all_f64(acc);
+    if ((tid & 63) == 0) s_red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// =================================================================================================
 // supervised_ce: weight * CrossEntropyLoss(sum) applied to the softmax OUTPUT of head 0 as logits
 // (neural_admixture.py:293,470-473).  One block; thread t takes samples t, t+256, ...
 //   loss_i = logsumexp(q_i) - q_i[y_i],  d/dq_ij = softmax(q_i)_j - [j == y_i]
@@ -1115,6 +1178,23 @@ extern "C" int nadm_savetxt_f32(const char* path, const float* a, int64_t rows, 
     }
     if (fclose(f) != 0) ok = false;
     return ok ? 0 : fail("nadm_savetxt_f32: write failed");
+}
+
+extern "C" int64_t nadm_loglik_blocks(int64_t M) { return (M + 1023) / 1024; }
+
+extern "C" int nadm_loglik(const uint8_t* xp, int64_t ld, int64_t rows, int64_t M, const float* P, const float* Q, int32_t K,
+                           int32_t q_stride, double eps, double* partial, void* stream) {
+    if (!xp || !P || !Q || !partial) return fail("nadm_loglik: null pointer");
+    if (ld * 4 < M) return fail("nadm_loglik: ld < ceil(M/4)");
+    if (K <= 0 || K > 16) return fail("nadm_loglik: K must be in 1..16");
+    if (q_stride < K) return fail("nadm_loglik: q_stride < K");
+    if (rows <= 0 || M <= 0) return fail("nadm_loglik: empty matrix");
+    dim3 grid((unsigned)nadm_loglik_blocks(M)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (K <= 4) hipLaunchKernelGGL((loglik_kernel<4>), grid, block, 0, st, xp, ld, rows, M, P, Q, K, q_stride, eps, partial);
+    else if (K <= 8) hipLaunchKernelGGL((loglik_kernel<8>), grid, block, 0, st, xp, ld, rows, M, P, Q, K, q_stride, eps, partial);
+    else hipLaunchKernelGGL((loglik_kernel<16>), grid, block, 0, st, xp, ld, rows, M, P, Q, K, q_stride, eps, partial);
+    return check_launch("loglik");
 }
 
 extern "C" int nadm_adam(float* param, const float* grad, float* m, float* v, int64_t n, int64_t clamp_from, float lr,

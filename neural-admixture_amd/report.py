@@ -38,11 +38,26 @@ def loglikelihood_rows(get_rows, N: int, P: np.ndarray, Q: np.ndarray, dev, eps:
     return float(total.item())
 
 
+def loglikelihood_hip(xp: torch.Tensor, M: int, P: np.ndarray, Q: np.ndarray, eps: float = 1e-6) -> float:
+    """The same float64 reduction in one HIP kernel over the resident packed matrix (nadm_loglik)."""
+    dev = xp.device
+    Pd = torch.as_tensor(np.ascontiguousarray(P, dtype=np.float32), device=dev)
+    Qd = torch.as_tensor(np.ascontiguousarray(Q, dtype=np.float32), device=dev)
+    K = Pd.shape[1]
+    part = torch.empty(int(lib.nadm_loglik_blocks(M)), dtype=torch.float64, device=dev)
+    check(lib.nadm_loglik(ptr(xp), xp.shape[1], xp.shape[0], M, ptr(Pd), ptr(Qd), K, K, float(eps), ptr(part),
+                          torch.cuda.current_stream().cuda_stream), "loglik")
+    return float(part.cpu().numpy().sum())
+
+
 def loglikelihood_packed(engine, data_u8_cpu, P: np.ndarray, Q: np.ndarray, eps: float = 1e-6, rows: int = 256) -> float:
     """Single-GPU runs decode the rows from the resident packed matrix (engine rows are in sample order there);
     sharded runs fall back to the host copy, which is in sample order like Q."""
     N = Q.shape[0]
-    if engine.xp is not None and engine.xp.shape[0] == N and not getattr(engine, "rows_are_sharded", False):
+    resident = engine.xp is not None and engine.xp.shape[0] == N and not getattr(engine, "rows_are_sharded", False)
+    if resident and P.shape[1] <= 16 and engine.device.type == "cuda":
+        return loglikelihood_hip(engine.xp, engine.M, P, Q, eps)
+    if resident:
         return loglikelihood_rows(device_rows_from_packed(engine.xp, engine.M), N, P, Q, engine.device, eps, rows)
     if hasattr(data_u8_cpu, "unpack_rows"):          # PackedGenotypes on the host
         get = lambda s, e: torch.from_numpy(data_u8_cpu.unpack_rows(s, e)).to(engine.device)

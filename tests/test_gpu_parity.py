@@ -471,6 +471,33 @@ def test_rsvd_through_hip_kernels_matches_reference_vt():
     assert mx(rows.qt_times(np.ascontiguousarray(QT.T)), r2) < 2e-6 * np.abs(r2).max()
 
 
+def test_loglikelihood_kernel_matches_float64_oracle():
+    """nadm_loglik (float64 reduction over the resident packed matrix) against the oracle's restatement of the
+    reference's Cython loop (utils.pyx:15-40) and against the value the reference printed on the demo run."""
+    from neural_admixture_amd.report import loglikelihood_hip
+    from neural_admixture_amd.layout import ModelLayout
+    dev = _dev()
+    rng = np.random.default_rng(4)
+    for N, M, K in ((70, 1500, 3), (33, 4099, 7), (20, 700, 12), (5, 3, 1)):
+        Gm = O.synth_genotypes(N, M, max(K, 2), seed=K, missing=0.05)
+        P = rng.uniform(0, 1, size=(M, K)).astype(np.float32)
+        P[rng.uniform(size=P.shape) < 0.05] = 0.0                     # clamped entries -> rec hits eps
+        Q = rng.dirichlet(np.ones(K), size=N).astype(np.float32)
+        ld = ModelLayout.row_stride(M)
+        pk = np.zeros((N, ld), dtype=np.uint8)
+        pk[:, :(M + 3) // 4] = O.pack2bit(Gm)
+        got = loglikelihood_hip(torch.from_numpy(pk).to(dev), M, P, Q)
+        ref = O.loglikelihood(Gm, P, Q)
+        assert abs(got - ref) <= 1e-11 * abs(ref)
+    d = np.load(f"{G}/demo_k3.npz")
+    N, M = int(d["N"]), int(d["M"])
+    ld = ModelLayout.row_stride(M)
+    pk = np.zeros((N, ld), dtype=np.uint8)
+    pk[:, :(M + 3) // 4] = d["G_packed"]
+    got = loglikelihood_hip(torch.from_numpy(pk).to(dev), M, d["hi_e5_P"], d["hi_e5_Q"])
+    assert abs(got - float(d["hi_e5_loglik"])) <= 1e-10 * abs(float(d["hi_e5_loglik"]))
+
+
 def test_cli_train_and_infer_demo(tmp_path):
     """`python -m neural_admixture_amd train|infer` on the demo BED: RSVD (GPU, from packed) + GMM init + training +
     outputs in the reference's file formats; infer reproduces Q from the saved encoder."""
