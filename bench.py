@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak (same guide); the three GEMM-shaped products run as bf16 pieces
 
 
 def parse():
@@ -184,7 +185,13 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kms, "alg_bytes_per_launch": alg_bytes,
                      "whole_step": {"alg_bytes": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
-                                    "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}},
+                                    "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+                     # algorithmic flops per genotype = 4C + 6K (X.V, Q.P^T, dP, dQ, dV); the pass-2 kernel
+                     # is bound by vector-ALU issue (BCE algebra per genotype), not by either roof -- DESIGN.md section 4
+                     "mfma": {"alg_flops_per_genotype": 4 * 8 + 6 * K,
+                              "achieved_tflops": world * b * M * args.steps / dt * (4 * 8 + 6 * K) / 1e12 / world,
+                              "peak_tflops": MFMA_BF16_PEAK_TFLOPS,
+                              "frac": b * M * args.steps / dt * (4 * 8 + 6 * K) / 1e12 / MFMA_BF16_PEAK_TFLOPS}},
         "loss_last_step": loss_last,
     }
     if rank == 0:
