@@ -839,11 +839,18 @@ constexpr int BF_NTW = NADM_BF_NTW;     // 16-SNP tiles per wave
 constexpr int BF_TS = NADM_BF_TS;       // samples per LDS tile
 
 template <int KP, bool LOSS>
-__global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(NADM_BF_WPE, NADM_BF_WPE))) void decode_bce_bf16_kernel(
+__global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(KP > 8 ? 2 : NADM_BF_WPE, KP > 8 ? 2 : NADM_BF_WPE))) void decode_bce_bf16_kernel(
     const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
     const float* __restrict__ P, const float* __restrict__ Q, int SP,
     float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart) {
-    static_assert(KP <= 8, "one 8-wide k slot");
+    static_assert(KP <= 16, "one or two 8-wide k slots");
+    // W (KP 9..16): k spans two 8-wide MFMA slots.  The pieces can no longer share an MFMA's 16 rows / columns, so
+    //   R^T  = [Ph Ph' Ph Ph'].[Qh Qh' Qm Qm'] + [Pm Pm' Pm Pm'].[Qh Qh' Qm Qm'] + [Ph Ph' Pl Pl'].[Ql Ql' Qh Qh']   (X' = k 8..15)
+    //   dQ^T = (Ph + Pm + Pl).dRh + (Ph + Pm).dRl      rows = the 16 k, five MFMAs into one accumulator, no fold
+    //   dP   = dRh.(Qh + Qm + Ql) + dRl.(Qh + Qm)      columns = the 16 k, five MFMAs, no fold
+    // = 8 MFMAs per 16 x 16 tile instead of 5; everything else is shared with the K <= 8 path.
+    constexpr bool W = KP > 8;
+    constexpr int KW = W ? 16 : 8;                       // k columns of the operand images
     static_assert(BF_NTW == 4 || BF_NTW == 2, "tile bits are read as one 32- or 16-bit word");
     constexpr int NTW = BF_NTW, MF_WAVES = BF_WAVES, MF_TS = BF_TS;
     constexpr int RB = MF_WAVES * 4 * NTW;               // 128 packed bytes per row per block
@@ -852,7 +859,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     constexpr int NTHR = 64 * MF_WAVES;
     __shared__ __attribute__((aligned(16))) uint8_t s_x[MF_TS * RS];
     __shared__ __attribute__((aligned(16))) uint4 s_qr[MF_TS / 16][2][64];   // B operands of R^T per 16-sample tile
-    __shared__ __attribute__((aligned(16))) uint4 s_qd[MF_TS / 32][2][64];   // B operands of dP per 32-sample pair
+    __shared__ __attribute__((aligned(16))) uint4 s_qd[MF_TS / 32][W ? 3 : 2][64];   // B operands of dP per 32-sample pair
     __shared__ __attribute__((aligned(16))) float s_dq[MF_WAVES][MF_TS * KP];
     __shared__ __attribute__((aligned(16))) uint16_t s_t[MF_WAVES][2][2][32 * 16];  // per wave: [SNP tile of the pair][hi / lo][32 samples][16 SNPs]
     __shared__ float s_loss[MF_WAVES];
@@ -869,17 +876,18 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
 
     // zero the operand slots that are never written (k-slots 2,3 of the second R MFMA; columns 8..15 of the second dP MFMA)
     for (int e = tid; e < (MF_TS / 16) * 2 * 64; e += NTHR) (&s_qr[0][0][0])[e] = make_uint4(0, 0, 0, 0);
-    for (int e = tid; e < (MF_TS / 32) * 2 * 64; e += NTHR) (&s_qd[0][0][0])[e] = make_uint4(0, 0, 0, 0);
+    for (int e = tid; e < (MF_TS / 32) * (W ? 3 : 2) * 64; e += NTHR) (&s_qd[0][0][0])[e] = make_uint4(0, 0, 0, 0);
 
     // ---- resident A operands built from P ----
-    uint4 pa_r1[NTW], pa_r2[NTW];            // R^T: lane (row = SNP n, slot a)
+    uint4 pa_r1[NTW], pa_r2[NTW], pa_r3[W ? NTW : 1];     // R^T: lane (row = SNP n, slot a)
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
         const int64_t m = snp_of(t, n >> 2, n & 3);
+        const int k0 = W ? 8 * (a & 1) : 0;               // W: slots alternate k 0..7 / 8..15
         uint32_t h[8], md[8], lo[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float v = (m < M && k < KP) ? P[m * KP + k] : 0.f;
+            const float v = (m < M && k0 + k < KP) ? P[m * KP + k0 + k] : 0.f;
             split3(v, h[k], md[k], lo[k]);
         }
         const uint4 H = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
@@ -888,27 +896,37 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
         // lane-group dependent choice of the piece, written as mask blends: a ?: on whole uint4 values is turned into a
         // table in scratch memory indexed by the lane group (64 B of scratch stores + loads per tile and thread)
         const uint32_t m01 = a < 2 ? 0xFFFFFFFFu : 0u, m0 = a == 0 ? 0xFFFFFFFFu : 0u, m1 = a == 1 ? 0xFFFFFFFFu : 0u;
-        pa_r1[t] = make_uint4((H.x & m01) | (Md.x & ~m01), (H.y & m01) | (Md.y & ~m01), (H.z & m01) | (Md.z & ~m01),
-                              (H.w & m01) | (Md.w & ~m01));                                  // slots [Ph Ph Pm Pm]
-        pa_r2[t] = make_uint4((H.x & m0) | (Lo.x & m1), (H.y & m0) | (Lo.y & m1), (H.z & m0) | (Lo.z & m1),
-                              (H.w & m0) | (Lo.w & m1));                                     // slots [Ph Pl 0 0]
+        if constexpr (W) {
+            pa_r1[t] = H;                                                                        // slots [Ph Ph' Ph Ph']
+            pa_r2[t] = Md;                                                                       // slots [Pm Pm' Pm Pm']
+            pa_r3[t] = make_uint4((H.x & m01) | (Lo.x & ~m01), (H.y & m01) | (Lo.y & ~m01), (H.z & m01) | (Lo.z & ~m01),
+                                  (H.w & m01) | (Lo.w & ~m01));                              // slots [Ph Ph' Pl Pl']
+        } else {
+            pa_r1[t] = make_uint4((H.x & m01) | (Md.x & ~m01), (H.y & m01) | (Md.y & ~m01), (H.z & m01) | (Md.z & ~m01),
+                                  (H.w & m01) | (Md.w & ~m01));                              // slots [Ph Ph Pm Pm]
+            pa_r2[t] = make_uint4((H.x & m0) | (Lo.x & m1), (H.y & m0) | (Lo.y & m1), (H.z & m0) | (Lo.z & m1),
+                                  (H.w & m0) | (Lo.w & m1));                                 // slots [Ph Pl 0 0]
+        }
     }
-    uint4 pa_q1[NTW / 2], pa_q2[NTW / 2];    // dQ^T: lane (row = k-row n: 0-7 hi / 8-15 mid, slot a = 8 SNPs of the tile pair)
+    // dQ^T: lane (row n, slot a = 8 SNPs of the tile pair).  K <= 8: rows 0-7 = k (hi) / 8-15 = k (mid), second operand (lo | 0);
+    // W: rows = the 16 k, one operand per piece
+    uint4 pa_q1[NTW / 2], pa_q2[NTW / 2], pa_q3[W ? NTW / 2 : 1];
 #pragma unroll
     for (int tp = 0; tp < NTW / 2; ++tp) {
-        uint32_t w1[8], w2[8];
+        uint32_t w1[8], w2[8], w3[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int64_t m = snp_of(2 * tp + (e >> 2), a, e & 3);
-            const int k = n & 7;
+            const int k = W ? n : (n & 7);
             const float v = (m < M && k < KP) ? P[m * KP + k] : 0.f;
             uint32_t h, md, lo;
             split3(v, h, md, lo);
-            w1[e] = (n < 8) ? h : md;
-            w2[e] = (n < 8) ? lo : 0u;
+            if constexpr (W) { w1[e] = h; w2[e] = md; w3[e] = lo; }
+            else { w1[e] = (n < 8) ? h : md; w2[e] = (n < 8) ? lo : 0u; w3[e] = 0u; }
         }
         pa_q1[tp] = make_uint4(w1[0] | (w1[1] << 16), w1[2] | (w1[3] << 16), w1[4] | (w1[5] << 16), w1[6] | (w1[7] << 16));
         pa_q2[tp] = make_uint4(w2[0] | (w2[1] << 16), w2[2] | (w2[3] << 16), w2[4] | (w2[5] << 16), w2[6] | (w2[7] << 16));
+        if constexpr (W) pa_q3[tp] = make_uint4(w3[0] | (w3[1] << 16), w3[2] | (w3[3] << 16), w3[4] | (w3[5] << 16), w3[6] | (w3[7] << 16));
     }
     f32x4 dpacc[NTW];
 #pragma unroll
@@ -922,9 +940,9 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
 
     // ---- X / Q staging (same scheme as the f32 MFMA kernel: unconditional clamped loads, index one tile ahead) ----
     constexpr int NPIECE = MF_TS * PPR;
-    constexpr int QPT = (MF_TS * 8 + NTHR - 1) / NTHR;     // Q elements staged per thread
-    static_assert(NPIECE <= NTHR && (MF_TS * 8) % QPT == 0 && NTHR % 8 == 0, "at most one X piece per thread");
-    const bool has_piece = tid < NPIECE, has_q = tid < MF_TS * 8 / QPT;
+    constexpr int QPT = (MF_TS * KW + NTHR - 1) / NTHR;    // Q elements staged per thread
+    static_assert(NPIECE <= NTHR && (MF_TS * KW) % QPT == 0 && NTHR % KW == 0, "at most one X piece per thread");
+    const bool has_piece = tid < NPIECE, has_q = tid < MF_TS * KW / QPT;
     const int pr = has_piece ? tid / PPR : 0, pc16 = tid % PPR;
     const int64_t poff = byte0 + pc16 * 16;
     const bool pcol_ok = poff < ld;
@@ -933,7 +951,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     int32_t row_pref = row_index(0);
     uint4 stage;
     float qstage[QPT];
-    const int qr0 = has_q ? tid >> 3 : 0, qk = tid & 7;    // this thread's Q elements: rows qr0 + j*NTHR/8 of the tile, column qk
+    const int qr0 = has_q ? tid / KW : 0, qk = tid % KW;   // this thread's Q elements: rows qr0 + j*NTHR/KW of the tile, column qk
     auto issue = [&](int i0) {
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
@@ -956,17 +974,31 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
             uint32_t h, md, lo;
             split3(v, h, md, lo);
             const int st = qr >> 4, i = qr & 15;
-            uint16_t* r1 = reinterpret_cast<uint16_t*>(&s_qr[st][0][0]) + qk;       // + lane*8 (uint16 units)
-            uint16_t* r2 = reinterpret_cast<uint16_t*>(&s_qr[st][1][0]) + qk;
-            r1[(i) * 8] = (uint16_t)h;        r1[(i + 32) * 8] = (uint16_t)h;            // slots 0,2: Qh
-            r1[(i + 16) * 8] = (uint16_t)md;  r1[(i + 48) * 8] = (uint16_t)md;           // slots 1,3: Qm
-            r2[(i) * 8] = (uint16_t)lo;       r2[(i + 16) * 8] = (uint16_t)h;            // slots 0,1: Ql, Qh
             const int pair = qr >> 5, within = qr & 31, q8 = within >> 3, e = within & 7;
-            uint16_t* d1 = reinterpret_cast<uint16_t*>(&s_qd[pair][0][0]) + e;
-            uint16_t* d2 = reinterpret_cast<uint16_t*>(&s_qd[pair][1][0]) + e;
-            d1[(q8 * 16 + qk) * 8] = (uint16_t)h;                                        // columns 0..7: Qh
-            d1[(q8 * 16 + qk + 8) * 8] = (uint16_t)md;                                   // columns 8..15: Qm
-            d2[(q8 * 16 + qk) * 8] = (uint16_t)lo;                                       // columns 0..7: Ql
+            if constexpr (W) {
+                const int sl = qk >> 3, kk = qk & 7;                                         // k slot and position inside it
+                uint16_t* r1 = reinterpret_cast<uint16_t*>(&s_qr[st][0][0]) + kk;          // + lane*8 (uint16 units)
+                uint16_t* r2 = reinterpret_cast<uint16_t*>(&s_qr[st][1][0]) + kk;
+                r1[(i + 16 * sl) * 8] = (uint16_t)h;   r1[(i + 16 * (2 + sl)) * 8] = (uint16_t)md;   // [Qh Qh' Qm Qm']
+                r2[(i + 16 * sl) * 8] = (uint16_t)lo;  r2[(i + 16 * (2 + sl)) * 8] = (uint16_t)h;    // [Ql Ql' Qh Qh']
+                uint16_t* d1 = reinterpret_cast<uint16_t*>(&s_qd[pair][0][0]) + e;
+                uint16_t* d2 = reinterpret_cast<uint16_t*>(&s_qd[pair][1][0]) + e;
+                uint16_t* d3 = reinterpret_cast<uint16_t*>(&s_qd[pair][2][0]) + e;
+                d1[(q8 * 16 + qk) * 8] = (uint16_t)h;                                        // column qk of Qh / Qm / Ql
+                d2[(q8 * 16 + qk) * 8] = (uint16_t)md;
+                d3[(q8 * 16 + qk) * 8] = (uint16_t)lo;
+            } else {
+                uint16_t* r1 = reinterpret_cast<uint16_t*>(&s_qr[st][0][0]) + qk;       // + lane*8 (uint16 units)
+                uint16_t* r2 = reinterpret_cast<uint16_t*>(&s_qr[st][1][0]) + qk;
+                r1[(i) * 8] = (uint16_t)h;        r1[(i + 32) * 8] = (uint16_t)h;            // slots 0,2: Qh
+                r1[(i + 16) * 8] = (uint16_t)md;  r1[(i + 48) * 8] = (uint16_t)md;           // slots 1,3: Qm
+                r2[(i) * 8] = (uint16_t)lo;       r2[(i + 16) * 8] = (uint16_t)h;            // slots 0,1: Ql, Qh
+                uint16_t* d1 = reinterpret_cast<uint16_t*>(&s_qd[pair][0][0]) + e;
+                uint16_t* d2 = reinterpret_cast<uint16_t*>(&s_qd[pair][1][0]) + e;
+                d1[(q8 * 16 + qk) * 8] = (uint16_t)h;                                        // columns 0..7: Qh
+                d1[(q8 * 16 + qk + 8) * 8] = (uint16_t)md;                                   // columns 8..15: Qm
+                d2[(q8 * 16 + qk) * 8] = (uint16_t)lo;                                       // columns 0..7: Ql
+            }
         }
     };
 
@@ -1001,6 +1033,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                     qb2[s2] = s_qr[st][1][lane];
                 }
                 const uint4 qd1 = s_qd[p][0][lane], qd2 = s_qd[p][1][lane];
+                uint4 qd3 = make_uint4(0, 0, 0, 0);
+                if constexpr (W) qd3 = s_qd[p][2][lane];
                 f32x4 dq[2];
                 dq[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 dq[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1014,7 +1048,12 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                             const int t = 2 * tp + t2;
                             f32x4 D = (f32x4){0.f, 0.f, 0.f, 0.f};
                             D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r1[t]), as_bf16x8(qb1[s2]), D, 0, 0, 0);
-                            D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r2[t]), as_bf16x8(qb2[s2]), D, 0, 0, 0);
+                            if constexpr (W) {
+                                D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r2[t]), as_bf16x8(qb1[s2]), D, 0, 0, 0);
+                                D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r3[t]), as_bf16x8(qb2[s2]), D, 0, 0, 0);
+                            } else {
+                                D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r2[t]), as_bf16x8(qb2[s2]), D, 0, 0, 0);
+                            }
 #pragma unroll
                             for (int h2 = 0; h2 < 2; ++h2) {
                                 const f32x2_t dR = bce_elem2<LOSS>(D[2 * h2], D[2 * h2 + 1], fp4_pair(h2 ? odd[s2] : even[s2], t), lossacc);
@@ -1036,6 +1075,10 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                         dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q1[tp]), bh, dq[s2], 0, 0, 0);
                         dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q2[tp]), bh, dq[s2], 0, 0, 0);
                         dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q1[tp]), bl, dq[s2], 0, 0, 0);
+                        if constexpr (W) {
+                            dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q3[tp]), bh, dq[s2], 0, 0, 0);
+                            dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q2[tp]), bl, dq[s2], 0, 0, 0);
+                        }
                     }
                     // dP: per SNP tile, read dR (hi, lo) of the 32 samples back transposed, then 3 MFMAs
 #pragma unroll
@@ -1054,6 +1097,10 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                         dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd1), dpacc[t], 0, 0, 0);
                         dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd2), dpacc[t], 0, 0, 0);
                         dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(qd1), dpacc[t], 0, 0, 0);
+                        if constexpr (W) {
+                            dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd3), dpacc[t], 0, 0, 0);
+                            dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(qd2), dpacc[t], 0, 0, 0);
+                        }
 #ifdef NADM_ABL_DUP_MFMA   // timing experiment only: does extra matrix-pipe work cost wall time?
                         dpacc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd1), dpacc2[t], 0, 0, 0);
                         dpacc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd2), dpacc2[t], 0, 0, 0);
@@ -1064,17 +1111,22 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
 #endif
                     }
                 }
-                // dQ^T rows k (hi part + lo part) and k+8 (mid part) sit 32 lanes apart: fold, lanes a<2 store
+                // K <= 8: dQ^T rows k (hi part + lo part) and k+8 (mid part) sit 32 lanes apart: fold, lanes a<2 store.
+                // W: rows 4a + r ARE k, every lane group with 4a < KP stores its four.
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     float o[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {                      // v_permlane32_swap: both halves of the wave see lo and hi
-                        const uint32_t u = __float_as_uint(dq[s2][r]);
-                        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-                        o[r] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (W) {
+                            o[r] = dq[s2][r];
+                        } else {                                       // v_permlane32_swap: both halves of the wave see lo and hi
+                            const uint32_t u = __float_as_uint(dq[s2][r]);
+                            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                            o[r] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                        }
                     }
-                    if (a < 2 && 4 * a < KP)
+                    if ((W || a < 2) && 4 * a < KP)
                         *reinterpret_cast<float4*>(&s_dq[wave][(16 * (2 * p + s2) + n) * KP + 4 * a]) = make_float4(o[0], o[1], o[2], o[3]);
                 }
             }
@@ -1107,7 +1159,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
 #ifdef NADM_ABL_DUP_MFMA
             v += 1e-30f * dpacc2[t][r];
 #endif
-            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /*row_ror:8*/, 0xf, 0xf, false));
+            if constexpr (!W) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /*row_ror:8*/, 0xf, 0xf, false));
             if (n < KP) s_dp[(int)(snp_of(t, a, r) - snp_blk0) * KP + n] = v;
         }
     }
@@ -1328,7 +1380,7 @@ template <int KP>
 static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, const float* P,
                               const float* Q, int SP, float* dP, float* dqpart, float* losspart, int with_loss,
                               hipStream_t st) {
-    if constexpr (KP <= 8) {
+    if constexpr (KP <= 16) {
         if (use_bf16_decode()) {
             static_assert(mf_chunk_snps(KP) == BF_WAVES * 16 * BF_NTW, "same chunking as the f32 MFMA kernel");
             const int64_t chunks = (M + mf_chunk_snps(KP) - 1) / mf_chunk_snps(KP);

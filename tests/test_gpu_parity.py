@@ -155,6 +155,7 @@ def test_one_step_against_reference_fixture(name):
     (10, 900, [33], 32, 16, 7),      # KP = 48 (SPL 1)
     (900, 1300, [4], 64, 8, 8),      # b > 832: two row-blocks in pass 1
     (70, 2600, [2, 3, 4, 5, 6, 7, 8, 9, 10], 64, 8, 9),   # c3-style multi-head, SP = 68
+    (150, 5000, [13], 64, 8, 10),    # KP = 16 on the bf16 matrix-pipe kernel: several sample tiles, ragged last one
 ])
 def test_step_against_oracle_random_shapes(N, M, ks, Hd, C, seed):
     Gm = O.synth_genotypes(N, M, max(2, min(max(ks), 6)), seed=seed + 100, missing=0.05)
