@@ -126,7 +126,7 @@ int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b
 /* ---- a11: MLP backward (softmax, Linear, ReLU, RMSNorm) ---------------------------------- */
 /* Reduces dqpart (the heads' slabs laid back to back in head order, head h holding
  * nadm_decode_chunks(M,kp_h)*b*kp_h floats), writes dZ [b,CP], the flat small-parameter gradient
- * grad_small [n_small], and when n_loss>0 adds the step's loss (sum of losspart[0..n_loss)) to
+ * grad_small [n_small] (NULL: left to nadm_mlp_bwd_weights), and when n_loss>0 adds the step's loss (sum of losspart[0..n_loss)) to
  * loss_acc[0] (running sum) and stores it in loss_acc[1] (last step); loss_acc is double[2].
  * Scratch: dL [b,SP], dHpre [b,Hd], dgp [b,CP], small_part [nadm_sample_splits(b), n_small]. */
 int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const float* dqpart, int64_t M, int32_t b,
@@ -143,6 +143,12 @@ int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const float* dqpart
  * and writes the weighted loss to *loss_slot (one float that nadm_mlp_bwd's n_loss range should cover). */
 int nadm_supervised_ce(const float* Q, int32_t SP, int32_t k, int32_t kp, const int32_t* labels, const int32_t* idx,
                        int32_t b, int32_t n_classes, float weight, float* dqpart0, float* loss_slot, void* stream);
+
+/* The weight-gradient half of nadm_mlp_bwd on its own (dWk, dbk, dW1, db1, dg from dL, dHpre, dgp, H, Zn -> grad_small):
+ * pass grad_small = NULL to nadm_mlp_bwd and call this on any stream ordered after it -- it is independent of pass 3,
+ * so a second stream can run it (and the small Adam) underneath nadm_encode_bwd. */
+int nadm_mlp_bwd_weights(const nadm_heads_t* hd, int32_t b, const float* Zn, const float* H, const float* dL,
+                         const float* dHpre, const float* dgp, float* small_part, float* grad_small, void* stream);
 
 /* ---- a11: dV = X^T . dZ  (autograd of neural_admixture.py:172) --------------------------- */
 int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,

@@ -1093,11 +1093,14 @@ extern "C" int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const fl
     return check_launch("mlp_fwd");
 }
 
+extern "C" int nadm_mlp_bwd_weights(const nadm_heads_t* hd, int32_t b, const float* Zn, const float* H, const float* dL,
+                                    const float* dHpre, const float* dgp, float* small_part, float* grad_small, void* stream);
+
 extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const float* dqpart, int64_t M, int32_t b,
                             const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
                             float* dL, float* dHpre, float* dgp, float* small_part, float* dZ, float* grad_small,
                             const float* losspart, int64_t n_loss, double* loss_acc, void* stream) {
-    if (!hd || !small || !dqpart || !Z || !rinv || !Zn || !H || !Q || !dL || !dHpre || !dgp || !small_part || !dZ || !grad_small)
+    if (!hd || !small || !dqpart || !Z || !rinv || !Zn || !H || !Q || !dL || !dHpre || !dgp || !small_part || !dZ)
         return fail("nadm_mlp_bwd: null pointer");
     if (n_loss > 0 && (!losspart || !loss_acc)) return fail("nadm_mlp_bwd: n_loss > 0 needs losspart and loss_acc");
     if (b <= 0) return fail("nadm_mlp_bwd: empty batch");
@@ -1122,10 +1125,20 @@ extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const fl
         hipLaunchKernelGGL((mlp_bwd_a_kernel<1>), dim3(b), dim3(256), lds, st, *hd, small, dqpart, dqc, b, Z, rinv, H, Q,
                            dL, dHpre, dgp, dZ, losspart, n_loss, loss_acc);
     }
+    if (check_launch("mlp_bwd")) return 1;
+    if (!grad_small) return 0;                       // the caller runs nadm_mlp_bwd_weights itself (possibly on another stream)
+    return nadm_mlp_bwd_weights(hd, b, Zn, H, dL, dHpre, dgp, small_part, grad_small, stream);
+}
+
+extern "C" int nadm_mlp_bwd_weights(const nadm_heads_t* hd, int32_t b, const float* Zn, const float* H, const float* dL,
+                                    const float* dHpre, const float* dgp, float* small_part, float* grad_small, void* stream) {
+    if (!hd || !Zn || !H || !dL || !dHpre || !dgp || !small_part || !grad_small) return fail("nadm_mlp_bwd_weights: null pointer");
+    if (b <= 0) return fail("nadm_mlp_bwd_weights: empty batch");
+    hipStream_t st = (hipStream_t)stream;
     const int splits = nadm_sample_splits(b);
     hipLaunchKernelGGL(mlp_bwd_b_kernel, dim3((hd->Hd + 255) / 256, splits), dim3(256), 0, st, *hd, b, Zn, H, dL, dHpre, dgp, small_part);
     hipLaunchKernelGGL(small_reduce_kernel, dim3((hd->n_small + 255) / 256), dim3(256), 0, st, small_part, splits, hd->n_small, grad_small);
-    return check_launch("mlp_bwd");
+    return check_launch("mlp_bwd_weights");
 }
 
 extern "C" int nadm_supervised_ce(const float* Q, int32_t SP, int32_t k, int32_t kp, const int32_t* labels, const int32_t* idx,

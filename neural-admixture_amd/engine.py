@@ -55,6 +55,11 @@ class Engine:
         self.step_count = 0
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event) on the launch stream
         self.timers: Optional[dict] = None
+        # train_step(): optional second stream for the work that does not depend on pass 3.  Measured on MI355X (b=800,
+        # M=500k, K=8): the ~35 us of hidden kernels are cancelled by the cross-stream event waits (0.569 vs 0.563 ms/step),
+        # so it is off by default.
+        self.overlap = False
+        self._side, self._ev = None, None
 
     def _timed(self, name):
         if self.timers is None:
@@ -154,10 +159,11 @@ class Engine:
         check(lib.nadm_mlp_fwd(C.byref(L.heads), ptr(self.small), ptr(self.zpart), L.enc_chunks, b, ptr(self.Z), ptr(self.rinv),
                                ptr(self.Zn), ptr(self.H), ptr(self.Q), st), "mlp_fwd")
 
-    def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_decoder_done=None) -> None:
+    def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_decoder_done=None, on_mlp_bwd_done=None) -> None:
         """Decoder + BCE fwd/bwd per head, MLP backward, dV.  Gradients land in gbig / gsmall.
         ``on_decoder_done`` (optional callable) is invoked after the dP kernels are enqueued -- the
-        multi-GPU path starts the all-reduce of the P gradients there, overlapping pass 3."""
+        multi-GPU path starts the all-reduce of the P gradients there, overlapping pass 3.  With
+        ``on_mlp_bwd_done`` the MLP weight gradients are left to that callback (nadm_mlp_bwd_weights on another stream)."""
         L, st = self.lay, _stream()
         dq_offs, _ = L.dq_offsets(b)
         loss_offs = L.loss_offsets()
@@ -182,8 +188,10 @@ class Engine:
             on_decoder_done()
         check(lib.nadm_mlp_bwd(C.byref(L.heads), ptr(self.small), ptr(self.dqpart), L.M, b, ptr(self.Z), ptr(self.rinv), ptr(self.Zn),
                                ptr(self.H), ptr(self.Q), ptr(self.dL), ptr(self.dHpre), ptr(self.dgp), ptr(self.small_part),
-                               ptr(self.dZ), ptr(self.gsmall), ptr(self.losspart), n_loss if with_loss else 0,
-                               ptr(self.loss_acc), st), "mlp_bwd")
+                               ptr(self.dZ), ptr(self.gsmall) if on_mlp_bwd_done is None else None, ptr(self.losspart),
+                               n_loss if with_loss else 0, ptr(self.loss_acc), st), "mlp_bwd")
+        if on_mlp_bwd_done is not None:
+            on_mlp_bwd_done()
         ev = self._timed("encode_bwd")
         check(lib.nadm_encode_bwd(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self.dZ), L.CP, ptr(self.gbig), st), "encode_bwd")
         if ev: ev[1].record()
@@ -199,10 +207,50 @@ class Engine:
         if ev: ev[1].record()
 
     def train_step(self, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True) -> None:
-        """One single-GPU step (neural_admixture.py:403-414 without the per-step host sync)."""
+        """One single-GPU step (neural_admixture.py:403-414 without the per-step host sync).
+
+        With ``overlap``: same kernels, same inputs and therefore the same bits as forward() + backward() + adam(), but the
+        pieces that do not depend on pass 3 run on a second HIP stream underneath it: Adam + clamp of the P matrices as soon as pass 2 is
+        done (HBM-bound, while passes 2'/3 are issue-bound), the MLP weight gradients and the small Adam as soon as the
+        MLP backward has produced dZ.  Enabled with ``Engine.overlap = True`` (off by default, see __init__)."""
+        if not self.overlap or self.device.type != "cuda":
+            self.forward(idx, b)
+            self.backward(idx, b, with_loss)
+            self.adam(lr)
+            return
+        L = self.lay
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._ev = [torch.cuda.Event() for _ in range(3)]
+        side, (ev_dec, ev_a, ev_side) = self._side, self._ev
+        sst = C.c_void_p(side.cuda_stream)
         self.forward(idx, b)
-        self.backward(idx, b, with_loss)
-        self.adam(lr)
+        self.step_count += 1
+        fsz = 4
+
+        def after_decoder():                                  # P gradients are final: update P underneath the rest
+            ev_dec.record(main)
+            side.wait_event(ev_dec)
+            off = L.clamp_from * fsz
+            check(lib.nadm_adam(C.c_void_p(self.big.data_ptr() + off), C.c_void_p(self.gbig.data_ptr() + off),
+                                C.c_void_p(self.mbig.data_ptr() + off), C.c_void_p(self.vbig.data_ptr() + off),
+                                L.n_big - L.clamp_from, 0, lr, self.step_count, 1.0, sst), "adam(P)")
+
+        def after_mlp_bwd():                                  # dL, dHpre, dgp are final: weight gradients + small Adam
+            ev_a.record(main)
+            side.wait_event(ev_a)
+            check(lib.nadm_mlp_bwd_weights(C.byref(L.heads), b, ptr(self.Zn), ptr(self.H), ptr(self.dL), ptr(self.dHpre), ptr(self.dgp),
+                                           ptr(self.small_part), ptr(self.gsmall), sst), "mlp_bwd_weights")
+            check(lib.nadm_adam(ptr(self.small), ptr(self.gsmall), ptr(self.msmall), ptr(self.vsmall), L.n_small, L.n_small,
+                                lr, self.step_count, 1.0, sst), "adam(small)")
+            ev_side.record(side)
+        self.backward(idx, b, with_loss, on_decoder_done=after_decoder, on_mlp_bwd_done=after_mlp_bwd)
+        ev = self._timed("adam")
+        check(lib.nadm_adam(ptr(self.big), ptr(self.gbig), ptr(self.mbig), ptr(self.vbig), L.clamp_from, L.clamp_from,
+                            lr, self.step_count, 1.0, _stream()), "adam(V)")
+        if ev: ev[1].record()
+        main.wait_event(ev_side)                              # the next step reads P and the small parameters
 
     def train_step_ddp(self, idx: torch.Tensor, b: int, lr: float, world: int, with_loss: bool = True) -> None:
         """Sample-sharded data-parallel step: local gradients -> all-reduce(sum) over RCCL -> Adam with

@@ -226,6 +226,30 @@ def test_fast_and_generic_mlp_kernels_agree(monkeypatch):
         assert abs(outs[0][4] - outs[1][4]) <= 1e-6 * abs(outs[1][4])
 
 
+def test_two_stream_step_is_bit_identical_to_the_single_stream_step():
+    """Engine.train_step overlaps the P / small-parameter updates and the MLP weight gradients with pass 3 on a second
+    stream; same kernels on the same inputs -> the parameters after several steps must be identical bit for bit."""
+    rng = np.random.default_rng(12)
+    N, M, ks, Hd = 300, 6000, [3, 8], 128
+    Gm = O.synth_genotypes(N, M, 4, seed=3)
+    V0 = (rng.standard_normal((M, 8)) / np.sqrt(M)).astype(np.float32)
+    P0 = rng.uniform(0.02, 0.98, size=(sum(ks), M)).astype(np.float32)
+    p = O.make_params(5, V0, P0, Hd, ks)
+    outs = []
+    for overlap in (True, False):
+        e = make_engine(Gm, p, 128)
+        e.overlap = overlap
+        perm = torch.from_numpy(np.random.default_rng(1).permutation(N).astype(np.int32)).to(e.device)
+        for s in range(6):
+            o = (s * 128) % (N - 128)
+            e.train_step(perm[o:o + 128], 128, 2e-3, with_loss=(s % 2 == 0))
+        torch.cuda.synchronize()
+        outs.append((e.big.cpu().numpy().copy(), e.small.cpu().numpy().copy(), e.mbig.cpu().numpy().copy(), e.vsmall.cpu().numpy().copy(),
+                     e.read_loss()[0]))
+    for a, c in zip(outs[0], outs[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(c))
+
+
 def test_without_loss_gives_same_gradients():
     Gm = O.synth_genotypes(50, 2100, 4, seed=5)
     rng = np.random.default_rng(1)
