@@ -37,8 +37,13 @@ class Engine:
         self.bmax = int(max_batch)
         z = lambda n, dt=_f32: torch.zeros(int(n), dtype=dt, device=device)
         # parameters, gradients, Adam moments
-        self.big, self.gbig, self.mbig, self.vbig = z(L.n_big), z(L.n_big), z(L.n_big), z(L.n_big)
-        self.small, self.gsmall, self.msmall, self.vsmall = z(L.n_small), z(L.n_small), z(L.n_small), z(L.n_small)
+        self.big, self.mbig, self.vbig = z(L.n_big), z(L.n_big), z(L.n_big)
+        self.small, self.msmall, self.vsmall = z(L.n_small), z(L.n_small), z(L.n_small)
+        # gradients live in ONE flat buffer [small | pad | V | P...] so that the data-parallel step needs two all-reduces:
+        # the P part right after pass 2, and small + V together after pass 3
+        self._ns_pad = (L.n_small + 63) // 64 * 64
+        self.gflat = z(self._ns_pad + L.n_big)
+        self.gsmall, self.gbig = self.gflat[: L.n_small], self.gflat[self._ns_pad:]
         # activations / scratch
         b = self.bmax
         self.zpart = z(L.enc_chunks * b * L.CP)
@@ -255,17 +260,19 @@ class Engine:
     def train_step_ddp(self, idx: torch.Tensor, b: int, lr: float, world: int, with_loss: bool = True) -> None:
         """Sample-sharded data-parallel step: local gradients -> all-reduce(sum) over RCCL -> Adam with
         grad_scale 1/world (DDP's mean, neural_admixture.py:315-319).  The P-gradient all-reduce is
-        launched as soon as pass 2 is enqueued and overlaps the MLP backward and pass 3."""
+        launched as soon as pass 2 is enqueued and overlaps the MLP backward and pass 3; the small gradients and dV
+        (adjacent in the flat gradient buffer) follow as one message after pass 3."""
         import torch.distributed as dist
         L = self.lay
         works = []
 
+        split = self._ns_pad + L.clamp_from                   # gflat = [small | pad | V] + [P heads]
+
         def start_p():
-            works.append(dist.all_reduce(self.gbig[L.clamp_from:], op=dist.ReduceOp.SUM, async_op=True))
+            works.append(dist.all_reduce(self.gflat[split:], op=dist.ReduceOp.SUM, async_op=True))
         self.forward(idx, b)
         self.backward(idx, b, with_loss, on_decoder_done=start_p)
-        works.append(dist.all_reduce(self.gbig[: L.clamp_from], op=dist.ReduceOp.SUM, async_op=True))
-        works.append(dist.all_reduce(self.gsmall, op=dist.ReduceOp.SUM, async_op=True))
+        works.append(dist.all_reduce(self.gflat[:split], op=dist.ReduceOp.SUM, async_op=True))
         for w in works:
             w.wait()
         self.adam(lr, 1.0 / world)
