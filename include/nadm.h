@@ -69,6 +69,11 @@ int         nadm_heads_init(nadm_heads_t* out, int C, int Hd, const int32_t* ks,
 /* Number of SNP chunks (= rows of partial buffers) the three genotype passes use for M SNPs. */
 int64_t     nadm_encode_chunks(int64_t M);      /* zpart  is [chunks, b, CP]  */
 int64_t     nadm_decode_chunks(int64_t M, int kp); /* per head: dqpart slab [chunks, b, kp], losspart [chunks] */
+/* SNPs per chunk of the decoder pass.  nadm_decode_bce / nadm_encode_bwd may be launched on an SNP sub-range
+ * [m0, m1) with m0 a multiple of lcm(this, 1024): pass xp + m0/4, P/dP (V/dV) + m0*kp, M = m1 - m0 and the slab /
+ * loss pointers advanced by m0/chunk_snps rows -- the data-parallel step does so to start the all-reduce of the first
+ * half of a gradient while the second half is still being computed. */
+int32_t     nadm_decode_chunk_snps(int kp);
 int32_t     nadm_sample_splits(int b);          /* small_part is [splits, n_small] */
 
 /* ---- a1/a2: packing  (replaces pack2bit.cu:10-36,65-117 and :38-62,120-142) ------------ */

@@ -39,6 +39,7 @@ def _load():
         "nadm_heads_init": (C.c_int, [HP, C.c_int, C.c_int, C.POINTER(i32), C.c_int]),
         "nadm_encode_chunks": (i64, [i64]),
         "nadm_decode_chunks": (i64, [i64, C.c_int]),
+        "nadm_decode_chunk_snps": (i32, [C.c_int]),
         "nadm_sample_splits": (i32, [C.c_int]),
         "nadm_pack2bit_host": (C.c_int, [vp, vp, i64, i64, i64]),
         "nadm_pack2bit": (C.c_int, [vp, vp, i64, i64, i64, vp]),

@@ -55,7 +55,7 @@ __global__ void encode_fwd_kernel(const uint8_t* __restrict__ xp, int64_t ld, co
             const int r = piece / PPR, c16 = piece % PPR;
             uint4 v = make_uint4(0, 0, 0, 0);
             const int64_t off = byte0 + c16 * 16;
-            if (r < nrows && off < ld) {
+            if (r < nrows && off * 4 < M) {
                 const int64_t row = idx[row0 + r];
                 v = *reinterpret_cast<const uint4*>(xp + row * ld + off);
             }
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
     __syncthreads();
 
     const int64_t byte_off = chunk * (EM_CHUNK_SNPS / 4) + wave * (EM_SLICE / 4) + 16 * q;
-    const bool col_ok = byte_off < ld;
+    const bool col_ok = byte_off * 4 < M;          // not `< ld`: on an SNP sub-range launch the bytes past M belong to the next range
     // all loads are unconditional with clamped addresses (a load inside a divergent branch makes the compiler wait for
     // every outstanding load, which would serialise the prefetch ring); invalid rows / columns are zeroed at use
     const int64_t byte_off_c = col_ok ? byte_off : 0;
@@ -282,14 +282,14 @@ struct TileLoader {
     static constexpr int NP = (TS * PPR + 255) / 256;   // pieces per thread
     uint4 stage[NP];
     __device__ __forceinline__ void issue(const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx,
-                                          int i0, int b, int64_t byte0, int tid) {
+                                          int i0, int b, int64_t byte0, int tid, int64_t M) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int piece = tid + p * 256;
             const int r = piece / PPR, c16 = piece % PPR;
             uint4 v = make_uint4(0, 0, 0, 0);
             const int64_t off = byte0 + c16 * 16;
-            if (piece < TS * PPR && i0 + r < b && off < ld) {
+            if (piece < TS * PPR && i0 + r < b && off * 4 < M) {
                 const int64_t row = idx[i0 + r];
                 v = *reinterpret_cast<const uint4*>(xp + row * ld + off);
             }
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void decode_bce_kernel(
     };
 
     const int ntiles = (b + TS - 1) / TS;
-    loader.issue(xp, ld, idx, 0, b, byte0, tid);
+    loader.issue(xp, ld, idx, 0, b, byte0, tid, M);
     loader.commit(s_x[0], tid);
     load_q(0, 0);
     __syncthreads();
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void decode_bce_kernel(
         const int cur = t & 1;
         const int i0 = t * TS;
         const int nt = min(TS, b - i0);
-        if (t + 1 < ntiles) loader.issue(xp, ld, idx, i0 + TS, b, byte0, tid);
+        if (t + 1 < ntiles) loader.issue(xp, ld, idx, i0 + TS, b, byte0, tid, M);
 
         for (int ii = 0; ii < nt; ++ii) {
             uint32_t bits;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(
         }
     };
     const int ntiles = (b + TS - 1) / TS;
-    loader.issue(xp, ld, idx, 0, b, byte0, tid);
+    loader.issue(xp, ld, idx, 0, b, byte0, tid, M);
     loader.commit(s_x[0], tid);
     load_z(0, 0);
     __syncthreads();
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(
         const int cur = t & 1;
         const int i0 = t * TS;
         const int nt = min(TS, b - i0);
-        if (t + 1 < ntiles) loader.issue(xp, ld, idx, i0 + TS, b, byte0, tid);
+        if (t + 1 < ntiles) loader.issue(xp, ld, idx, i0 + TS, b, byte0, tid, M);
         for (int ii = 0; ii < nt; ++ii) {
             const uint32_t bits = s_x[cur][ii * RB + tid];
             float z[CP];
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(64 * mf_waves(KP)) void decode_bce_mfma_kernel(
     const int pc = tid < NPIECE ? tid : tid - NPIECE * (tid / NPIECE);   // duplicate pieces beyond NPIECE (never committed)
     const int pr = pc / PPR, pc16 = pc % PPR;
     const int64_t poff = byte0 + pc16 * 16;
-    const bool pcol_ok = poff < ld;
+    const bool pcol_ok = poff * 4 < M;             // not `< ld`: on an SNP sub-range launch the bytes past M belong to the next range
     const int64_t poff_c = pcol_ok ? poff : 0;
     auto row_index = [&](int i0) -> int32_t { const int smp = i0 + pr; return idx[smp < b ? smp : b - 1]; };
     int32_t row_pref = row_index(0);                         // kept as the raw 32-bit value: widened only when used
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
     const bool has_piece = tid < NPIECE, has_q = tid < MF_TS * KW / QPT;
     const int pr = has_piece ? tid / PPR : 0, pc16 = tid % PPR;
     const int64_t poff = byte0 + pc16 * 16;
-    const bool pcol_ok = poff < ld;
+    const bool pcol_ok = poff * 4 < M;             // not `< ld`: on an SNP sub-range launch the bytes past M belong to the next range
     const int64_t poff_c = pcol_ok ? poff : 0;
     auto row_index = [&](int i0) -> int32_t { const int smp = i0 + pr; return idx[smp < b ? smp : b - 1]; };
     int32_t row_pref = row_index(0);
@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(256) void encode_bwd_mfma_kernel(const uint8_t* __r
     // ---- loader mapping: thread -> 4 rows x 4 byte columns ----
     const int cg = tid & 31, rg = tid >> 5;                   // byte columns 4cg..4cg+3, rows 4rg..4rg+3 of the tile
     const int64_t loff = byte0 + 4 * cg;
-    const bool lcol_ok = loff < ld;
+    const bool lcol_ok = loff * 4 < M;             // not `< ld`: sub-range launches, see pass 2
     const int64_t loff_c = lcol_ok ? loff : 0;
     auto row_idx = [&](int i0, int k) -> int32_t { const int smp = i0 + 4 * rg + k; return idx[smp < b ? smp : b - 1]; };
     // Loads run EB_D - 1 tiles ahead of the compute: one 32-sample tile is only ~0.3 us of work per wave, far less than
@@ -1434,10 +1434,14 @@ extern "C" int64_t nadm_encode_chunks(int64_t M) {
     return (M + ENC_CHUNK_SNPS - 1) / ENC_CHUNK_SNPS;
 }
 
+extern "C" int32_t nadm_decode_chunk_snps(int kp) {
+    if (kp <= 16 && use_mfma_decode()) return mf_chunk_snps(kp);
+    return 256 * dec_spl(kp);
+}
+
 extern "C" int64_t nadm_decode_chunks(int64_t M, int kp) {
-    if (kp <= 16 && use_mfma_decode()) return (M + mf_chunk_snps(kp) - 1) / mf_chunk_snps(kp);
-    const int spl = dec_spl(kp);
-    return (M + 256 * spl - 1) / (256 * spl);
+    const int64_t c = nadm_decode_chunk_snps(kp);
+    return (M + c - 1) / c;
 }
 
 static int enc_rows_per_block(int b) {

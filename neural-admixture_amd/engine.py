@@ -10,6 +10,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import List, Optional, Sequence
 
+import math
+
 import numpy as np
 import torch
 
@@ -164,24 +166,43 @@ class Engine:
         check(lib.nadm_mlp_fwd(C.byref(L.heads), ptr(self.small), ptr(self.zpart), L.enc_chunks, b, ptr(self.Z), ptr(self.rinv),
                                ptr(self.Zn), ptr(self.H), ptr(self.Q), st), "mlp_fwd")
 
-    def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_decoder_done=None, on_mlp_bwd_done=None) -> None:
-        """Decoder + BCE fwd/bwd per head, MLP backward, dV.  Gradients land in gbig / gsmall.
-        ``on_decoder_done`` (optional callable) is invoked after the dP kernels are enqueued -- the
-        multi-GPU path starts the all-reduce of the P gradients there, overlapping pass 3.  With
-        ``on_mlp_bwd_done`` the MLP weight gradients are left to that callback (nadm_mlp_bwd_weights on another stream)."""
+    def _snp_ranges(self, n_parts: int, align: int):
+        """[m0, m1) ranges covering the M SNPs, boundaries at multiples of ``align``."""
+        M = self.lay.M
+        units = (M + align - 1) // align
+        n_parts = max(1, min(n_parts, units))
+        cuts = [min(M, (units * i // n_parts) * align) for i in range(n_parts)] + [M]
+        return [(cuts[i], cuts[i + 1]) for i in range(n_parts) if cuts[i + 1] > cuts[i]]
+
+    def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_decoder_done=None, on_mlp_bwd_done=None,
+                 on_grad_ready=None, p_parts: int = 1, v_parts: int = 1) -> None:
+        """Decoder + BCE fwd/bwd per head, MLP backward, dV.  Gradients land in gbig / gsmall (views of gflat).
+        ``on_decoder_done`` (optional callable) is invoked after all the dP kernels are enqueued.  With
+        ``on_mlp_bwd_done`` the MLP weight gradients are left to that callback (nadm_mlp_bwd_weights on another stream).
+        ``on_grad_ready(lo, hi)`` is invoked each time a contiguous piece gflat[lo:hi] of the big gradients is final and
+        enqueued; passes 2 and 3 are launched on ``p_parts`` / ``v_parts`` SNP sub-ranges so that the data-parallel step can
+        all-reduce one piece while the next is being computed (each head's P, or the halves of a single head's P; the
+        small gradients travel with the first piece of dV)."""
         L, st = self.lay, _stream()
         dq_offs, _ = L.dq_offsets(b)
         loss_offs = L.loss_offsets()
         fsz = 4
         ev = self._timed("decode_bce")
         for h in range(len(L.ks)):
-            check(lib.nadm_decode_bce(
-                ptr(self.xp), self.ld, ptr(idx), b, L.M,
-                C.c_void_p(self.big.data_ptr() + L.p_off[h] * fsz), L.kp[h],
-                C.c_void_p(self.Q.data_ptr() + L.qoff[h] * fsz), L.SP,
-                C.c_void_p(self.gbig.data_ptr() + L.p_off[h] * fsz),
-                C.c_void_p(self.dqpart.data_ptr() + dq_offs[h] * fsz),
-                C.c_void_p(self.losspart.data_ptr() + loss_offs[h] * fsz), 1 if with_loss else 0, st), "decode_bce")
+            kp = L.kp[h]
+            csnps = int(lib.nadm_decode_chunk_snps(kp))
+            align = csnps * 1024 // math.gcd(csnps, 1024)
+            for m0, m1 in self._snp_ranges(p_parts, align):
+                c0 = m0 // csnps
+                check(lib.nadm_decode_bce(
+                    C.c_void_p(self.xp.data_ptr() + m0 // 4), self.ld, ptr(idx), b, m1 - m0,
+                    C.c_void_p(self.big.data_ptr() + (L.p_off[h] + m0 * kp) * fsz), kp,
+                    C.c_void_p(self.Q.data_ptr() + L.qoff[h] * fsz), L.SP,
+                    C.c_void_p(self.gbig.data_ptr() + (L.p_off[h] + m0 * kp) * fsz),
+                    C.c_void_p(self.dqpart.data_ptr() + (dq_offs[h] + c0 * b * kp) * fsz),
+                    C.c_void_p(self.losspart.data_ptr() + (loss_offs[h] + c0) * fsz), 1 if with_loss else 0, st), "decode_bce")
+                if on_grad_ready is not None:
+                    on_grad_ready(self._ns_pad + L.p_off[h] + m0 * kp, self._ns_pad + L.p_off[h] + m1 * kp)
         if ev: ev[1].record()
         n_loss = L.n_loss
         if self.labels is not None:
@@ -198,7 +219,11 @@ class Engine:
         if on_mlp_bwd_done is not None:
             on_mlp_bwd_done()
         ev = self._timed("encode_bwd")
-        check(lib.nadm_encode_bwd(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self.dZ), L.CP, ptr(self.gbig), st), "encode_bwd")
+        for i, (m0, m1) in enumerate(self._snp_ranges(v_parts, 1024)):
+            check(lib.nadm_encode_bwd(C.c_void_p(self.xp.data_ptr() + m0 // 4), self.ld, ptr(idx), b, m1 - m0, ptr(self.dZ), L.CP,
+                                      C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz), st), "encode_bwd")
+            if on_grad_ready is not None:                     # the first piece carries the small gradients in front of it
+                on_grad_ready(0 if i == 0 else self._ns_pad + m0 * L.CP, self._ns_pad + m1 * L.CP)
         if ev: ev[1].record()
 
     def adam(self, lr: float, grad_scale: float = 1.0) -> None:
@@ -259,20 +284,21 @@ class Engine:
 
     def train_step_ddp(self, idx: torch.Tensor, b: int, lr: float, world: int, with_loss: bool = True) -> None:
         """Sample-sharded data-parallel step: local gradients -> all-reduce(sum) over RCCL -> Adam with
-        grad_scale 1/world (DDP's mean, neural_admixture.py:315-319).  The P-gradient all-reduce is
-        launched as soon as pass 2 is enqueued and overlaps the MLP backward and pass 3; the small gradients and dV
-        (adjacent in the flat gradient buffer) follow as one message after pass 3."""
+        grad_scale 1/world (DDP's mean, neural_admixture.py:315-319).  Every piece of the flat gradient buffer is
+        all-reduced as soon as the kernel that completes it is enqueued, so the messages run underneath the remaining
+        kernels: P of head h under pass 2 of head h+1 (the two halves of a single head under each other), the last P piece
+        under the MLP backward and pass 3, the first half of dV (+ the small gradients) under the second."""
         import torch.distributed as dist
         L = self.lay
         works = []
 
-        split = self._ns_pad + L.clamp_from                   # gflat = [small | pad | V] + [P heads]
 
-        def start_p():
-            works.append(dist.all_reduce(self.gflat[split:], op=dist.ReduceOp.SUM, async_op=True))
+        def reduce_piece(lo, hi):                             # gflat = [small | pad | V | P heads]
+            works.append(dist.all_reduce(self.gflat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         self.forward(idx, b)
-        self.backward(idx, b, with_loss, on_decoder_done=start_p)
-        works.append(dist.all_reduce(self.gflat[:split], op=dist.ReduceOp.SUM, async_op=True))
+        # message plan: one per head (a head's all-reduce runs under the next head's pass 2), a single head in two halves;
+        # dV in two halves, the first one together with the small gradients
+        self.backward(idx, b, with_loss, on_grad_ready=reduce_piece, p_parts=2 if len(L.ks) == 1 else 1, v_parts=2)
         for w in works:
             w.wait()
         self.adam(lr, 1.0 / world)

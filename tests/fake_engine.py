@@ -39,7 +39,7 @@ class OracleEngine(Engine):
             Q[:, L.qoff[i]: L.qoff[i] + k] = Qs[i]
         self.Q[: b * L.SP] = torch.from_numpy(Q.reshape(-1))
 
-    def backward(self, idx, b, with_loss=True, on_decoder_done=None):
+    def backward(self, idx, b, with_loss=True, on_decoder_done=None, on_mlp_bwd_done=None, on_grad_ready=None, p_parts=1, v_parts=1):
         L, h = self.lay, self.lay.heads
         lab = None if self.labels is None else self.labels.numpy().astype(np.int64)[self._idx]
         loss, g, _ = O.step_grads(self._params(), self.G[self._idx], lab)
@@ -58,6 +58,14 @@ class OracleEngine(Engine):
         if on_decoder_done is not None:
             on_decoder_done()
         self.gsmall.copy_(torch.from_numpy(sm))
+        if on_grad_ready is not None:                   # same message plan as the product: P pieces, then small+V pieces
+            split = self._ns_pad + L.clamp_from
+            mid = split + (L.n_big - L.clamp_from) // 2
+            on_grad_ready(split, mid)
+            on_grad_ready(mid, self._ns_pad + L.n_big)
+            half = self._ns_pad + L.clamp_from // 2
+            on_grad_ready(0, half)
+            on_grad_ready(half, split)
         if with_loss:
             self.loss_acc[0] += loss
             self.loss_acc[1] = loss

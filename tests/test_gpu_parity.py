@@ -250,6 +250,33 @@ def test_two_stream_step_is_bit_identical_to_the_single_stream_step():
         assert np.array_equal(np.asarray(a), np.asarray(c))
 
 
+def test_snp_subrange_launches_give_identical_gradients_and_cover_the_flat_buffer():
+    """The data-parallel step launches passes 2 and 3 on SNP sub-ranges and all-reduces each finished piece of the flat
+    gradient buffer: the pieces must tile gflat exactly once and the gradients must not depend on the split."""
+    rng = np.random.default_rng(2)
+    for M, ks in ((5003, [6]), (9001, [2, 5, 11])):
+        N, Hd = 90, 64
+        Gm = O.synth_genotypes(N, M, 4, seed=M)
+        V0 = (rng.standard_normal((M, 8)) / np.sqrt(M)).astype(np.float32)
+        P0 = rng.uniform(0.02, 0.98, size=(sum(ks), M)).astype(np.float32)
+        p = O.make_params(1, V0, P0, Hd, ks)
+        res = []
+        for parts in ((1, 1), (2, 2), (3, 4)):
+            e = make_engine(Gm, p, N)
+            idx = torch.arange(N, dtype=torch.int32, device=e.device)
+            pieces = []
+            e.forward(idx, N)
+            e.backward(idx, N, True, on_grad_ready=lambda lo, hi: pieces.append((lo, hi)), p_parts=parts[0], v_parts=parts[1])
+            torch.cuda.synchronize()
+            cover = np.zeros(e.gflat.numel(), dtype=np.int32)
+            for lo, hi in pieces:
+                cover[lo:hi] += 1
+            assert cover.min() == 1 and cover.max() == 1
+            res.append((e.gflat.cpu().numpy().copy(), e.read_loss()[1]))
+        for g, l in res[1:]:
+            assert np.array_equal(g, res[0][0]) and l == res[0][1]
+
+
 def test_without_loss_gives_same_gradients():
     Gm = O.synth_genotypes(50, 2100, 4, seed=5)
     rng = np.random.default_rng(1)
