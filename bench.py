@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--hidden", type=int, default=1024)
     ap.add_argument("--no-loss", action="store_true", help="skip the loss value (gradients unchanged); default computes it every step like the reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true", help="single GPU: run the data-parallel step (sub-range launches + RCCL all-reduce on a 1-rank group)")
     ap.add_argument("--cpu-rows", type=int, default=2400, help="rows of the same workload used for the bounded CPU baseline")
     return ap.parse_args()
 
@@ -104,11 +105,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or args.force_ddp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), rank=rank, world_size=world)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     import neural_admixture_amd as na
@@ -131,7 +133,7 @@ def main():
 
     def step(s):
         o = (s % nb) * b
-        if world > 1:
+        if world > 1 or args.force_ddp:
             eng.train_step_ddp(perm[o:o + b], b, lr, world, with_loss)
         else:
             eng.train_step(perm[o:o + b], b, lr, with_loss)
@@ -198,7 +200,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(eng, args, dev)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_ddp:
         dist.destroy_process_group()
 
 

@@ -67,6 +67,7 @@ class Engine:
         # so it is off by default.
         self.overlap = False
         self._side, self._ev = None, None
+        self._n_cu: Optional[int] = None
 
     def _timed(self, name):
         if self.timers is None:
@@ -174,6 +175,22 @@ class Engine:
         cuts = [min(M, (units * i // n_parts) * align) for i in range(n_parts)] + [M]
         return [(cuts[i], cuts[i + 1]) for i in range(n_parts) if cuts[i + 1] > cuts[i]]
 
+    def _round_ranges(self, chunk_snps: int, align: int, blocks_per_cu: int):
+        """Two ranges for one pass-2 launch pair: the first covers the FULL rounds of resident blocks (CUs x blocks per CU),
+        the second the partial last round.  A pass-2 block lives ~100 us, kernels on one stream do not overlap, so cutting
+        anywhere else would add a second under-filled tail; cutting here costs nothing and lets the all-reduce of the
+        first ~3/4 of a P gradient run under the last round."""
+        M = self.lay.M
+        if self._n_cu is None:
+            self._n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 256
+        slots = self._n_cu * blocks_per_cu
+        chunks = (M + chunk_snps - 1) // chunk_snps
+        full = (chunks // slots) * slots
+        m_cut = (full * chunk_snps) // align * align
+        if full == 0 or full == chunks or m_cut <= 0 or m_cut >= M:
+            return [(0, M)]
+        return [(0, m_cut), (m_cut, M)]
+
     def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_decoder_done=None, on_mlp_bwd_done=None,
                  on_grad_ready=None, p_parts: int = 1, v_parts: int = 1) -> None:
         """Decoder + BCE fwd/bwd per head, MLP backward, dV.  Gradients land in gbig / gsmall (views of gflat).
@@ -192,7 +209,7 @@ class Engine:
             kp = L.kp[h]
             csnps = int(lib.nadm_decode_chunk_snps(kp))
             align = csnps * 1024 // math.gcd(csnps, 1024)
-            for m0, m1 in self._snp_ranges(p_parts, align):
+            for m0, m1 in (self._round_ranges(csnps, align, 3 if kp <= 8 else 2) if p_parts == "rounds" else self._snp_ranges(p_parts, align)):
                 c0 = m0 // csnps
                 check(lib.nadm_decode_bce(
                     C.c_void_p(self.xp.data_ptr() + m0 // 4), self.ld, ptr(idx), b, m1 - m0,
@@ -226,14 +243,29 @@ class Engine:
                 on_grad_ready(0 if i == 0 else self._ns_pad + m0 * L.CP, self._ns_pad + m1 * L.CP)
         if ev: ev[1].record()
 
+    def adam_part(self, part: str, lr: float, grad_scale: float = 1.0, stream=None) -> None:
+        """Adam (+ clamp for P) on one part of the parameters -- "P", "V" or "small" -- for the CURRENT step_count."""
+        L, fsz = self.lay, 4
+        st = _stream() if stream is None else stream
+        if part == "P":
+            off = L.clamp_from * fsz
+            check(lib.nadm_adam(C.c_void_p(self.big.data_ptr() + off), C.c_void_p(self.gbig.data_ptr() + off),
+                                C.c_void_p(self.mbig.data_ptr() + off), C.c_void_p(self.vbig.data_ptr() + off),
+                                L.n_big - L.clamp_from, 0, lr, self.step_count, grad_scale, st), "adam(P)")
+        elif part == "V":
+            check(lib.nadm_adam(ptr(self.big), ptr(self.gbig), ptr(self.mbig), ptr(self.vbig), L.clamp_from, L.clamp_from,
+                                lr, self.step_count, grad_scale, st), "adam(V)")
+        else:
+            check(lib.nadm_adam(ptr(self.small), ptr(self.gsmall), ptr(self.msmall), ptr(self.vsmall), L.n_small, L.n_small,
+                                lr, self.step_count, grad_scale, st), "adam(small)")
+
     def adam(self, lr: float, grad_scale: float = 1.0) -> None:
         L, st = self.lay, _stream()
         self.step_count += 1
         ev = self._timed("adam")
         check(lib.nadm_adam(ptr(self.big), ptr(self.gbig), ptr(self.mbig), ptr(self.vbig), L.n_big, L.clamp_from,
                             lr, self.step_count, grad_scale, st), "adam(big)")
-        check(lib.nadm_adam(ptr(self.small), ptr(self.gsmall), ptr(self.msmall), ptr(self.vsmall), L.n_small, L.n_small,
-                            lr, self.step_count, grad_scale, st), "adam(small)")
+        self.adam_part("small", lr, grad_scale)
         if ev: ev[1].record()
 
     def train_step(self, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True) -> None:
@@ -262,23 +294,18 @@ class Engine:
         def after_decoder():                                  # P gradients are final: update P underneath the rest
             ev_dec.record(main)
             side.wait_event(ev_dec)
-            off = L.clamp_from * fsz
-            check(lib.nadm_adam(C.c_void_p(self.big.data_ptr() + off), C.c_void_p(self.gbig.data_ptr() + off),
-                                C.c_void_p(self.mbig.data_ptr() + off), C.c_void_p(self.vbig.data_ptr() + off),
-                                L.n_big - L.clamp_from, 0, lr, self.step_count, 1.0, sst), "adam(P)")
+            self.adam_part("P", lr, 1.0, sst)
 
         def after_mlp_bwd():                                  # dL, dHpre, dgp are final: weight gradients + small Adam
             ev_a.record(main)
             side.wait_event(ev_a)
             check(lib.nadm_mlp_bwd_weights(C.byref(L.heads), b, ptr(self.Zn), ptr(self.H), ptr(self.dL), ptr(self.dHpre), ptr(self.dgp),
                                            ptr(self.small_part), ptr(self.gsmall), sst), "mlp_bwd_weights")
-            check(lib.nadm_adam(ptr(self.small), ptr(self.gsmall), ptr(self.msmall), ptr(self.vsmall), L.n_small, L.n_small,
-                                lr, self.step_count, 1.0, sst), "adam(small)")
+            self.adam_part("small", lr, 1.0, sst)
             ev_side.record(side)
         self.backward(idx, b, with_loss, on_decoder_done=after_decoder, on_mlp_bwd_done=after_mlp_bwd)
         ev = self._timed("adam")
-        check(lib.nadm_adam(ptr(self.big), ptr(self.gbig), ptr(self.mbig), ptr(self.vbig), L.clamp_from, L.clamp_from,
-                            lr, self.step_count, 1.0, _stream()), "adam(V)")
+        self.adam_part("V", lr, 1.0)
         if ev: ev[1].record()
         main.wait_event(ev_side)                              # the next step reads P and the small parameters
 
@@ -286,8 +313,9 @@ class Engine:
         """Sample-sharded data-parallel step: local gradients -> all-reduce(sum) over RCCL -> Adam with
         grad_scale 1/world (DDP's mean, neural_admixture.py:315-319).  Every piece of the flat gradient buffer is
         all-reduced as soon as the kernel that completes it is enqueued, so the messages run underneath the remaining
-        kernels: P of head h under pass 2 of head h+1 (the two halves of a single head under each other), the last P piece
-        under the MLP backward and pass 3, the first half of dV (+ the small gradients) under the second."""
+        kernels: P of head h under pass 2 of head h+1 (a single head: the part computed by the full rounds of blocks
+        under the last round), the last P piece under the MLP backward and pass 3; the small gradients and dV follow as
+        one message after pass 3."""
         import torch.distributed as dist
         L = self.lay
         works = []
@@ -296,12 +324,21 @@ class Engine:
         def reduce_piece(lo, hi):                             # gflat = [small | pad | V | P heads]
             works.append(dist.all_reduce(self.gflat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         self.forward(idx, b)
-        # message plan: one per head (a head's all-reduce runs under the next head's pass 2), a single head in two halves;
-        # dV in two halves, the first one together with the small gradients
-        self.backward(idx, b, with_loss, on_grad_ready=reduce_piece, p_parts=2 if len(L.ks) == 1 else 1, v_parts=2)
-        for w in works:
+        # message plan: one per head (a head's all-reduce runs under the next head's pass 2); a single head is cut where
+        # its last round of blocks starts (_round_ranges); then the small gradients + dV as one message
+        self.backward(idx, b, with_loss, on_grad_ready=reduce_piece, p_parts="rounds" if len(L.ks) == 1 else 1, v_parts=1)
+        # Adam on the P matrices as soon as THEIR messages are in (the small + dV message is the last one on the
+        # communicator, so this update runs underneath it), then the rest
+        scale = 1.0 / world
+        self.step_count += 1
+        for w in works[:-1]:
             w.wait()
-        self.adam(lr, 1.0 / world)
+        ev = self._timed("adam")
+        self.adam_part("P", lr, scale)
+        works[-1].wait()
+        self.adam_part("V", lr, scale)
+        self.adam_part("small", lr, scale)
+        if ev: ev[1].record()
 
     def infer_q(self, idx: torch.Tensor, b: int) -> List[torch.Tensor]:
         """Encoder-only pass (final Q, neural_admixture.py:369-383; src/inference.py:71-77)."""

@@ -72,17 +72,26 @@ class OracleEngine(Engine):
 
     def adam(self, lr, grad_scale=1.0):
         self.step_count += 1
+        for part in ("P", "V", "small"):
+            self.adam_part(part, lr, grad_scale)
+
+    def adam_part(self, part, lr, grad_scale=1.0, stream=None):
         t = self.step_count
         bc1, bc2 = 1.0 - O.BETA1 ** t, 1.0 - O.BETA2 ** t
-        for p_, g_, m_, v_, cf in ((self.big, self.gbig, self.mbig, self.vbig, self.lay.clamp_from),
-                                   (self.small, self.gsmall, self.msmall, self.vsmall, None)):
-            g = g_ * np.float32(grad_scale)
-            m_.add_((g - m_) * np.float32(1.0 - O.BETA1))
-            v_.mul_(np.float32(O.BETA2)).add_(g * g * np.float32(1.0 - O.BETA2))
-            den = v_.sqrt() / np.float32(np.sqrt(bc2)) + np.float32(O.ADAM_EPS)
-            p_.sub_(np.float32(lr / bc1) * (m_ / den))
-            if cf is not None:
-                p_[cf:].clamp_(0.0, 1.0)
+        cf = self.lay.clamp_from
+        if part == "small":
+            p_, g_, m_, v_, clamp = self.small, self.gsmall, self.msmall, self.vsmall, False
+        elif part == "V":
+            p_, g_, m_, v_, clamp = self.big[:cf], self.gbig[:cf], self.mbig[:cf], self.vbig[:cf], False
+        else:
+            p_, g_, m_, v_, clamp = self.big[cf:], self.gbig[cf:], self.mbig[cf:], self.vbig[cf:], True
+        g = g_ * np.float32(grad_scale)
+        m_.add_((g - m_) * np.float32(1.0 - O.BETA1))
+        v_.mul_(np.float32(O.BETA2)).add_(g * g * np.float32(1.0 - O.BETA2))
+        den = v_.sqrt() / np.float32(np.sqrt(bc2)) + np.float32(O.ADAM_EPS)
+        p_.sub_(np.float32(lr / bc1) * (m_ / den))
+        if clamp:
+            p_.clamp_(0.0, 1.0)
 
     def infer_q(self, idx, b):
         self.forward(idx, b)
