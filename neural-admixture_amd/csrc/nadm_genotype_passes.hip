@@ -931,11 +931,6 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
     f32x4 dpacc[NTW];
 #pragma unroll
     for (int t = 0; t < NTW; ++t) dpacc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#ifdef NADM_ABL_DUP_MFMA
-    f32x4 dpacc2[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) dpacc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#endif
     f32x2_t lossacc = {0.f, 0.f};
 
     // ---- X / Q staging (same scheme as the f32 MFMA kernel: unconditional clamped loads, index one tile ahead) ----
@@ -1065,9 +1060,6 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
                             // transposition buffer of this SNP tile: T[t2][hl][sample 16*s2 + n][SNP 4a .. 4a+3]  (row = 16 bf16 = 32 B)
                             *reinterpret_cast<uint2*>(tw + (2 * t2 + 0) * 512 + (16 * s2 + n) * 16 + 4 * a) = make_uint2(hi[t2][0], hi[t2][1]);
                             *reinterpret_cast<uint2*>(tw + (2 * t2 + 1) * 512 + (16 * s2 + n) * 16 + 4 * a) = make_uint2(lo[t2][0], lo[t2][1]);
-#ifdef NADM_BF_SCHED
-                            __builtin_amdgcn_sched_barrier(0);
-#endif
                         }
                         // dQ^T of this sample tile: the lane's 8 dR values (2 tiles x 4 SNPs) are the B operand
                         const bf16x8 bh = as_bf16x8(make_uint4(hi[0][0], hi[0][1], hi[1][0], hi[1][1]));
@@ -1101,14 +1093,6 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
                             dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd3), dpacc[t], 0, 0, 0);
                             dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(qd2), dpacc[t], 0, 0, 0);
                         }
-#ifdef NADM_ABL_DUP_MFMA   // timing experiment only: does extra matrix-pipe work cost wall time?
-                        dpacc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd1), dpacc2[t], 0, 0, 0);
-                        dpacc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd2), dpacc2[t], 0, 0, 0);
-                        dpacc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(qd1), dpacc2[t], 0, 0, 0);
-                        dpacc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(qd2), dpacc2[t], 0, 0, 0);
-                        dpacc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd1), dpacc2[t], 0, 0, 0);
-                        dpacc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd2), dpacc2[t], 0, 0, 0);
-#endif
                     }
                 }
                 // K <= 8: dQ^T rows k (hi part + lo part) and k+8 (mid part) sit 32 lanes apart: fold, lanes a<2 store.
@@ -1156,9 +1140,6 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float v = dpacc[t][r];
-#ifdef NADM_ABL_DUP_MFMA
-            v += 1e-30f * dpacc2[t][r];
-#endif
             if constexpr (!W) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /*row_ror:8*/, 0xf, 0xf, false));
             if (n < KP) s_dp[(int)(snp_of(t, a, r) - snp_blk0) * KP + n] = v;
         }
