@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--hidden", type=int, default=1024)
     ap.add_argument("--no-loss", action="store_true", help="skip the loss value (gradients unchanged); default computes it every step like the reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parallelism", choices=("dp", "snp"), default="dp",
+                    help="dp (default, the reference's scheme): samples sharded, gradient all-reduce; snp: SNPs sharded, every rank "
+                         "processes the global batch of batch*N rows on its M/N SNPs, two small all-reduces per step")
     ap.add_argument("--force-ddp", action="store_true", help="single GPU: run the data-parallel step (sub-range launches + RCCL all-reduce on a 1-rank group)")
     ap.add_argument("--cpu-rows", type=int, default=2400, help="rows of the same workload used for the bounded CPU baseline")
     return ap.parse_args()
@@ -105,7 +108,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or args.force_ddp:
+    if world > 1 or args.force_ddp or args.parallelism == "snp":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -117,23 +120,34 @@ def main():
     from neural_admixture_amd.model import init_encoder_weights
 
     M, K, b = args.snps, args.k, args.batch
-    rows_local = args.rows // world
-    eng = na.Engine(M, 8, args.hidden, [K], dev, b)
-    eng.set_packed(make_dataset(eng, rows_local, rank * rows_local, K, dev))
+    snp = args.parallelism == "snp"
     rng = np.random.default_rng(42)                                     # identical parameters on every rank
     V0 = (0.01 * rng.standard_normal((M, 8))).astype(np.float32)
     P0 = rng.uniform(5e-6, 1 - 5e-6, size=(K, M)).astype(np.float32)
+    if snp:
+        # every rank: ALL rows of its SNP slice (same bytes in HBM per rank as the sample-sharded layout), global batch b*world
+        from neural_admixture_amd.snp_parallel import SnpShardedEngine
+        rows_local, gb = args.rows, b * world
+        eng = SnpShardedEngine(M, 8, args.hidden, [K], dev, gb, rank, world)
+        eng.set_packed(make_dataset(eng, rows_local, 0, K, dev, seed=1234 + 7 * rank))
+        gperm = torch.Generator(device="cpu").manual_seed(1000)         # the same global batches on every rank
+    else:
+        rows_local, gb = args.rows // world, b
+        eng = na.Engine(M, 8, args.hidden, [K], dev, b)
+        eng.set_packed(make_dataset(eng, rows_local, rank * rows_local, K, dev))
+        gperm = torch.Generator(device="cpu").manual_seed(1000 + rank)
     eng.load_params(V0, P0, init_encoder_weights(42, 8, args.hidden, [K]))
     del V0, P0
-    gperm = torch.Generator(device="cpu").manual_seed(1000 + rank)
     perm = torch.randperm(rows_local, generator=gperm).to(torch.int32).to(dev)
-    nb = rows_local // b
+    nb = rows_local // gb
     with_loss = not args.no_loss
     lr = 2e-3
 
     def step(s):
-        o = (s % nb) * b
-        if world > 1 or args.force_ddp:
+        o = (s % nb) * gb
+        if snp:
+            eng.train_step(perm[o:o + gb], gb, lr, with_loss)
+        elif world > 1 or args.force_ddp:
             eng.train_step_ddp(perm[o:o + b], b, lr, world, with_loss)
         else:
             eng.train_step(perm[o:o + b], b, lr, with_loss)
@@ -180,9 +194,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[3]: synthetic {args.rows} samples x {M} SNPs, K={K}, 2-bit packed resident in HBM, "
-                               f"sample-sharded over {world} GPU(s), batch {b}/GPU, hidden {args.hidden}, n_components 8, "
+                               f"{'SNP' if snp else 'sample'}-sharded over {world} GPU(s), batch {b}/GPU, hidden {args.hidden}, n_components 8, "
                                f"loss value {'every step' if with_loss else 'skipped'}",
-                   "global_batch": b * world, "parallelism": f"dp{world}"},
+                   "global_batch": b * world, "parallelism": f"{args.parallelism}{world}"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kms, "alg_bytes_per_launch": alg_bytes,
@@ -200,7 +214,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(eng, args, dev)
         print(json.dumps(out))
-    if world > 1 or args.force_ddp:
+    if world > 1 or args.force_ddp or args.parallelism == "snp":
         dist.destroy_process_group()
 
 

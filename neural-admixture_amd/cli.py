@@ -36,6 +36,8 @@ def parse_train_args(argv):
     p.add_argument("--n_components", type=int, default=8)
     p.add_argument("--num_gpus", type=int, default=1)
     p.add_argument("--threads", type=int, default=1)
+    p.add_argument("--parallelism", choices=("dp", "snp"), default="dp",
+                   help="multi-GPU sharding: dp = samples (the reference's DDP), snp = SNPs (two tiny all-reduces per step)")
     return p.parse_args(argv)
 
 
@@ -62,7 +64,7 @@ def _read(path):
     return data
 
 
-def _train_worker(rank, args, num_gpus, data, V, t0):
+def _train_worker(rank, args, num_gpus, data, V, pops, t0):
     from .train import train
     from .io import save_model, write_outputs
     if num_gpus > 1:                                        # src/utils.py:69-95
@@ -74,7 +76,7 @@ def _train_worker(rank, args, num_gpus, data, V, t0):
     device = torch.device(f"cuda:{rank}")
     K = args.k
     Ps, Qs, model = train(args.epochs, args.batch_size, args.learning_rate, K, args.seed, data, device, num_gpus, args.hidden_size,
-                          master, V, None, args.min_k, args.max_k, args.n_components)
+                          master, V, pops, args.min_k, args.max_k, args.n_components, parallelism=args.parallelism)
     if master:
         save_model(model, args.name, args.save_dir)
         write_outputs(Qs, args.name, K, args.min_k, args.max_k, args.save_dir, Ps)
@@ -94,8 +96,11 @@ def main(argv=None):
     if mode == "train":
         args = parse_train_args(argv[1:])
         assert args.epochs > 0 and args.batch_size > 0 and args.learning_rate > 0 and args.hidden_size > 0 and args.n_components > 0
-        if args.pops_path:
-            raise SystemExit("supervised mode (--pops_path) is not on the accelerated path yet")
+        pops = None
+        if args.pops_path:                                  # src/utils.py:28-33: one population name per line
+            with open(args.pops_path, "r") as fb:
+                pops = [ln.strip() for ln in fb.readlines()]
+            assert args.k is not None, "Supervised mode needs --k (the number of populations in --pops_path)."
         if args.k is not None:
             assert args.k > 1, "Please select K > 1."
             log.info(f"    Running on K = {args.k}.")
@@ -112,9 +117,9 @@ def main(argv=None):
         V = RSVD(data, data.N, data.M, args.n_components, args.seed)
         if num_gpus > 1:
             data.packed.share_memory_()
-            torch.multiprocessing.spawn(_train_worker, args=(args, num_gpus, data, V, t0), nprocs=num_gpus)
+            torch.multiprocessing.spawn(_train_worker, args=(args, num_gpus, data, V, pops, t0), nprocs=num_gpus)
         else:
-            _train_worker(0, args, 1, data, V, t0)
+            _train_worker(0, args, 1, data, V, pops, t0)
         return 0
     args = parse_infer_args(argv[1:])
     from .model import Q_P

@@ -156,16 +156,27 @@ class Engine:
         return self.gbig[L.p_off[h]: L.p_off[h] + L.M * L.kp[h]].view(L.M, L.kp[h])[:, : L.ks[h]]
 
     # ------------------------------------------------------------------ kernels
-    def forward(self, idx: torch.Tensor, b: int) -> None:
-        """idx int32 [b] device row indices into xp.  Fills Z, rinv, Zn, H, Q."""
+    def encode_partial(self, idx: torch.Tensor, b: int) -> None:
+        """Pass 1: per-chunk partial sums of Z = X.V for the batch rows idx (int32 [b], device) into zpart."""
         L, st = self.lay, _stream()
         if b > self.bmax:
             raise RuntimeError("batch larger than the engine was sized for")
         ev = self._timed("encode_fwd")
         check(lib.nadm_encode_fwd(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self.big), L.CP, ptr(self.zpart), st), "encode_fwd")
         if ev: ev[1].record()
-        check(lib.nadm_mlp_fwd(C.byref(L.heads), ptr(self.small), ptr(self.zpart), L.enc_chunks, b, ptr(self.Z), ptr(self.rinv),
+
+    def mlp_forward(self, b: int, z_src: Optional[torch.Tensor] = None, n_chunks: Optional[int] = None) -> None:
+        """RMSNorm + MLP + per-head softmax from partial sums [n_chunks, b, CP] (default: this engine's zpart).  Fills Z,
+        rinv, Zn, H, Q."""
+        L, st = self.lay, _stream()
+        check(lib.nadm_mlp_fwd(C.byref(L.heads), ptr(self.small), ptr(self.zpart if z_src is None else z_src),
+                               L.enc_chunks if n_chunks is None else n_chunks, b, ptr(self.Z), ptr(self.rinv),
                                ptr(self.Zn), ptr(self.H), ptr(self.Q), st), "mlp_fwd")
+
+    def forward(self, idx: torch.Tensor, b: int) -> None:
+        """idx int32 [b] device row indices into xp.  Fills Z, rinv, Zn, H, Q."""
+        self.encode_partial(idx, b)
+        self.mlp_forward(b)
 
     def _snp_ranges(self, n_parts: int, align: int):
         """[m0, m1) ranges covering the M SNPs, boundaries at multiples of ``align``."""
@@ -191,15 +202,10 @@ class Engine:
             return [(0, M)]
         return [(0, m_cut), (m_cut, M)]
 
-    def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_decoder_done=None, on_mlp_bwd_done=None,
-                 on_grad_ready=None, p_parts: int = 1, v_parts: int = 1) -> None:
-        """Decoder + BCE fwd/bwd per head, MLP backward, dV.  Gradients land in gbig / gsmall (views of gflat).
-        ``on_decoder_done`` (optional callable) is invoked after all the dP kernels are enqueued.  With
-        ``on_mlp_bwd_done`` the MLP weight gradients are left to that callback (nadm_mlp_bwd_weights on another stream).
-        ``on_grad_ready(lo, hi)`` is invoked each time a contiguous piece gflat[lo:hi] of the big gradients is final and
-        enqueued; passes 2 and 3 are launched on ``p_parts`` / ``v_parts`` SNP sub-ranges so that the data-parallel step can
-        all-reduce one piece while the next is being computed (each head's P, or the halves of a single head's P; the
-        small gradients travel with the first piece of dV)."""
+    def decode_all(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_grad_ready=None, p_parts=1,
+                   supervised: bool = True) -> int:
+        """Pass 2 for every head (optionally on SNP sub-ranges, see backward) + the supervised term.  Returns the number of
+        loss slots the MLP backward has to add up."""
         L, st = self.lay, _stream()
         dq_offs, _ = L.dq_offsets(b)
         loss_offs = L.loss_offsets()
@@ -222,19 +228,28 @@ class Engine:
                     on_grad_ready(self._ns_pad + L.p_off[h] + m0 * kp, self._ns_pad + L.p_off[h] + m1 * kp)
         if ev: ev[1].record()
         n_loss = L.n_loss
-        if self.labels is not None:
+        if self.labels is not None and supervised:
             check(lib.nadm_supervised_ce(ptr(self.Q), L.SP, L.ks[0], L.kp[0], ptr(self.labels), ptr(idx), b, self.n_classes,
                                          self.sup_weight, ptr(self.dqpart), C.c_void_p(self.losspart.data_ptr() + L.n_loss * fsz),
                                          st), "supervised_ce")
             n_loss += 1
-        if on_decoder_done is not None:
-            on_decoder_done()
-        check(lib.nadm_mlp_bwd(C.byref(L.heads), ptr(self.small), ptr(self.dqpart), L.M, b, ptr(self.Z), ptr(self.rinv), ptr(self.Zn),
+        return n_loss
+
+    def mlp_backward(self, b: int, n_loss: int, dq_src: Optional[torch.Tensor] = None, dq_M: Optional[int] = None,
+                     weights: bool = True) -> None:
+        """MLP / RMSNorm backward from the dQ partial slabs (default: this engine's dqpart over its M SNPs; ``dq_src`` with
+        ``dq_M`` = 1 takes already reduced [b, kp_h] blocks).  n_loss > 0 adds that many loss slots to loss_acc.
+        ``weights=False`` leaves the weight gradients to nadm_mlp_bwd_weights."""
+        L, st = self.lay, _stream()
+        check(lib.nadm_mlp_bwd(C.byref(L.heads), ptr(self.small), ptr(self.dqpart if dq_src is None else dq_src),
+                               L.M if dq_M is None else dq_M, b, ptr(self.Z), ptr(self.rinv), ptr(self.Zn),
                                ptr(self.H), ptr(self.Q), ptr(self.dL), ptr(self.dHpre), ptr(self.dgp), ptr(self.small_part),
-                               ptr(self.dZ), ptr(self.gsmall) if on_mlp_bwd_done is None else None, ptr(self.losspart),
-                               n_loss if with_loss else 0, ptr(self.loss_acc), st), "mlp_bwd")
-        if on_mlp_bwd_done is not None:
-            on_mlp_bwd_done()
+                               ptr(self.dZ), ptr(self.gsmall) if weights else None, ptr(self.losspart),
+                               n_loss, ptr(self.loss_acc), st), "mlp_bwd")
+
+    def encode_backward(self, idx: torch.Tensor, b: int, on_grad_ready=None, v_parts: int = 1) -> None:
+        """Pass 3: dV = X^T.dZ (optionally on SNP sub-ranges)."""
+        L, st, fsz = self.lay, _stream(), 4
         ev = self._timed("encode_bwd")
         for i, (m0, m1) in enumerate(self._snp_ranges(v_parts, 1024)):
             check(lib.nadm_encode_bwd(C.c_void_p(self.xp.data_ptr() + m0 // 4), self.ld, ptr(idx), b, m1 - m0, ptr(self.dZ), L.CP,
@@ -242,6 +257,23 @@ class Engine:
             if on_grad_ready is not None:                     # the first piece carries the small gradients in front of it
                 on_grad_ready(0 if i == 0 else self._ns_pad + m0 * L.CP, self._ns_pad + m1 * L.CP)
         if ev: ev[1].record()
+
+    def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_decoder_done=None, on_mlp_bwd_done=None,
+                 on_grad_ready=None, p_parts=1, v_parts: int = 1) -> None:
+        """Decoder + BCE fwd/bwd per head, MLP backward, dV.  Gradients land in gbig / gsmall (views of gflat).
+        ``on_decoder_done`` (optional callable) is invoked after all the dP kernels are enqueued.  With
+        ``on_mlp_bwd_done`` the MLP weight gradients are left to that callback (nadm_mlp_bwd_weights on another stream).
+        ``on_grad_ready(lo, hi)`` is invoked each time a contiguous piece gflat[lo:hi] of the big gradients is final and
+        enqueued; passes 2 and 3 are launched on ``p_parts`` / ``v_parts`` SNP sub-ranges so that the data-parallel step can
+        all-reduce one piece while the next is being computed (each head's P, or the two parts of a single head's P; the
+        small gradients travel with the first piece of dV)."""
+        n_loss = self.decode_all(idx, b, with_loss, on_grad_ready, p_parts)
+        if on_decoder_done is not None:
+            on_decoder_done()
+        self.mlp_backward(b, n_loss if with_loss else 0, weights=on_mlp_bwd_done is None)
+        if on_mlp_bwd_done is not None:
+            on_mlp_bwd_done()
+        self.encode_backward(idx, b, on_grad_ready, v_parts)
 
     def adam_part(self, part: str, lr: float, grad_scale: float = 1.0, stream=None) -> None:
         """Adam (+ clamp for P) on one part of the parameters -- "P", "V" or "small" -- for the CURRENT step_count."""

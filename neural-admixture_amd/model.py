@@ -41,10 +41,11 @@ class Q_P:
     """Parameter container / inference facade.  Not an nn.Module: the math lives in the HIP kernels."""
 
     def __init__(self, hidden_size: int, num_features: int, V: Optional[torch.Tensor] = None, P: Optional[torch.Tensor] = None,
-                 ks_list: List[int] = [], is_train: bool = True, engine: Optional[Engine] = None):
+                 ks_list: List[int] = [], is_train: bool = True, engine: Optional[Engine] = None, full_params: Optional[dict] = None):
         self.hidden_size, self.num_features = int(hidden_size), int(num_features)
         self.ks_list = [int(k) for k in ks_list]
         self.engine = engine
+        self.full_params = full_params       # SNP-sharded runs: {"V": [M,C], "P": [[M,k] ...]} gathered on the master
         self._pending = None
         if engine is None and V is not None:
             self._pending = {"V": V}
@@ -55,7 +56,8 @@ class Q_P:
         sm = e.small.detach().cpu()
         h = L.heads
         sd = OrderedDict()
-        sd["V"] = e.V().detach().cpu().contiguous()
+        fp = self.full_params
+        sd["V"] = (fp["V"] if fp else e.V()).detach().cpu().contiguous()
         sd["batch_norm.weight"] = sm[h.g_off: h.g_off + L.C].clone()
         sd["common_encoder.0.weight"] = sm[h.w1_off: h.w1_off + L.Hd * L.C].view(L.Hd, L.C).clone()
         sd["common_encoder.0.bias"] = sm[h.b1_off: h.b1_off + L.Hd].clone()
@@ -63,7 +65,7 @@ class Q_P:
             sd[f"multihead_encoder.heads.{i}.weight"] = sm[h.wk_off[i]: h.wk_off[i] + k * L.Hd].view(k, L.Hd).clone()
             sd[f"multihead_encoder.heads.{i}.bias"] = sm[h.bk_off[i]: h.bk_off[i] + k].clone()
         for i in range(len(L.ks)):
-            sd[f"decoders.decoders.{i}.weight"] = e.P(i).detach().cpu().contiguous()
+            sd[f"decoders.decoders.{i}.weight"] = (fp["P"][i] if fp else e.P(i)).detach().cpu().contiguous()
         return sd
 
     def load_state_dict(self, sd, device: Optional[torch.device] = None, max_batch: int = 1024):
@@ -117,9 +119,10 @@ def hudsons_fst(p1: torch.Tensor, p2: torch.Tensor) -> float:
 class NeuralAdmixture:
     """Trainer mirror (constructor signature of neural_admixture.py:248-249)."""
     engine_cls = Engine          # tests swap in an oracle-backed double to run the DDP orchestration on gloo
+    engine_snp_cls = None        # set below (import cycle): snp_parallel.SnpShardedEngine
 
     def __init__(self, k, epochs, batch_size, learning_rate, device, seed, num_gpus, master, pack2bit=None,
-                 min_k=None, max_k=None, supervised_loss_weight=100, loss_mode: str = "logged"):
+                 min_k=None, max_k=None, supervised_loss_weight=100, loss_mode: str = "logged", parallelism: str = "dp"):
         self.k, self.min_k, self.max_k = k, min_k, max_k
         self.ks_list = [int(k)] if k is not None else list(range(int(min_k), int(max_k) + 1))
         self.num_gpus, self.device, self.master, self.seed = num_gpus, device, master, int(seed)
@@ -128,8 +131,12 @@ class NeuralAdmixture:
         self.batch_size = int(batch_size) // num_gpus if num_gpus > 0 else int(batch_size)   # :287
         self.lr = float(learning_rate)
         self.supervised_loss_weight = float(supervised_loss_weight)
+        if parallelism not in ("dp", "snp"):
+            raise ValueError("parallelism must be 'dp' (samples sharded, gradient all-reduce) or 'snp' (SNPs sharded)")
+        self.parallelism = parallelism
         self.loss_mode = loss_mode       # "logged": loss only on epochs that print it (:416); "always": every step
         self.epoch_losses: dict = {}
+        self.logliks: Optional[list] = None   # filled by the SNP-sharded run (computed where the SNP slices live)
 
     # ---- batch order (src/loaders.py:8-35; sampler objects are torch's own) ----
     def _world(self):
@@ -147,6 +154,8 @@ class NeuralAdmixture:
         dev = self.device
         C = int(num_features)
         infer_b = min(N, 1024)
+        if self.parallelism == "snp" and world > 1:
+            return self._launch_training_snp(P, data, hidden_size, C, V, M, N, pops, world, rank)
         eng = self.engine_cls(M, C, hidden_size, self.ks_list, dev, max(self.batch_size, infer_b))
         self.engine = eng
         small = init_encoder_weights(self.seed, C, hidden_size, self.ks_list)
@@ -227,12 +236,78 @@ class NeuralAdmixture:
             Ps, Qs = [], []
         return Qs, Ps, self.raw_model
 
-    def display_divergences(self) -> None:
+    def _launch_training_snp(self, P, data, hidden_size, C, V, M, N, pops, world, rank):
+        """SNP-sharded run (snp_parallel.SnpShardedEngine): every rank holds all samples of its SNP slice and processes
+        the GLOBAL batch -- the union of the per-rank batches the reference's DistributedSampler would hand out
+        (src/loaders.py:25-27), in rank order -- so the trajectory is the sample-sharded one up to summation order."""
+        import torch.distributed as dist
+        from torch.utils.data.distributed import DistributedSampler
+        from .snp_parallel import SnpShardedEngine
+        dev = self.device
+        infer_b = min(N, 1024)
+        b_local = self.batch_size                                  # batch_size // num_gpus (:287)
+        eng = self.engine_snp_cls(M, C, hidden_size, self.ks_list, dev, max(b_local * world, infer_b), rank, world)
+        self.engine = eng
+        small = init_encoder_weights(self.seed, C, hidden_size, self.ks_list)
+        eng.load_params(V.detach().cpu().numpy(), P.detach().cpu().numpy(), small)
+        eng.pack_from_host(data)
+        shards = [np.asarray(list(iter(DistributedSampler(range(N), num_replicas=world, rank=r, shuffle=True, seed=self.seed))), dtype=np.int32)
+                  for r in range(world)]
+        n_local = len(shards[0])
+        steps = []
+        for s in range(0, n_local, b_local):
+            steps.append(torch.as_tensor(np.concatenate([sh[s:s + b_local] for sh in shards])).to(dev))
+        if pops is not None:
+            eng.set_labels(torch.as_tensor(pops).detach().cpu().numpy().astype(np.int64), self.ks_list[0], self.supervised_loss_weight)
+        log_every = 5 if pops is None else 2
+        if self.master:
+            log.info("")
+            log.info("    Starting training (SNP-sharded)...")
+            log.info("")
+        for epoch in range(self.epochs):
+            logged = (epoch % log_every == 0)
+            with_loss = logged or self.loss_mode == "always"
+            for idx in steps:                                       # set_epoch is never called: the same batches every epoch
+                eng.train_step(idx, int(idx.numel()), self.lr, with_loss)
+            if with_loss:
+                loss_acc, _ = eng.read_loss(reset=True)             # collective: every rank calls it
+                self.epoch_losses[epoch] = loss_acc
+                if logged and self.master:                          # the global batch's loss (the reference's master prints its shard's)
+                    log.info(f"            Loss in epoch {epoch:3d} on device {dev} is {loss_acc:,.0f}")
+        seq = torch.arange(N, dtype=torch.int32, device=dev)
+        Qloc = [[] for _ in self.ks_list]
+        for s in range(0, N, infer_b):
+            bb = min(infer_b, N - s)
+            for h, q in enumerate(eng.infer_q(seq[s:s + bb], bb)):
+                Qloc[h].append(q)
+        Qs = [torch.cat(q, dim=0) for q in Qloc]                    # replicated: every rank has every row
+        # log-likelihood report (train.py:134-146): every rank sums over its SNPs, one all-reduce of the doubles
+        ll = torch.zeros(len(self.ks_list), dtype=torch.float64, device=dev)
+        if dev.type == "cuda" and max(self.ks_list) <= 16:
+            from .report import loglikelihood_hip
+            for h in range(len(self.ks_list)):
+                ll[h] = loglikelihood_hip(eng.xp, eng.M, eng.P(h).detach().cpu().numpy(), Qs[h].cpu().numpy())
+            dist.all_reduce(ll)
+            self.logliks = [float(v) for v in ll.cpu()]
+        Pfull = [eng.gather_rows(eng.P(h)) for h in range(len(self.ks_list))]
+        Vfull = eng.gather_rows(eng.V())
+        if self.master:
+            log.info("")
+            log.info("    Training finished!")
+            log.info("")
+        self.raw_model = Q_P(hidden_size, C, ks_list=self.ks_list, engine=eng,
+                             full_params={"V": Vfull, "P": Pfull} if self.master else None)
+        self.display_divergences(Pfull if self.master else None)
+        if self.master:
+            return [q.cpu().numpy() for q in Qs], [p_.detach().cpu().numpy().copy() for p_ in Pfull], self.raw_model
+        return [], [], self.raw_model
+
+    def display_divergences(self, P_full=None) -> None:
         """Pairwise Hudson Fst between estimated populations (neural_admixture.py:476-509)."""
         if not self.master:
             return
         for i, k in enumerate(self.ks_list):
-            dec = self.engine.P(i)
+            dec = P_full[i] if P_full is not None else self.engine.P(i)
             header = '\t'.join([f'Pop{p}' for p in range(k - 1)])
             log.info("    Results:")
             log.info(f'\n            Fst divergences between estimated populations: (K = {k})')
@@ -245,3 +320,8 @@ class NeuralAdmixture:
                     out += f"\t{hudsons_fst(dec[:, l], dec[:, j]):0.3f}"
                 log.info(out)
             log.info("\n")
+
+
+from .snp_parallel import SnpShardedEngine as _SnpShardedEngine  # noqa: E402
+
+NeuralAdmixture.engine_snp_cls = _SnpShardedEngine

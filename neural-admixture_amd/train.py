@@ -91,10 +91,13 @@ def supervised_init(data_np, pops, K: int):
 
 def train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int, data: torch.Tensor, device: torch.device,
           num_gpus: int, hidden_size: int, master: bool, V: np.ndarray, pops, min_k: int = None, max_k: int = None,
-          n_components: int = None):
+          n_components: int = None, *, parallelism: str = "dp"):
     """See module docstring.  ``data`` uint8 [N,M] CPU tensor (or an ``io.PackedGenotypes``, e.g. from
     ``io.read_bed_packed``); ``V`` numpy [C,M] (RSVD output,
-    svd.py:83); returns Ps (list of [M,k] float32), Qs (list of [N,k] float32), model."""
+    svd.py:83); returns Ps (list of [M,k] float32), Qs (list of [N,k] float32), model.
+    ``parallelism`` (keyword, not in the reference): "dp" = samples sharded over the GPUs with a gradient all-reduce, as the
+    reference does; "snp" = SNPs sharded (snp_parallel.py): same trajectory up to summation order, two tiny all-reduces
+    per step instead of the 4*M*(C+S)-byte one."""
     if device.type != "cuda":
         raise RuntimeError("neural_admixture_amd.train requires a ROCm GPU device; the CPU path is the reference's own")
     N, M = data.shape
@@ -139,13 +142,14 @@ def train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int,
         if pops is not None:
             pops = torch.as_tensor(y_num, dtype=torch.int64)
 
-    model = NeuralAdmixture(K, epochs, batch_size, learning_rate, device, seed, num_gpus, master, None, min_k, max_k)
+    model = NeuralAdmixture(K, epochs, batch_size, learning_rate, device, seed, num_gpus, master, None, min_k, max_k,
+                            parallelism=parallelism)
     Qs, Ps, raw = model.launch_training(P_init, data, hidden_size, Vt.shape[1], Vt, M, N, pops)
 
     if master:
         ks = [K] if K is not None else list(range(min_k, max_k + 1))
         for i, k in enumerate(ks):
-            logl = loglikelihood_packed(model.engine, data, Ps[i], Qs[i])
+            logl = model.logliks[i] if model.logliks is not None else loglikelihood_packed(model.engine, data, Ps[i], Qs[i])
             if K is not None:
                 log.info(f"    Log-likelihood: {logl:2f}.")
             else:

@@ -196,16 +196,22 @@ def softmax_rows(L: np.ndarray) -> np.ndarray:
     return (e / e.sum(axis=1, keepdims=True, dtype=F32)).astype(F32)
 
 
-def encoder_forward(p: Params, X: np.ndarray):
-    """X [b,M] -> (Z, rinv, Zn, H, [Q_h]).  neural_admixture.py:172-176."""
-    C = p.V.shape[1]
-    Z = (X @ p.V).astype(F32)
+def mlp_forward(p: Params, Z: np.ndarray):
+    """Z [b,C] -> (rinv, Zn, H, [Q_h]): RMSNorm, Linear+ReLU, per-head Linear+softmax (neural_admixture.py:173-176)."""
+    C = Z.shape[1]
     ms = (Z * Z).sum(axis=1, dtype=F32) / F32(C)
     rinv = (F32(1) / np.sqrt(ms + F32(RMS_EPS), dtype=F32)).astype(F32)
     Zn = (Z * rinv[:, None] * p.g[None, :]).astype(F32)
     Hpre = (Zn @ p.W1.T + p.b1[None, :]).astype(F32)
     H = np.maximum(Hpre, F32(0))
     Qs = [softmax_rows((H @ p.Wk[h].T + p.bk[h][None, :]).astype(F32)) for h in range(len(p.ks))]
+    return rinv, Zn, H, Qs
+
+
+def encoder_forward(p: Params, X: np.ndarray):
+    """X [b,M] -> (Z, rinv, Zn, H, [Q_h]).  neural_admixture.py:172-176."""
+    Z = (X @ p.V).astype(F32)
+    rinv, Zn, H, Qs = mlp_forward(p, Z)
     return Z, rinv, Zn, H, Qs
 
 
@@ -234,40 +240,39 @@ def labels_from_pops(pops) -> np.ndarray:
     return np.asarray([lut[a] for a in pops], dtype=np.int64)
 
 
-def step_grads(p: Params, G: np.ndarray, labels: Optional[np.ndarray] = None):
-    """One forward+backward on batch G uint8 [b,M].  With ``labels`` (int [b]) the supervised term
-    100 * CrossEntropyLoss(sum)(Q_0, labels) is added -- applied to the softmax OUTPUT of head 0 as if it were
-    logits (neural_admixture.py:470-473: out[1][0] is probs[0]).  Returns (loss, grads dict keyed like
-    Params.tensors(), aux dict with Z/Q).  Closed form of the autograd graph of
-    neural_admixture.py:157-177 + :94-97 (clamp, mask on the pre-clamp value, inclusive bounds)
-    + BCE backward (r-x)/max(r(1-r),1e-12)."""
-    X = decode_x(G)
-    Z, rinv, Zn, H, Qs = encoder_forward(p, X)
-    C = p.V.shape[1]
-    loss = 0.0
+def decoder_grads(Q: np.ndarray, P: np.ndarray, X: np.ndarray):
+    """One head: (loss, dP [M,k], dQ [b,k]) of BCE(sum)(clamp(Q.P^T, 0, 1), X) -- neural_admixture.py:94-97 (clamp, gradient
+    mask on the pre-clamp value with inclusive bounds) + BCE backward (r-x)/max(r(1-r),1e-12)."""
+    Rraw = (Q @ P.T).astype(F32)
+    R = np.clip(Rraw, F32(0), F32(1))
+    loss = bce_sum(R, X)
+    den = np.maximum((F32(1) - R) * R, BCE_EPS)
+    dR = ((R - X) / den).astype(F32)
+    dR[(Rraw < 0) | (Rraw > 1)] = 0
+    return loss, (dR.T @ Q).astype(F32), (dR @ P).astype(F32)
+
+
+def supervised_term(Q: np.ndarray, labels: np.ndarray):
+    """(loss, dQ contribution) of 100 * CrossEntropyLoss(sum)(Q, labels) with Q -- the softmax OUTPUT -- used as logits
+    (neural_admixture.py:470-473): loss = sum_i logsumexp(q_i) - q_i[y_i]; d/dq = softmax(q_i) - onehot."""
+    qm = Q.max(axis=1, keepdims=True)
+    e = np.exp(Q - qm, dtype=F32)
+    se = e.sum(axis=1, keepdims=True, dtype=F32)
+    lse = (qm + np.log(se, dtype=F32))[:, 0]
+    rows = np.arange(Q.shape[0])
+    loss = SUPERVISED_WEIGHT * float((lse.astype(np.float64) - Q[rows, labels].astype(np.float64)).sum())
+    gce = (e / se).astype(F32)
+    gce[rows, labels] -= F32(1)
+    return loss, (F32(SUPERVISED_WEIGHT) * gce).astype(F32)
+
+
+def mlp_backward(p: Params, Z: np.ndarray, rinv: np.ndarray, Zn: np.ndarray, H: np.ndarray, Qs, dQs):
+    """Backward of mlp_forward given dL/dQ_h: returns (grads of g, W1, b1, Wk_h, bk_h; dZ [b,C])."""
+    C = Z.shape[1]
     dH = np.zeros_like(H)
     grads: Dict[str, np.ndarray] = {}
     for h in range(len(p.ks)):
-        Q, P = Qs[h], p.P[h]
-        Rraw = (Q @ P.T).astype(F32)
-        R = np.clip(Rraw, F32(0), F32(1))
-        loss += bce_sum(R, X)
-        den = np.maximum((F32(1) - R) * R, BCE_EPS)
-        dR = ((R - X) / den).astype(F32)
-        dR[(Rraw < 0) | (Rraw > 1)] = 0
-        grads[f"P{h}"] = (dR.T @ Q).astype(F32)
-        dQ = (dR @ P).astype(F32)
-        if labels is not None and h == 0:
-            # CE(sum) on q as logits: loss = sum_i logsumexp(q_i) - q_i[y_i]; d/dq = softmax(q_i) - onehot
-            qm = Q.max(axis=1, keepdims=True)
-            e = np.exp(Q - qm, dtype=F32)
-            se = e.sum(axis=1, keepdims=True, dtype=F32)
-            lse = (qm + np.log(se, dtype=F32))[:, 0]
-            rows = np.arange(Q.shape[0])
-            loss += SUPERVISED_WEIGHT * float((lse.astype(np.float64) - Q[rows, labels].astype(np.float64)).sum())
-            gce = (e / se).astype(F32)
-            gce[rows, labels] -= F32(1)
-            dQ = (dQ + F32(SUPERVISED_WEIGHT) * gce).astype(F32)
+        Q, dQ = Qs[h], dQs[h]
         dL = (Q * (dQ - (dQ * Q).sum(axis=1, keepdims=True, dtype=F32))).astype(F32)
         grads[f"Wk{h}"] = (dL.T @ H).astype(F32)
         grads[f"bk{h}"] = dL.sum(axis=0, dtype=F32)
@@ -279,6 +284,32 @@ def step_grads(p: Params, G: np.ndarray, labels: Optional[np.ndarray] = None):
     t = dZn * p.g[None, :]
     grads["g"] = (dZn * Z * rinv[:, None]).sum(axis=0, dtype=F32)
     dZ = (rinv[:, None] * t - Z * (rinv ** 3)[:, None] * ((t * Z).sum(axis=1, keepdims=True, dtype=F32) / F32(C))).astype(F32)
+    return grads, dZ
+
+
+def step_grads(p: Params, G: np.ndarray, labels: Optional[np.ndarray] = None):
+    """One forward+backward on batch G uint8 [b,M].  With ``labels`` (int [b]) the supervised term
+    100 * CrossEntropyLoss(sum)(Q_0, labels) is added -- applied to the softmax OUTPUT of head 0 as if it were
+    logits (neural_admixture.py:470-473: out[1][0] is probs[0]).  Returns (loss, grads dict keyed like
+    Params.tensors(), aux dict with Z/Q).  Closed form of the autograd graph of
+    neural_admixture.py:157-177 + :94-97 (clamp, mask on the pre-clamp value, inclusive bounds)
+    + BCE backward (r-x)/max(r(1-r),1e-12)."""
+    X = decode_x(G)
+    Z, rinv, Zn, H, Qs = encoder_forward(p, X)
+    loss = 0.0
+    grads: Dict[str, np.ndarray] = {}
+    dQs = []
+    for h in range(len(p.ks)):
+        l, dP, dQ = decoder_grads(Qs[h], p.P[h], X)
+        loss += l
+        grads[f"P{h}"] = dP
+        if labels is not None and h == 0:
+            ls, dq_sup = supervised_term(Qs[h], labels)
+            loss += ls
+            dQ = (dQ + dq_sup).astype(F32)
+        dQs.append(dQ)
+    g_small, dZ = mlp_backward(p, Z, rinv, Zn, H, Qs, dQs)
+    grads.update(g_small)
     grads["V"] = (X.T @ dZ).astype(F32)
     aux = {"Z": Z, "Qs": Qs, "dZ": dZ, "H": H, "Zn": Zn}
     return loss, grads, aux

@@ -114,9 +114,12 @@ def test_initial_weights_match_reference_rng_stream():
 
 def test_train_signature_matches_reference():
     import neural_admixture_amd as na
-    names = list(inspect.signature(na.train).parameters)
-    assert names == ["epochs", "batch_size", "learning_rate", "K", "seed", "data", "device", "num_gpus", "hidden_size",
-                     "master", "V", "pops", "min_k", "max_k", "n_components"]          # train.py:19-21
+    params = inspect.signature(na.train).parameters
+    names = list(params)
+    assert names[:15] == ["epochs", "batch_size", "learning_rate", "K", "seed", "data", "device", "num_gpus", "hidden_size",
+                          "master", "V", "pops", "min_k", "max_k", "n_components"]     # train.py:19-21
+    for extra in names[15:]:                                # additions must be keyword-only with a default
+        assert params[extra].kind is inspect.Parameter.KEYWORD_ONLY and params[extra].default is not inspect.Parameter.empty
     names = list(inspect.signature(na.NeuralAdmixture.__init__).parameters)[1:13]
     assert names == ["k", "epochs", "batch_size", "learning_rate", "device", "seed", "num_gpus", "master", "pack2bit",
                      "min_k", "max_k", "supervised_loss_weight"]                        # neural_admixture.py:248-249

@@ -277,6 +277,86 @@ def test_snp_subrange_launches_give_identical_gradients_and_cover_the_flat_buffe
             assert np.array_equal(g, res[0][0]) and l == res[0][1]
 
 
+def test_snp_sharded_engine_on_gpu():
+    """snp_parallel.SnpShardedEngine with the real kernels: (1) a 1-rank RCCL group must reproduce the plain engine (same
+    kernels, Z and dQ summed by torch instead of inside the MLP kernels -> 1e-6); (2) two slices of one matrix driven stage
+    by stage on one GPU, with the two all-reduces done by hand, must reproduce it as well (slicing of packed columns,
+    of V / P, kernels on a slice whose length is not a multiple of any chunk)."""
+    import torch.distributed as dist
+    from neural_admixture_amd.snp_parallel import SnpShardedEngine, snp_slices
+    from neural_admixture_amd.model import init_encoder_weights
+    dev = _dev()
+    rng = np.random.default_rng(31)
+    N, M, ks, Hd, b = 200, 9001, [3, 7], 64, 150
+    Gm = O.synth_genotypes(N, M, 4, seed=8, missing=0.03)
+    V0 = (rng.standard_normal((M, 8)) / np.sqrt(M)).astype(np.float32)
+    P0 = rng.uniform(0.02, 0.98, size=(sum(ks), M)).astype(np.float32)
+    small = init_encoder_weights(4, 8, Hd, ks)
+    p = O.make_params(4, V0, P0, Hd, ks)
+    data = torch.from_numpy(Gm)
+    idx = torch.from_numpy(rng.permutation(N)[:b].astype(np.int32)).to(dev)
+
+    ref = make_engine(Gm, p, b)
+    for _ in range(3):
+        ref.train_step(idx, b, 2e-3, True)
+    torch.cuda.synchronize()
+    ref_loss = ref.read_loss()[0]
+
+    # (1) world 1, real process group
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(29700 + os.getpid() % 200)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        e1 = SnpShardedEngine(M, 8, Hd, ks, dev, b, 0, 1)
+        e1.load_params(V0, P0, small)
+        e1.pack_from_host(data)
+        for _ in range(3):
+            e1.train_step(idx, b, 2e-3, True)
+        torch.cuda.synchronize()
+        assert mx(e1.big.cpu().numpy(), ref.big.cpu().numpy()) < 2e-6 and mx(e1.small.cpu().numpy(), ref.small.cpu().numpy()) < 2e-6
+        assert abs(e1.read_loss()[0] - ref_loss) < 1e-6 * abs(ref_loss)
+    finally:
+        dist.destroy_process_group()
+
+    # (2) two slices, stages driven by hand (no process group: _all_reduce is a no-op at world... so sum explicitly)
+    sl = snp_slices(M, 2)
+    assert sl[0][1] == sl[1][0] and sl[1][1] == M and (sl[0][1] - sl[0][0]) % 4 == 0
+    es = []
+    for r in range(2):
+        e = SnpShardedEngine(M, 8, Hd, ks, dev, b, r, 2)
+        e.load_params(V0, P0, small)
+        e.pack_from_host(data)
+        es.append(e)
+    L = es[0].lay
+    for _ in range(3):
+        zs = []
+        for e in es:
+            e.encode_partial(idx, b)
+            zs.append(e.zpart[: e.lay.enc_chunks * b * L.CP].view(e.lay.enc_chunks, b * L.CP).sum(0))
+        zsum = (zs[0] + zs[1]).contiguous()
+        dqs = []
+        for r, e in enumerate(es):
+            e.mlp_forward(b, zsum, 1)
+            n_loss = e.decode_all(idx, b, True, supervised=(r == 0))
+            offs, _ = e.lay.dq_offsets(b)
+            dqs.append(torch.cat([e.dqpart[offs[h]: offs[h] + e.lay.dec_chunks[h] * b * kp].view(e.lay.dec_chunks[h], b * kp).sum(0)
+                                  for h, kp in enumerate(L.kp)]))
+            e._n_loss = n_loss
+        dqsum = (dqs[0] + dqs[1]).contiguous()
+        for e in es:
+            e.mlp_backward(b, e._n_loss, dq_src=dqsum, dq_M=1)
+            e.encode_backward(idx, b)
+            e.adam(2e-3, 1.0)
+    torch.cuda.synchronize()
+    got_V = np.concatenate([e.V().cpu().numpy() for e in es], axis=0)
+    assert mx(got_V, ref.V().cpu().numpy()) < 2e-6
+    for h in range(len(ks)):
+        assert mx(np.concatenate([e.P(h).cpu().numpy() for e in es], axis=0), ref.P(h).cpu().numpy()) < 2e-6
+    assert mx(es[0].small.cpu().numpy(), ref.small.cpu().numpy()) < 2e-6 and np.array_equal(es[0].small.cpu().numpy(), es[1].small.cpu().numpy())
+    tot = sum(float(e.loss_acc.cpu()[0]) for e in es)
+    assert abs(tot - ref_loss) < 1e-6 * abs(ref_loss)
+
+
 def test_without_loss_gives_same_gradients():
     Gm = O.synth_genotypes(50, 2100, 4, seed=5)
     rng = np.random.default_rng(1)
