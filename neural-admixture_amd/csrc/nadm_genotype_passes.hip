@@ -794,6 +794,15 @@ __device__ __forceinline__ void split3(float v, uint32_t& h, uint32_t& m, uint32
     const float r2 = r1 - __uint_as_float(m << 16);
     l = pk_bf16(r2, 0.f) & 0xFFFFu;
 }
+// the same for TWO values at once: one v_cvt_pk_bf16_f32 per piece serves both, and the three results are already the
+// packed (v0 | v1 << 16) dwords the MFMA operands are built from -- half the instructions of two split3 calls
+__device__ __forceinline__ void split3_pair(float v0, float v1, uint32_t& H, uint32_t& Md, uint32_t& Lo) {
+    H = pk_bf16(v0, v1);
+    const f32x2_t r1 = (f32x2_t){v0, v1} - (f32x2_t){__uint_as_float(H << 16), __uint_as_float(H & 0xFFFF0000u)};
+    Md = pk_bf16(r1.x, r1.y);
+    const f32x2_t r2 = r1 - (f32x2_t){__uint_as_float(Md << 16), __uint_as_float(Md & 0xFFFF0000u)};
+    Lo = pk_bf16(r2.x, r2.y);
+}
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 // Two genotypes at a time with packed f32 math.  On gfx950 every VALU instruction costs ~4.5 cycles per wave
@@ -884,15 +893,16 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
     for (int t = 0; t < NTW; ++t) {
         const int64_t m = snp_of(t, n >> 2, n & 3);
         const int k0 = W ? 8 * (a & 1) : 0;               // W: slots alternate k 0..7 / 8..15
-        uint32_t h[8], md[8], lo[8];
+        uint32_t h[4], md[4], lo[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float v = (m < M && k0 + k < KP) ? P[m * KP + k0 + k] : 0.f;
-            split3(v, h[k], md[k], lo[k]);
+        for (int k = 0; k < 8; k += 2) {
+            const float v0 = (m < M && k0 + k < KP) ? P[m * KP + k0 + k] : 0.f;
+            const float v1 = (m < M && k0 + k + 1 < KP) ? P[m * KP + k0 + k + 1] : 0.f;
+            split3_pair(v0, v1, h[k >> 1], md[k >> 1], lo[k >> 1]);
         }
-        const uint4 H = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-        const uint4 Md = make_uint4(md[0] | (md[1] << 16), md[2] | (md[3] << 16), md[4] | (md[5] << 16), md[6] | (md[7] << 16));
-        const uint4 Lo = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+        const uint4 H = make_uint4(h[0], h[1], h[2], h[3]);
+        const uint4 Md = make_uint4(md[0], md[1], md[2], md[3]);
+        const uint4 Lo = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         // lane-group dependent choice of the piece, written as mask blends: a ?: on whole uint4 values is turned into a
         // table in scratch memory indexed by the lane group (64 B of scratch stores + loads per tile and thread)
         const uint32_t m01 = a < 2 ? 0xFFFFFFFFu : 0u, m0 = a == 0 ? 0xFFFFFFFFu : 0u, m1 = a == 1 ? 0xFFFFFFFFu : 0u;
@@ -913,20 +923,21 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
     uint4 pa_q1[NTW / 2], pa_q2[NTW / 2], pa_q3[W ? NTW / 2 : 1];
 #pragma unroll
     for (int tp = 0; tp < NTW / 2; ++tp) {
-        uint32_t w1[8], w2[8], w3[8];
+        uint32_t w1[4], w2[4], w3[4];
+        const int kq = W ? n : (n & 7);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int64_t m = snp_of(2 * tp + (e >> 2), a, e & 3);
-            const int k = W ? n : (n & 7);
-            const float v = (m < M && k < KP) ? P[m * KP + k] : 0.f;
+        for (int e = 0; e < 8; e += 2) {
+            const int64_t m0 = snp_of(2 * tp + (e >> 2), a, e & 3), m1 = snp_of(2 * tp + (e >> 2), a, (e & 3) + 1);
+            const float v0 = (m0 < M && kq < KP) ? P[m0 * KP + kq] : 0.f;
+            const float v1 = (m1 < M && kq < KP) ? P[m1 * KP + kq] : 0.f;
             uint32_t h, md, lo;
-            split3(v, h, md, lo);
-            if constexpr (W) { w1[e] = h; w2[e] = md; w3[e] = lo; }
-            else { w1[e] = (n < 8) ? h : md; w2[e] = (n < 8) ? lo : 0u; w3[e] = 0u; }
+            split3_pair(v0, v1, h, md, lo);
+            if constexpr (W) { w1[e >> 1] = h; w2[e >> 1] = md; w3[e >> 1] = lo; }
+            else { w1[e >> 1] = (n < 8) ? h : md; w2[e >> 1] = (n < 8) ? lo : 0u; w3[e >> 1] = 0u; }
         }
-        pa_q1[tp] = make_uint4(w1[0] | (w1[1] << 16), w1[2] | (w1[3] << 16), w1[4] | (w1[5] << 16), w1[6] | (w1[7] << 16));
-        pa_q2[tp] = make_uint4(w2[0] | (w2[1] << 16), w2[2] | (w2[3] << 16), w2[4] | (w2[5] << 16), w2[6] | (w2[7] << 16));
-        if constexpr (W) pa_q3[tp] = make_uint4(w3[0] | (w3[1] << 16), w3[2] | (w3[3] << 16), w3[4] | (w3[5] << 16), w3[6] | (w3[7] << 16));
+        pa_q1[tp] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+        pa_q2[tp] = make_uint4(w2[0], w2[1], w2[2], w2[3]);
+        if constexpr (W) pa_q3[tp] = make_uint4(w3[0], w3[1], w3[2], w3[3]);
     }
     f32x4 dpacc[NTW];
 #pragma unroll
