@@ -771,11 +771,11 @@ __global__ __launch_bounds__(64 * mf_waves(KP)) void decode_bce_mfma_kernel(
 // (v_mfma_f32_16x16x32_bf16, 16x the f32 rate) with fp32 operands split into bf16 pieces:
 //   R^T = P.Q^T      P, Q split 3-way (hi+mid+lo = 24 mantissa bits); the 6 product terms >= 2^-16 fill the
 //                    K = 32 dimension of two MFMAs: [Ph Ph Pm Pm].[Qh Qm Qh Qm] and [Ph Pl 0 0].[Ql Qh 0 0]
-//   dQ^T = P^T.dR^T  dR split 2-way with round-to-nearest (v_cvt_pk_bf16_f32; 2^-17 relative, unbiased),
-//                    P 3-way in the 16 output rows ([Ph|Pm] and [Pl|0]); reduction = 32 SNPs = 2 tiles, the
-//                    lane's own 8 dR values ARE the B operand (no cross-lane movement)
+//   dQ^T = P^T.dR^T  dR split 2-way with round-to-nearest (v_cvt_pk_bf16_f32; 16-17 bits, unbiased), P with its hi
+//                    and mid pieces in the 16 output rows [Ph|Pm] (a third piece would be below dR's own 2^-18
+//                    truncation); reduction = 32 SNPs = 2 tiles, the lane's own 8 dR values ARE the B operand
 //   dP = dR^T.Q      same dR pieces, transposed through a 2 KB per-wave LDS buffer and read back with
-//                    ds_read_b64_tr_b16; Q 3-way in the 16 output columns; reduction = 32 samples = 2 tiles
+//                    ds_read_b64_tr_b16; Q hi|mid in the 16 output columns; reduction = 32 samples = 2 tiles
 // The VALU only does the per-genotype BCE algebra and the bf16 split.  Work unit of a wave: 2 SNP tiles x
 // 2 sample tiles.  Everything else (tile staging, chunking, dQ partial slabs) is as in the f32 MFMA kernel.
 // =================================================================================================
@@ -855,9 +855,9 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
     static_assert(KP <= 16, "one or two 8-wide k slots");
     // W (KP 9..16): k spans two 8-wide MFMA slots.  The pieces can no longer share an MFMA's 16 rows / columns, so
     //   R^T  = [Ph Ph' Ph Ph'].[Qh Qh' Qm Qm'] + [Pm Pm' Pm Pm'].[Qh Qh' Qm Qm'] + [Ph Ph' Pl Pl'].[Ql Ql' Qh Qh']   (X' = k 8..15)
-    //   dQ^T = (Ph + Pm + Pl).dRh + (Ph + Pm).dRl      rows = the 16 k, five MFMAs into one accumulator, no fold
-    //   dP   = dRh.(Qh + Qm + Ql) + dRl.(Qh + Qm)      columns = the 16 k, five MFMAs, no fold
-    // = 8 MFMAs per 16 x 16 tile instead of 5; everything else is shared with the K <= 8 path.
+    //   dQ^T = (Ph + Pm).(dRh + dRl)      rows = the 16 k, four MFMAs into one accumulator, no fold
+    //   dP   = (dRh + dRl).(Qh + Qm)      columns = the 16 k, four MFMAs, no fold
+    // = 7 MFMAs per 16 x 16 tile instead of 4; everything else is shared with the K <= 8 path.
     constexpr bool W = KP > 8;
     constexpr int KW = W ? 16 : 8;                       // k columns of the operand images
     static_assert(BF_NTW == 4 || BF_NTW == 2, "tile bits are read as one 32- or 16-bit word");
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
     constexpr int NTHR = 64 * MF_WAVES;
     __shared__ __attribute__((aligned(16))) uint8_t s_x[MF_TS * RS];
     __shared__ __attribute__((aligned(16))) uint4 s_qr[MF_TS / 16][2][64];   // B operands of R^T per 16-sample tile
-    __shared__ __attribute__((aligned(16))) uint4 s_qd[MF_TS / 32][W ? 3 : 2][64];   // B operands of dP per 32-sample pair
+    __shared__ __attribute__((aligned(16))) uint4 s_qd[MF_TS / 32][W ? 2 : 1][64];   // B operands of dP per 32-sample pair
     __shared__ __attribute__((aligned(16))) float s_dq[MF_WAVES][MF_TS * KP];
     __shared__ __attribute__((aligned(16))) uint16_t s_t[MF_WAVES][2][2][32 * 16];  // per wave: [SNP tile of the pair][hi / lo][32 samples][16 SNPs]
     __shared__ float s_loss[MF_WAVES];
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
 
     // zero the operand slots that are never written (k-slots 2,3 of the second R MFMA; columns 8..15 of the second dP MFMA)
     for (int e = tid; e < (MF_TS / 16) * 2 * 64; e += NTHR) (&s_qr[0][0][0])[e] = make_uint4(0, 0, 0, 0);
-    for (int e = tid; e < (MF_TS / 32) * (W ? 3 : 2) * 64; e += NTHR) (&s_qd[0][0][0])[e] = make_uint4(0, 0, 0, 0);
+    for (int e = tid; e < (MF_TS / 32) * (W ? 2 : 1) * 64; e += NTHR) (&s_qd[0][0][0])[e] = make_uint4(0, 0, 0, 0);
 
     // ---- resident A operands built from P ----
     uint4 pa_r1[NTW], pa_r2[NTW], pa_r3[W ? NTW : 1];     // R^T: lane (row = SNP n, slot a)
@@ -918,12 +918,13 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
                                   (H.w & m0) | (Lo.w & m1));                                 // slots [Ph Pl 0 0]
         }
     }
-    // dQ^T: lane (row n, slot a = 8 SNPs of the tile pair).  K <= 8: rows 0-7 = k (hi) / 8-15 = k (mid), second operand (lo | 0);
-    // W: rows = the 16 k, one operand per piece
-    uint4 pa_q1[NTW / 2], pa_q2[NTW / 2], pa_q3[W ? NTW / 2 : 1];
+    // dQ^T: lane (row n, slot a = 8 SNPs of the tile pair).  P enters dQ (and Q enters dP) with its hi and mid pieces only:
+    // dR itself is carried as hi + lo = 16-17 bits, so a 24-bit partner would add MFMAs without adding accuracy.
+    // K <= 8: rows 0-7 = k (hi), rows 8-15 = k (mid) in ONE operand; W: rows = the 16 k, one operand per piece
+    uint4 pa_q1[NTW / 2], pa_q2[W ? NTW / 2 : 1];
 #pragma unroll
     for (int tp = 0; tp < NTW / 2; ++tp) {
-        uint32_t w1[4], w2[4], w3[4];
+        uint32_t w1[4], w2[4];
         const int kq = W ? n : (n & 7);
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
@@ -932,12 +933,11 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
             const float v1 = (m1 < M && kq < KP) ? P[m1 * KP + kq] : 0.f;
             uint32_t h, md, lo;
             split3_pair(v0, v1, h, md, lo);
-            if constexpr (W) { w1[e >> 1] = h; w2[e >> 1] = md; w3[e >> 1] = lo; }
-            else { w1[e >> 1] = (n < 8) ? h : md; w2[e >> 1] = (n < 8) ? lo : 0u; w3[e >> 1] = 0u; }
+            if constexpr (W) { w1[e >> 1] = h; w2[e >> 1] = md; }
+            else { w1[e >> 1] = (n < 8) ? h : md; w2[e >> 1] = 0u; }
         }
         pa_q1[tp] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
-        pa_q2[tp] = make_uint4(w2[0], w2[1], w2[2], w2[3]);
-        if constexpr (W) pa_q3[tp] = make_uint4(w3[0], w3[1], w3[2], w3[3]);
+        if constexpr (W) pa_q2[tp] = make_uint4(w2[0], w2[1], w2[2], w2[3]);
     }
     f32x4 dpacc[NTW];
 #pragma unroll
@@ -989,10 +989,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
                 r2[(i + 16 * sl) * 8] = (uint16_t)lo;  r2[(i + 16 * (2 + sl)) * 8] = (uint16_t)h;    // [Ql Ql' Qh Qh']
                 uint16_t* d1 = reinterpret_cast<uint16_t*>(&s_qd[pair][0][0]) + e;
                 uint16_t* d2 = reinterpret_cast<uint16_t*>(&s_qd[pair][1][0]) + e;
-                uint16_t* d3 = reinterpret_cast<uint16_t*>(&s_qd[pair][2][0]) + e;
-                d1[(q8 * 16 + qk) * 8] = (uint16_t)h;                                        // column qk of Qh / Qm / Ql
+                d1[(q8 * 16 + qk) * 8] = (uint16_t)h;                                        // column qk of Qh / Qm
                 d2[(q8 * 16 + qk) * 8] = (uint16_t)md;
-                d3[(q8 * 16 + qk) * 8] = (uint16_t)lo;
             } else {
                 uint16_t* r1 = reinterpret_cast<uint16_t*>(&s_qr[st][0][0]) + qk;       // + lane*8 (uint16 units)
                 uint16_t* r2 = reinterpret_cast<uint16_t*>(&s_qr[st][1][0]) + qk;
@@ -1000,10 +998,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
                 r1[(i + 16) * 8] = (uint16_t)md;  r1[(i + 48) * 8] = (uint16_t)md;           // slots 1,3: Qm
                 r2[(i) * 8] = (uint16_t)lo;       r2[(i + 16) * 8] = (uint16_t)h;            // slots 0,1: Ql, Qh
                 uint16_t* d1 = reinterpret_cast<uint16_t*>(&s_qd[pair][0][0]) + e;
-                uint16_t* d2 = reinterpret_cast<uint16_t*>(&s_qd[pair][1][0]) + e;
                 d1[(q8 * 16 + qk) * 8] = (uint16_t)h;                                        // columns 0..7: Qh
                 d1[(q8 * 16 + qk + 8) * 8] = (uint16_t)md;                                   // columns 8..15: Qm
-                d2[(q8 * 16 + qk) * 8] = (uint16_t)lo;                                       // columns 0..7: Ql
             }
         }
     };
@@ -1038,9 +1034,9 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
                     qb1[s2] = s_qr[st][0][lane];
                     qb2[s2] = s_qr[st][1][lane];
                 }
-                const uint4 qd1 = s_qd[p][0][lane], qd2 = s_qd[p][1][lane];
-                uint4 qd3 = make_uint4(0, 0, 0, 0);
-                if constexpr (W) qd3 = s_qd[p][2][lane];
+                const uint4 qd1 = s_qd[p][0][lane];
+                uint4 qd2 = make_uint4(0, 0, 0, 0);
+                if constexpr (W) qd2 = s_qd[p][1][lane];
                 f32x4 dq[2];
                 dq[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 dq[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1076,14 +1072,13 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
                         const bf16x8 bh = as_bf16x8(make_uint4(hi[0][0], hi[0][1], hi[1][0], hi[1][1]));
                         const bf16x8 bl = as_bf16x8(make_uint4(lo[0][0], lo[0][1], lo[1][0], lo[1][1]));
                         dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q1[tp]), bh, dq[s2], 0, 0, 0);
-                        dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q2[tp]), bh, dq[s2], 0, 0, 0);
                         dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q1[tp]), bl, dq[s2], 0, 0, 0);
                         if constexpr (W) {
-                            dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q3[tp]), bh, dq[s2], 0, 0, 0);
+                            dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q2[tp]), bh, dq[s2], 0, 0, 0);
                             dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q2[tp]), bl, dq[s2], 0, 0, 0);
                         }
                     }
-                    // dP: per SNP tile, read dR (hi, lo) of the 32 samples back transposed, then 3 MFMAs
+                    // dP: per SNP tile, read dR (hi, lo) of the 32 samples back transposed, then 2 (W: 4) MFMAs
 #pragma unroll
                     for (int t2 = 0; t2 < 2; ++t2) {
                         // A operand: lane (row = SNP n, slot a = samples 8a..8a+7): two transposing reads of 4 samples each
@@ -1098,15 +1093,14 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
                         const bf16x8 al = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
                         const int t = 2 * tp + t2;
                         dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd1), dpacc[t], 0, 0, 0);
-                        dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd2), dpacc[t], 0, 0, 0);
                         dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(qd1), dpacc[t], 0, 0, 0);
                         if constexpr (W) {
-                            dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd3), dpacc[t], 0, 0, 0);
+                            dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd2), dpacc[t], 0, 0, 0);
                             dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(qd2), dpacc[t], 0, 0, 0);
                         }
                     }
                 }
-                // K <= 8: dQ^T rows k (hi part + lo part) and k+8 (mid part) sit 32 lanes apart: fold, lanes a<2 store.
+                // K <= 8: dQ^T rows k (hi part) and k+8 (mid part) sit 32 lanes apart: fold, lanes a<2 store.
                 // W: rows 4a + r ARE k, every lane group with 4a < KP stores its four.
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -1140,7 +1134,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(K
         __syncthreads();
     }
 
-    // ---- dP: columns 0..7 (hi + lo parts) and 8..15 (mid part) fold with a rotate by 8 inside the 16-lane row ----
+    // ---- dP: columns 0..7 (hi part) and 8..15 (mid part) fold with a rotate by 8 inside the 16-lane row ----
     // The block's dP rows are one contiguous [chunk SNPs x KP] slab: staged through LDS (the transposition buffers are free
     // now) and written as full 16 B / lane rows instead of 32 B pieces scattered over rows.
     static_assert(sizeof(s_t) >= (size_t)MF_WAVES * 16 * NTW * KP * sizeof(float), "dP staging fits the transposition buffers");
