@@ -40,7 +40,7 @@ extern "C" {
 
 #define NADM_MAX_HEADS 32
 #define NADM_MAX_K 64
-#define NADM_ABI_VERSION 1
+#define NADM_ABI_VERSION 2   /* 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */

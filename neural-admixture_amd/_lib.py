@@ -64,7 +64,7 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.nadm_abi_version() != 1:
+    if lib.nadm_abi_version() != 2:
         raise RuntimeError("neural_admixture_amd: libnadm.so ABI version mismatch")
     return lib, tuple(sig)
 
