@@ -219,6 +219,9 @@ def test_cli_parsers_have_the_reference_flags():
     assert (a.epochs, a.batch_size, a.learning_rate, a.seed, a.hidden_size, a.n_components) == (250, 800, 2e-3, 42, 1024, 8)   # entry.py:27-43
     b = parse_infer_args(["--out_name", "o", "--save_dir", "s", "--data_path", "x.bed", "--name", "n"])
     assert b.batch_size == 1024 and b.seed == 42                                                                           # entry.py:57-65
+    assert a.parallelism == "dp" and a.pops_path == "" and a.supervised_loss_weight == 100
+    c = parse_train_args(["--save_dir", "o", "--data_path", "x.bed", "--name", "n", "--k", "3", "--parallelism", "snp", "--pops_path", "p.txt"])
+    assert c.parallelism == "snp" and c.pops_path == "p.txt"
 
 
 def test_supervised_host_logic_against_oracle_and_reference():

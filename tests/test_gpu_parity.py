@@ -650,6 +650,38 @@ def test_cli_train_and_infer_demo(tmp_path):
     assert mx(np.loadtxt(out / "again.3.Q"), Q) < 1e-6
 
 
+def test_cli_supervised_run_from_bed_and_pops_file(tmp_path):
+    """`train --pops_path`: BED written from the supervised fixture's matrix (inverse of the reader's [2,3,1,0] recode),
+    population names from a text file (src/utils.py:28-33); the result must equal the boundary call with the same inputs."""
+    import neural_admixture_amd as na
+    from neural_admixture_amd import cli
+    from neural_admixture_amd.io import read_bed_packed
+    from neural_admixture_amd.svd import RSVD
+    dev = _dev()
+    d = np.load(f"{G}/supervised_k4.npz")
+    N, M, K = int(d["N"]), int(d["M"]), int(d["K"])
+    Gm = O.unpack2bit(d["G_packed"], M)
+    assert Gm[Gm != 3].mean() < 1.0 and Gm.mean() < 1.0                   # no allele flip in the reader
+    inv = np.array([3, 2, 0, 1], dtype=np.uint8)                           # genotype code -> PLINK 2-bit code
+    codes = inv[Gm.T]                                                      # SNP-major [M, N]
+    nb = (N + 3) // 4
+    pad = np.zeros((M, nb * 4), dtype=np.uint8)
+    pad[:, :N] = codes
+    bed = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+    (tmp_path / "s.bed").write_bytes(bytes([0x6C, 0x1B, 0x01]) + bed.tobytes())
+    (tmp_path / "s.fam").write_text("\n".join(["s"] * N) + "\n")
+    (tmp_path / "pops.txt").write_text("\n".join(str(a) for a in d["pops"]) + "\n")
+    data = read_bed_packed(str(tmp_path / "s.bed"))
+    assert np.array_equal(data.unpack_rows(0, N), Gm)
+    out = tmp_path / "out"
+    assert cli.main(["train", "--epochs", "3", "--k", str(K), "--name", "sup", "--data_path", str(tmp_path / "s.bed"), "--save_dir", str(out),
+                     "--seed", "13", "--batch_size", "100", "--hidden_size", "128", "--pops_path", str(tmp_path / "pops.txt")]) == 0
+    Q = np.loadtxt(out / "sup.4.Q", dtype=np.float32)
+    V = RSVD(data, N, M, 8, 13)
+    Ps, Qs, _ = na.train(3, 100, 2e-3, K, 13, data, dev, 1, 128, True, V, [str(a) for a in d["pops"]], None, None, 8)
+    assert np.array_equal(Q, Qs[0])
+
+
 def test_ddp_step_on_rccl_world1_equals_plain_step():
     """The RCCL code path (async all-reduce of the flat gradient views, stream waits, 1/world scaling) on a
     one-rank NCCL group: must be bit-identical to the single-GPU step."""
