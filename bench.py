@@ -113,7 +113,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), rank=rank, world_size=world)
+        # RCCL prints a version banner through C stdio on stdout; keep stdout for the one JSON line: send fd 1 to stderr
+        # while the communicator is created (eager with device_id=) and flush the C buffers before switching back
+        import ctypes
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), rank=rank, world_size=world)
+            t_ = torch.zeros(1, device=f"cuda:{local_rank}")
+            dist.all_reduce(t_)
+            torch.cuda.synchronize()
+        finally:
+            ctypes.CDLL(None).fflush(None)
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     import neural_admixture_amd as na
