@@ -47,7 +47,6 @@ def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_comp
     Note the projection keeps missing (3) as 1.5, exactly like the reference (train.py:52).
     ``data_np``: uint8 [N,M] array or an io.PackedGenotypes.  With a GPU ``device`` and n_components <= 8 the
     projection runs on the GPU (pca_project_gpu); otherwise on the host, 1024 rows at a time like the reference."""
-    from sklearn.mixture import GaussianMixture
     N = data_np.shape[0]
     if device is not None and device.type == "cuda" and n_components <= 8:
         X_pca = pca_project_gpu(data_np, V_CM, device)
@@ -58,12 +57,34 @@ def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_comp
             X_pca[i:i + 1024] = (rows(i, min(N, i + 1024)).astype(np.float32) / 2) @ V_CM.T
     X_pca = X_pca.astype("float64")
     ks = [K] if K is not None else list(range(min_k, max_k + 1))
-    Ps = []
-    for k in ks:
-        gmm = GaussianMixture(n_components=k, n_init=5, init_params="k-means++", tol=1e-4, covariance_type="full",
-                              max_iter=100, random_state=seed).fit(X_pca)
-        Ps.append(np.clip(gmm.means_ @ V_CM, 5e-6, 1 - 5e-6))
-    return np.concatenate(Ps, axis=0)
+    means = _gmm_means_parallel(X_pca, ks, seed) if len(ks) > 2 else None
+    if means is None:
+        from ._gmm_fit import fit_means
+        means = [fit_means(X_pca, k, seed) for k in ks]
+    return np.concatenate([np.clip(m @ V_CM, 5e-6, 1 - 5e-6) for m in means], axis=0)
+
+
+def _gmm_means_parallel(X_pca: np.ndarray, ks, seed: int):
+    """The multi-head run fits one GMM per K (train.py:65-67, a list comprehension in the reference).  The fits are
+    independent and deterministic (random_state), so they run as concurrent child processes (_gmm_fit.py as a script:
+    numpy + sklearn only, no fork of the process that owns the GPU context).  Returns None on any failure -- the caller
+    then fits sequentially in-process, which gives the same numbers."""
+    import os
+    import subprocess
+    import tempfile
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gmm_fit.py")
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            xp = os.path.join(td, "x.npy")
+            np.save(xp, X_pca)
+            env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+            procs = [subprocess.Popen([sys.executable, script, xp, str(k), str(seed), os.path.join(td, f"m{k}.npy")], env=env,
+                                      stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for k in ks]
+            if any(p.wait(timeout=600) != 0 for p in procs):
+                return None
+            return [np.load(os.path.join(td, f"m{k}.npy")) for k in ks]
+    except Exception:
+        return None
 
 
 def supervised_init(data_np, pops, K: int):

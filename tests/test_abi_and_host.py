@@ -273,3 +273,18 @@ def test_native_savetxt_matches_numpy_bytes(tmp_path):
     assert np.array_equal(np.loadtxt(tmp_path / "run.3.P", dtype=np.float32), P)
     savetxt(tmp_path / "f64.txt", Q.astype(np.float64))                 # other dtypes: numpy path
     assert np.allclose(np.loadtxt(tmp_path / "f64.txt"), Q)
+
+
+def test_parallel_gmm_fits_equal_sequential_ones():
+    """Multi-head init: one sklearn GMM per K (train.py:65-67) fitted in concurrent child processes (_gmm_fit.py) gives
+    exactly the means of the in-process sequential fits."""
+    from neural_admixture_amd.train import _gmm_means_parallel
+    from neural_admixture_amd._gmm_fit import fit_means
+    rng = np.random.default_rng(0)
+    cent = rng.standard_normal((4, 8)) * 3
+    X = np.concatenate([c + rng.standard_normal((60, 8)) for c in cent]).astype("float64")
+    ks = [2, 3, 4]
+    par = _gmm_means_parallel(X, ks, 7)
+    assert par is not None
+    for k, m in zip(ks, par):
+        assert m.shape == (k, 8) and np.array_equal(m, fit_means(X, k, 7))
