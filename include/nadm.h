@@ -97,6 +97,12 @@ int nadm_unpack2bit(const uint8_t* in_dev, uint8_t* out_dev, int64_t rows, int64
 int nadm_bed_to_packed(const uint8_t* bed, int64_t N, int64_t M, uint8_t* out_host, int64_t ld,
                        int64_t* counts, int32_t flip_if_mean_ge1, int32_t* flipped);
 
+/* The same conversion on the device: bed_dev = the file contents after the 3 magic bytes, already in HBM ([M, ceil(N/4)]);
+ * out_dev [N, ld] (ld % 16 == 0; the row padding is written as zeros); counts_dev uint64[4] and flipped_dev int32[1] are
+ * device scratch/outputs (zeroed here).  The flip decision is taken on the device, nothing is read back: asynchronous. */
+int nadm_bed_to_packed_dev(const uint8_t* bed_dev, int64_t N, int64_t M, uint8_t* out_dev, int64_t ld, uint64_t* counts_dev,
+                           int32_t flip_if_mean_ge1, int32_t* flipped_dev, void* stream);
+
 /* ---- a4/a5: encoder projection  Z = X.V  (neural_admixture.py:169-172) ----------------- */
 /* rows idx[0..b) of xp are the batch (replaces Dataset_admixture.__getitem__ + collate,
  * loaders.py:62-72, and the per-step unpack2bit_gpu_to_gpu, neural_admixture.py:404-406).

@@ -45,6 +45,7 @@ def _load():
         "nadm_pack2bit": (C.c_int, [vp, vp, i64, i64, i64, vp]),
         "nadm_unpack2bit": (C.c_int, [vp, vp, i64, i64, i64, vp]),
         "nadm_bed_to_packed": (C.c_int, [vp, i64, i64, vp, i64, C.POINTER(i64), i32, C.POINTER(i32)]),
+        "nadm_bed_to_packed_dev": (C.c_int, [vp, i64, i64, vp, i64, vp, i32, vp, vp]),
         "nadm_encode_fwd": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp]),
         "nadm_pca_project": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp]),
         "nadm_pca_project_t": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp]),

@@ -54,12 +54,12 @@ def parse_infer_args(argv):
     return p.parse_args(argv)
 
 
-def _read(path):
+def _read(path, device=None, keep_on_device=False):
     from .io import read_bed_packed
     if ".bed" not in os.path.basename(path):
         raise SystemExit("    Invalid format: this build reads PLINK .bed input (VCF/PGEN readers are the reference's own).")
     log.info("    Input format is BED.")
-    data = read_bed_packed(path)
+    data = read_bed_packed(path, device, keep_on_device)
     log.info(f"    Data contains {data.N} samples and {data.M} SNPs.")
     return data
 
@@ -111,7 +111,7 @@ def main(argv=None):
             raise ValueError("Please provide either --k or both --min_k and --max_k.")
         num_gpus = max(1, min(args.num_gpus, torch.cuda.device_count()))
         from .svd import RSVD
-        data = _read(args.data_path)
+        data = _read(args.data_path, torch.device("cuda:0"), keep_on_device=(num_gpus == 1))   # 2-bit transpose on the GPU
         log.info("")
         log.info("    Running SVD...")
         V = RSVD(data, data.N, data.M, args.n_components, args.seed)

@@ -683,6 +683,91 @@ __global__ __launch_bounds__(256) void loglik_kernel(const uint8_t* __restrict__
 }
 
 // =================================================================================================
+// bed_to_packed on the device: PLINK .bed is SNP-major, 4 samples per byte; the engine wants sample-major, 4 SNPs per
+// byte -- a transpose of a 2-bit matrix plus the reference's recode [2,3,1,0] (src/utils_c/utils.pyx:52).
+//   A 32-bit word made of the bytes of 4 consecutive SNPs at one byte column holds a 4 x 4 block (SNP r, sample i) of
+//   2-bit fields at bit 8r + 2i; two delta swaps transpose it to (sample i, SNP r) at bit 8i + 2r = one output byte per
+//   sample.  The recode is bitwise: g_hi = ~c_hi, g_lo = c_lo ^ c_hi.
+//   block = 256 threads, tile = 512 SNPs (128 output byte columns) x 128 samples (32 input byte columns): every thread
+//   transposes 16 words; the tile goes through LDS so that each sample row is written as 128 contiguous bytes.
+//   Code counts (for the reader's "flip if the mean code is >= 1" rule) are integer atomics: order-independent.
+// =================================================================================================
+__device__ __forceinline__ uint32_t transpose4x4_2bit(uint32_t w) {
+    uint32_t t = ((w >> 6) ^ w) & 0x00CC00CCu;
+    w ^= t ^ (t << 6);
+    t = ((w >> 12) ^ w) & 0x0000F0F0u;
+    return w ^ t ^ (t << 12);
+}
+
+__global__ __launch_bounds__(256) void bed_to_packed_kernel(const uint8_t* __restrict__ bed, int64_t N, int64_t M, int64_t nb,
+                                                            uint8_t* __restrict__ out, int64_t ld, unsigned long long* __restrict__ counts) {
+    constexpr int TG = 128, TJ = 32;                        // SNP groups (of 4) and sample byte columns per tile
+    __shared__ __attribute__((aligned(16))) uint8_t s_t[TJ * 4][TG + 16];
+    __shared__ unsigned int s_cnt[4];
+    const int tid = threadIdx.x;
+    const int64_t g0 = (int64_t)blockIdx.x * TG, j0 = (int64_t)blockIdx.y * TJ;
+    if (tid < 4) s_cnt[tid] = 0;
+    unsigned int c1 = 0, c2 = 0, c3 = 0, cv = 0;
+    for (int e = tid; e < TG * TJ; e += 256) {
+        const int jj = e % TJ, gg = e / TJ;                  // lanes run along the sample byte columns: coalesced byte loads
+        const int64_t j = j0 + jj, m = 4 * (g0 + gg);
+        uint32_t w = 0, valid = 0;
+        if (j < nb) {
+            const int ns = (int)((N - 4 * j < 4) ? (N - 4 * j) : 4);       // samples in this byte
+            const uint32_t smask = ns == 4 ? 0xFFu : ((1u << (2 * ns)) - 1u);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (m + r < M) {
+                    w |= (uint32_t)bed[(m + r) * nb + j] << (8 * r);
+                    valid |= smask << (8 * r);
+                }
+        }
+        const uint32_t hi = w & 0xAAAAAAAAu, lo = w & 0x55555555u;        // PLINK 00,01,10,11 -> 2,3,1,0
+        uint32_t g = ((~hi) & 0xAAAAAAAAu) | (lo ^ (hi >> 1));
+        g &= valid;                                          // padding samples / SNPs past M stay 0
+        const uint32_t gl = g & 0x55555555u, gh = (g >> 1) & 0x55555555u;
+        c3 += __popc(gl & gh); c2 += __popc(gh & ~gl); c1 += __popc(gl & ~gh); cv += __popc(valid & 0x55555555u);
+        const uint32_t t = transpose4x4_2bit(g);             // byte i = sample 4j+i, its 4 SNPs of group gg
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_t[4 * jj + i][gg] = (uint8_t)(t >> (8 * i));
+    }
+    __syncthreads();
+    for (int e = tid; e < TJ * 4 * (TG / 16); e += 256) {    // 128 sample rows x 128 bytes, 16 B per store
+        const int row = e / (TG / 16), c16 = e % (TG / 16);
+        const int64_t smp = 4 * j0 + row, col = g0 + 16 * c16;
+        if (smp < N && col < ld) *reinterpret_cast<uint4*>(out + smp * ld + col) = *reinterpret_cast<const uint4*>(&s_t[row][16 * c16]);
+    }
+    atomicAdd(&s_cnt[1], c1); atomicAdd(&s_cnt[2], c2); atomicAdd(&s_cnt[3], c3); atomicAdd(&s_cnt[0], cv - c1 - c2 - c3);
+    __syncthreads();
+    if (tid < 4 && s_cnt[tid]) atomicAdd(&counts[tid], (unsigned long long)s_cnt[tid]);
+}
+
+// flip 0 <-> 2 (1 and 3 unchanged) on every byte if the mean code is >= 1 (src/snp_reader.py:109-110, with the missing
+// code kept at 3 like the packed path of the reference, pack2bit.cu:29); decided on the device from the counts.
+__global__ __launch_bounds__(256) void bed_flip_kernel(uint8_t* __restrict__ out, int64_t N, int64_t M, int64_t ld,
+                                                       const unsigned long long* __restrict__ counts, int32_t* __restrict__ flipped) {
+    const double mean = (double)(counts[1] + 2 * counts[2] + 3 * counts[3]) / ((double)N * (double)M);
+    const bool flip = mean >= 1.0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *flipped = flip ? 1 : 0;
+    if (!flip) return;
+    const int64_t mp16 = ((M + 3) / 4 + 15) / 16;            // 16-byte pieces that hold SNPs
+    const int64_t r = blockIdx.y;
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < mp16; c += (int64_t)gridDim.x * 256) {
+        uint4* pz = reinterpret_cast<uint4*>(out + r * ld + 16 * c);
+        uint4 v = *pz;
+        uint32_t* w = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t snp0 = (16 * c + 4 * k) * 4;       // first SNP of this word
+            uint32_t keep = 0xFFFFFFFFu;                      // fields that hold real SNPs (the row tail must stay 0)
+            if (snp0 + 16 > M) keep = snp0 >= M ? 0u : ((1u << (2 * (M - snp0))) - 1u);
+            w[k] = (w[k] ^ ((~w[k] & 0x55555555u) << 1)) & keep;
+        }
+        *pz = v;
+    }
+}
+
+// =================================================================================================
 // supervised_ce: weight * CrossEntropyLoss(sum) applied to the softmax OUTPUT of head 0 as logits
 // (neural_admixture.py:293,470-473).  One block; thread t takes samples t, t+256, ...
 //   loss_i = logsumexp(q_i) - q_i[y_i],  d/dq_ij = softmax(q_i)_j - [j == y_i]
@@ -1045,6 +1130,27 @@ extern "C" int nadm_bed_to_packed(const uint8_t* bed, int64_t N, int64_t M, uint
     }
     if (flipped) *flipped = did;
     return 0;
+}
+
+extern "C" int nadm_bed_to_packed_dev(const uint8_t* bed_dev, int64_t N, int64_t M, uint8_t* out_dev, int64_t ld, uint64_t* counts_dev,
+                                      int32_t flip_if_mean_ge1, int32_t* flipped_dev, void* stream) {
+    if (!bed_dev || !out_dev || !counts_dev || !flipped_dev) return fail("nadm_bed_to_packed_dev: null pointer");
+    if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_bed_to_packed_dev: ld must be a multiple of 16 and >= ceil(M/4)");
+    if (N <= 0 || M <= 0) return fail("nadm_bed_to_packed_dev: empty matrix");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nb = (N + 3) / 4;
+    if (hipMemsetAsync(counts_dev, 0, 4 * sizeof(uint64_t), st) != hipSuccess || hipMemsetAsync(flipped_dev, 0, sizeof(int32_t), st) != hipSuccess)
+        return fail("nadm_bed_to_packed_dev: memset failed");
+    // the tile grid covers ld bytes per row, so the row padding is written (as zeros) too
+    dim3 grid((unsigned)((ld + 127) / 128), (unsigned)((nb + 31) / 32));
+    hipLaunchKernelGGL(bed_to_packed_kernel, grid, dim3(256), 0, st, bed_dev, N, M, nb, out_dev, ld, (unsigned long long*)counts_dev);
+    if (flip_if_mean_ge1) {
+        const int64_t mp16 = ((M + 3) / 4 + 15) / 16;
+        dim3 g2((unsigned)((mp16 + 255) / 256 < 64 ? (mp16 + 255) / 256 : 64), (unsigned)N);
+        if (N > 65535) return fail("nadm_bed_to_packed_dev: more than 65535 samples need the flip in row chunks (not implemented)");
+        hipLaunchKernelGGL(bed_flip_kernel, g2, dim3(256), 0, st, out_dev, N, M, ld, (const unsigned long long*)counts_dev, flipped_dev);
+    }
+    return check_launch("bed_to_packed_dev");
 }
 
 extern "C" int nadm_pack2bit(const uint8_t* g_dev, uint8_t* out_dev, int64_t rows, int64_t M, int64_t ld, void* stream) {

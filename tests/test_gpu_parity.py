@@ -630,6 +630,41 @@ def test_loglikelihood_kernel_matches_float64_oracle():
     assert abs(got - float(d["hi_e5_loglik"])) <= 1e-10 * abs(float(d["hi_e5_loglik"]))
 
 
+def test_bed_to_packed_on_device_equals_the_host_converter(tmp_path):
+    """nadm_bed_to_packed_dev (word-level 4x4 transposes of 2-bit fields, LDS tile, integer-atomic counts, on-device flip
+    decision) against nadm_bed_to_packed on ragged shapes, with and without the allele flip, and on the demo BED."""
+    import ctypes as C
+    from neural_admixture_amd._lib import lib, check, ptr
+    from neural_admixture_amd.layout import ModelLayout
+    from neural_admixture_amd.io import read_bed_packed
+    dev = _dev()
+    rng = np.random.default_rng(17)
+    for N, M, p_alt in ((1, 1, 0.2), (5, 3, 0.9), (131, 517, 0.15), (130, 2049, 0.8), (1000, 4100, 0.3)):
+        nb = (N + 3) // 4
+        # PLINK codes: 0 = hom A1 (-> 2), 1 = missing (-> 3), 2 = het (-> 1), 3 = hom A2 (-> 0); p_alt steers the mean across 1
+        codes = rng.choice(4, size=(M, nb * 4), p=[p_alt * 0.9, 0.03, 0.07, 0.9 - p_alt * 0.9]).astype(np.uint8)
+        bed = (codes[:, 0::4] | (codes[:, 1::4] << 2) | (codes[:, 2::4] << 4) | (codes[:, 3::4] << 6)).astype(np.uint8)
+        bed = np.ascontiguousarray(bed)
+        ld = ModelLayout.row_stride(M)
+        ref = torch.full((N, ld), 255, dtype=torch.uint8)
+        c4, fl = (C.c_int64 * 4)(), C.c_int32(0)
+        check(lib.nadm_bed_to_packed(C.c_void_p(bed.ctypes.data), N, M, ptr(ref), ld, c4, 1, C.byref(fl)))
+        bd = torch.from_numpy(bed).to(dev)
+        out = torch.full((N, ld), 255, dtype=torch.uint8, device=dev)
+        cnt = torch.full((4,), 7, dtype=torch.int64, device=dev)
+        flp = torch.full((1,), 9, dtype=torch.int32, device=dev)
+        check(lib.nadm_bed_to_packed_dev(ptr(bd), N, M, ptr(out), ld, ptr(cnt), 1, ptr(flp), None))
+        torch.cuda.synchronize()
+        assert [int(v) for v in cnt.cpu()] == [int(c4[i]) for i in range(4)]
+        assert int(flp.cpu()[0]) == fl.value
+        assert np.array_equal(out.cpu().numpy(), ref.numpy())
+    d = np.load(f"{G}/demo_k3.npz")
+    d["bed_bytes"].tofile(tmp_path / "demo.bed")
+    (tmp_path / "demo.fam").write_text("\n".join(["s"] * int(d["N"])) + "\n")
+    a, b2 = read_bed_packed(str(tmp_path / "demo.bed")), read_bed_packed(str(tmp_path / "demo.bed"), dev, keep_on_device=True)
+    assert b2.packed.device.type == "cuda" and a.flipped == b2.flipped and np.array_equal(a.packed.numpy(), b2.packed.cpu().numpy())
+
+
 def test_cli_train_and_infer_demo(tmp_path):
     """`python -m neural_admixture_amd train|infer` on the demo BED: RSVD (GPU, from packed) + GMM init + training +
     outputs in the reference's file formats; infer reproduces Q from the saved encoder."""
