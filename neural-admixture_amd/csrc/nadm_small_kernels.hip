@@ -1076,31 +1076,46 @@ extern "C" int nadm_bed_to_packed(const uint8_t* bed, int64_t N, int64_t M, uint
     if (!bed || !out || !counts) return fail("nadm_bed_to_packed: null pointer");
     if (ld * 4 < M) return fail("nadm_bed_to_packed: ld < ceil(M/4)");
     const int64_t nb = (N + 3) / 4;                       // bytes per SNP in the .bed
-    static const uint8_t lut[4] = {2, 3, 1, 0};
     int nt = (int)std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
     if (nt > 64) nt = 64;
     const int64_t nblk = (M + 255) / 256;
     if (nblk < nt) nt = (int)(nblk > 0 ? nblk : 1);
     std::vector<std::array<int64_t, 4>> cnt(nt, std::array<int64_t, 4>{0, 0, 0, 0});
+    // word-level version of the device kernel: the bytes of 4 consecutive SNPs at one sample-byte column form a 4 x 4 block
+    // of 2-bit fields; recode bitwise, transpose with two delta swaps, one output byte per sample
+    auto tr = [](uint32_t w) -> uint32_t {
+        uint32_t t = ((w >> 6) ^ w) & 0x00CC00CCu;
+        w ^= t ^ (t << 6);
+        t = ((w >> 12) ^ w) & 0x0000F0F0u;
+        return w ^ t ^ (t << 12);
+    };
     auto work = [&](int t) {
-        std::vector<uint8_t> rows(4 * 64);
+        uint8_t rows[4][64];
         for (int64_t blk = t; blk < nblk; blk += nt) {
             const int64_t m0 = blk * 256;
             const int64_t nm = (M - m0 < 256) ? (M - m0) : 256;
             const int64_t ncol = (nm + 3) / 4;            // output bytes per row in this block
             for (int64_t bi = 0; bi < nb; ++bi) {
-                memset(rows.data(), 0, rows.size());
                 const int ns = (int)((N - 4 * bi < 4) ? (N - 4 * bi) : 4);
-                for (int64_t j = 0; j < nm; ++j) {
-                    const uint8_t v = bed[(m0 + j) * nb + bi];
-                    for (int s4 = 0; s4 < ns; ++s4) {
-                        const uint8_t code = lut[(v >> (2 * s4)) & 3];
-                        cnt[t][code]++;
-                        rows[s4 * 64 + (j >> 2)] |= (uint8_t)(code << (2 * (j & 3)));
-                    }
+                const uint32_t smask = ns == 4 ? 0xFFu : ((1u << (2 * ns)) - 1u);
+                for (int64_t g = 0; g < ncol; ++g) {
+                    uint32_t w = 0, valid = 0;
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * g + r < nm) {
+                            w |= (uint32_t)bed[(m0 + 4 * g + r) * nb + bi] << (8 * r);
+                            valid |= smask << (8 * r);
+                        }
+                    const uint32_t hi = w & 0xAAAAAAAAu, lo = w & 0x55555555u;
+                    const uint32_t gq = (((~hi) & 0xAAAAAAAAu) | (lo ^ (hi >> 1))) & valid;
+                    const uint32_t gl = gq & 0x55555555u, gh = (gq >> 1) & 0x55555555u;
+                    const int c3 = __builtin_popcount(gl & gh), c2 = __builtin_popcount(gh & ~gl), c1 = __builtin_popcount(gl & ~gh);
+                    cnt[t][3] += c3; cnt[t][2] += c2; cnt[t][1] += c1;
+                    cnt[t][0] += __builtin_popcount(valid & 0x55555555u) - c1 - c2 - c3;
+                    const uint32_t q = tr(gq);
+                    rows[0][g] = (uint8_t)q; rows[1][g] = (uint8_t)(q >> 8); rows[2][g] = (uint8_t)(q >> 16); rows[3][g] = (uint8_t)(q >> 24);
                 }
-                for (int s4 = 0; s4 < ns; ++s4) memcpy(out + (4 * bi + s4) * ld + (m0 >> 2), rows.data() + s4 * 64, (size_t)ncol);
+                for (int s4 = 0; s4 < ns; ++s4) memcpy(out + (4 * bi + s4) * ld + (m0 >> 2), rows[s4], (size_t)ncol);
             }
         }
     };
