@@ -129,7 +129,7 @@ def main(argv=None):
     sd = torch.load(f"{args.save_dir}/{args.name}.pt", map_location="cpu", weights_only=True)
     model = Q_P(int(cfg["hidden_size"]), int(cfg["num_features"]), ks_list=cfg["ks"], is_train=False)
     model.load_state_dict(sd, device=torch.device("cuda:0"), max_batch=args.batch_size)
-    data = _read(args.data_path)
+    data = _read(args.data_path, torch.device("cuda:0"), keep_on_device=True)
     eng = model.engine
     eng.pack_from_host(data)
     idx = torch.arange(data.N, dtype=torch.int32, device=eng.device)
