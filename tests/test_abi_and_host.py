@@ -51,6 +51,43 @@ def test_argument_validation_without_gpu():
         check(lib.nadm_heads_init(C.byref(h), 8, 64, ks, 1), "heads_init")
 
 
+def test_argument_validation_of_the_round1_additions(tmp_path):
+    """Error paths of the entry points added after the core path: every one fails with a message before any launch."""
+    from neural_admixture_amd._lib import lib, check
+    buf = torch.zeros(64)
+    p = C.c_void_p(buf.data_ptr())
+    with pytest.raises(RuntimeError, match="K must be in 1..16"):
+        check(lib.nadm_loglik(p, 16, 4, 8, p, p, 17, 17, 1e-6, p, None), "loglik")
+    with pytest.raises(RuntimeError, match="q_stride"):
+        check(lib.nadm_loglik(p, 16, 4, 8, p, p, 4, 3, 1e-6, p, None), "loglik")
+    with pytest.raises(RuntimeError, match="CP <= 8"):
+        check(lib.nadm_pca_project(p, 16, p, 4, 8, p, 12, p, None), "pca_project")
+    with pytest.raises(RuntimeError, match="CP <= 8"):
+        check(lib.nadm_pca_project_t(p, 16, p, 4, 8, p, 12, p, None), "pca_project_t")
+    with pytest.raises(RuntimeError, match="number of classes"):
+        check(lib.nadm_supervised_ce(p, 8, 3, 4, p, None, 4, 5, 100.0, p, p, None), "supervised_ce")
+    with pytest.raises(RuntimeError, match="k <= kp <= SP"):
+        check(lib.nadm_supervised_ce(p, 8, 5, 4, p, None, 4, 5, 100.0, p, p, None), "supervised_ce")
+    with pytest.raises(RuntimeError, match="null pointer"):
+        check(lib.nadm_bed_to_packed_dev(None, 4, 8, p, 16, p, 1, p, None), "bed_to_packed_dev")
+    with pytest.raises(RuntimeError, match="multiple of 16"):
+        check(lib.nadm_bed_to_packed_dev(p, 4, 8, p, 8, p, 1, p, None), "bed_to_packed_dev")
+    with pytest.raises(RuntimeError, match="cannot open"):
+        check(lib.nadm_savetxt_f32(str(tmp_path / "no_such_dir" / "x.txt").encode(), p, 2, 2, 2), "savetxt")
+    with pytest.raises(RuntimeError, match="bad shape"):
+        check(lib.nadm_savetxt_f32(str(tmp_path / "x.txt").encode(), p, 2, 4, 2), "savetxt")
+    with pytest.raises(RuntimeError, match="null pointer"):
+        check(lib.nadm_mlp_bwd_weights(None, 4, p, p, p, p, p, p, p, None), "mlp_bwd_weights")
+    # chunk bookkeeping: slabs of pass 2 are 256 SNPs for the matrix-pipe kernels, consistent with nadm_decode_chunks
+    for kp in (4, 8, 12, 16):
+        assert lib.nadm_decode_chunk_snps(kp) == 256
+        assert lib.nadm_decode_chunks(1000, kp) == 4 and lib.nadm_decode_chunks(1024, kp) == 4 and lib.nadm_decode_chunks(1025, kp) == 5
+    for kp in (24, 48):
+        c = lib.nadm_decode_chunk_snps(kp)
+        assert c > 0 and lib.nadm_decode_chunks(10 * c + 1, kp) == 11
+    assert lib.nadm_loglik_blocks(1) == 1 and lib.nadm_loglik_blocks(1025) == 2
+
+
 def test_engine_refuses_cpu_device():
     import neural_admixture_amd as na
     with pytest.raises(RuntimeError, match="GPU"):
