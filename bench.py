@@ -162,7 +162,7 @@ def main():
         if snp:
             eng.train_step(perm[o:o + gb], gb, lr, with_loss)
         elif world > 1 or args.force_ddp:
-            eng.train_step_ddp(perm[o:o + b], b, lr, world, with_loss)
+            eng.train_step_ddp(perm[o:o + b], b, lr, world, with_loss, defer_tail=True)
         else:
             eng.train_step(perm[o:o + b], b, lr, with_loss)
 
@@ -175,6 +175,8 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(args.warmup + s)
+    if not snp and (world > 1 or args.force_ddp):
+        eng.finish_ddp()                                   # the last step's deferred P piece belongs to the timed work
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -68,6 +68,7 @@ class Engine:
         self.overlap = False
         self._side, self._ev = None, None
         self._n_cu: Optional[int] = None
+        self._pending_ddp: list = []
 
     def _timed(self, name):
         if self.timers is None:
@@ -291,6 +292,14 @@ class Engine:
             check(lib.nadm_adam(ptr(self.small), ptr(self.gsmall), ptr(self.msmall), ptr(self.vsmall), L.n_small, L.n_small,
                                 lr, self.step_count, grad_scale, st), "adam(small)")
 
+    def adam_p_range(self, lo: int, hi: int, lr: float, grad_scale: float, step: int, stream=None) -> None:
+        """Adam + clamp on elements [lo, hi) of the big buffer (a range inside the P matrices) for step count ``step``."""
+        fsz = 4
+        st = _stream() if stream is None else stream
+        check(lib.nadm_adam(C.c_void_p(self.big.data_ptr() + lo * fsz), C.c_void_p(self.gbig.data_ptr() + lo * fsz),
+                            C.c_void_p(self.mbig.data_ptr() + lo * fsz), C.c_void_p(self.vbig.data_ptr() + lo * fsz),
+                            hi - lo, 0, lr, step, grad_scale, st), "adam(P range)")
+
     def adam(self, lr: float, grad_scale: float = 1.0) -> None:
         L, st = self.lay, _stream()
         self.step_count += 1
@@ -341,36 +350,70 @@ class Engine:
         if ev: ev[1].record()
         main.wait_event(ev_side)                              # the next step reads P and the small parameters
 
-    def train_step_ddp(self, idx: torch.Tensor, b: int, lr: float, world: int, with_loss: bool = True) -> None:
+    def train_step_ddp(self, idx: torch.Tensor, b: int, lr: float, world: int, with_loss: bool = True,
+                       defer_tail: bool = False) -> None:
         """Sample-sharded data-parallel step: local gradients -> all-reduce(sum) over RCCL -> Adam with
         grad_scale 1/world (DDP's mean, neural_admixture.py:315-319).  Every piece of the flat gradient buffer is
         all-reduced as soon as the kernel that completes it is enqueued, so the messages run underneath the remaining
         kernels: P of head h under pass 2 of head h+1 (a single head: the part computed by the full rounds of blocks
         under the last round), the last P piece under the MLP backward and pass 3; the small gradients and dV follow as
-        one message after pass 3."""
+        one message after pass 3.
+
+        ``defer_tail``: the next step needs V and the small parameters at once (pass 1, MLP) but P only when its pass 2
+        starts.  The LAST P piece is therefore sent AFTER the small + dV message and its Adam update is applied at the
+        beginning of the next call (or by finish_ddp()), which takes that message off the critical path when the links are
+        the bottleneck.  Same arithmetic, same results; the caller must call finish_ddp() before reading P."""
         import torch.distributed as dist
         L = self.lay
-        works = []
+        works, pieces = [], []
+        deferred = []
 
+        def send(lo, hi):
+            works.append(dist.all_reduce(self.gflat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            pieces.append((lo, hi))
+
+        held = []                                             # defer_tail: the most recent P piece, not yet sent
 
         def reduce_piece(lo, hi):                             # gflat = [small | pad | V | P heads]
-            works.append(dist.all_reduce(self.gflat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            if lo >= self._ns_pad + L.clamp_from and defer_tail:
+                if held:
+                    send(*held.pop())
+                held.append((lo, hi))
+                return
+            send(lo, hi)
+            if held:                                          # first [small | dV] piece is on its way: now the last P piece
+                deferred.append(held[-1])
+                send(*held.pop())
         self.forward(idx, b)
+        self.finish_ddp()                                     # the previous step's deferred P piece: needed from pass 2 on
         # message plan: one per head (a head's all-reduce runs under the next head's pass 2); a single head is cut where
         # its last round of blocks starts (_round_ranges); then the small gradients + dV as one message
         self.backward(idx, b, with_loss, on_grad_ready=reduce_piece, p_parts="rounds" if len(L.ks) == 1 else 1, v_parts=1)
-        # Adam on the P matrices as soon as THEIR messages are in (the small + dV message is the last one on the
-        # communicator, so this update runs underneath it), then the rest
         scale = 1.0 / world
         self.step_count += 1
-        for w in works[:-1]:
-            w.wait()
+        off = self._ns_pad
         ev = self._timed("adam")
-        self.adam_part("P", lr, scale)
-        works[-1].wait()
-        self.adam_part("V", lr, scale)
+        p_start = self._ns_pad + L.clamp_from
+        deferred_set = set(deferred)
+        pending = []
+        for w, (lo, hi) in zip(works, pieces):                # messages complete in the order they were enqueued
+            if (lo, hi) in deferred_set:
+                pending.append((w, lo - off, hi - off, lr, scale, self.step_count))
+                continue
+            w.wait()
+            if lo >= p_start:                                 # a P piece: Adam on it while later messages are still in flight
+                self.adam_p_range(lo - off, hi - off, lr, scale, self.step_count)
+        self.adam_part("V", lr, scale)                        # every [small | dV] piece is in
         self.adam_part("small", lr, scale)
         if ev: ev[1].record()
+        self._pending_ddp = pending
+
+    def finish_ddp(self) -> None:
+        """Apply the Adam update of a P piece whose all-reduce was deferred by train_step_ddp(defer_tail=True)."""
+        for w, lo, hi, lr, scale, step in self._pending_ddp:
+            w.wait()
+            self.adam_p_range(lo, hi, lr, scale, step)
+        self._pending_ddp = []
 
     def infer_q(self, idx: torch.Tensor, b: int) -> List[torch.Tensor]:
         """Encoder-only pass (final Q, neural_admixture.py:369-383; src/inference.py:71-77)."""

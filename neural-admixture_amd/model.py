@@ -193,7 +193,7 @@ class NeuralAdmixture:
             for s in range(0, n_local, b):
                 bb = min(b, n_local - s)
                 if world > 1:
-                    eng.train_step_ddp(order[s:s + bb], bb, self.lr, world, with_loss)
+                    eng.train_step_ddp(order[s:s + bb], bb, self.lr, world, with_loss, defer_tail=True)
                 else:
                     eng.train_step(order[s:s + bb], bb, self.lr, with_loss)
             if with_loss:
@@ -202,6 +202,8 @@ class NeuralAdmixture:
                 if logged and self.master:
                     log.info(f"            Loss in epoch {epoch:3d} on device {dev} is {loss_acc:,.0f}")
 
+        if world > 1:
+            eng.finish_ddp()                               # the last step's deferred P piece
         # ---- final Q: sequential batches of <=1024, encoder only (:369-383) ----
         Qloc = [[] for _ in self.ks_list]
         for s in range(0, n_local, infer_b):

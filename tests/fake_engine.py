@@ -76,6 +76,9 @@ class OracleEngine(Engine):
         for part in ("P", "V", "small"):
             self.adam_part(part, lr, grad_scale)
 
+    def adam_p_range(self, lo, hi, lr, grad_scale, step, stream=None):
+        self._adam_on(self.big[lo:hi], self.gbig[lo:hi], self.mbig[lo:hi], self.vbig[lo:hi], True, lr, grad_scale, step)
+
     def adam_part(self, part, lr, grad_scale=1.0, stream=None):
         t = self.step_count
         bc1, bc2 = 1.0 - O.BETA1 ** t, 1.0 - O.BETA2 ** t
@@ -86,6 +89,11 @@ class OracleEngine(Engine):
             p_, g_, m_, v_, clamp = self.big[:cf], self.gbig[:cf], self.mbig[:cf], self.vbig[:cf], False
         else:
             p_, g_, m_, v_, clamp = self.big[cf:], self.gbig[cf:], self.mbig[cf:], self.vbig[cf:], True
+        self._adam_on(p_, g_, m_, v_, clamp, lr, grad_scale, t)
+
+    @staticmethod
+    def _adam_on(p_, g_, m_, v_, clamp, lr, grad_scale, t):
+        bc1, bc2 = 1.0 - O.BETA1 ** t, 1.0 - O.BETA2 ** t
         g = g_ * np.float32(grad_scale)
         m_.add_((g - m_) * np.float32(1.0 - O.BETA1))
         v_.mul_(np.float32(O.BETA2)).add_(g * g * np.float32(1.0 - O.BETA2))

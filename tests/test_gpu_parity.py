@@ -740,6 +740,25 @@ def test_ddp_step_on_rccl_world1_equals_plain_step():
         torch.cuda.synchronize()
         assert torch.equal(e1.big, e2.big) and torch.equal(e1.small, e2.small)
         assert e1.read_loss() == e2.read_loss()
+        # wide enough for the round-boundary cut of pass 2 (two P messages), multi-head (one message per head), and the
+        # deferred last P piece (sent after [small | dV], applied at the start of the next step / by finish_ddp)
+        for M2, ks2 in ((300_000, [5]), (40_000, [2, 3, 4])):
+            Gw = O.synth_genotypes(12, M2, 3, seed=5)
+            pw = O.make_params(2, (rng.standard_normal((M2, 8)) / 500).astype(np.float32),
+                               rng.uniform(0.1, 0.9, (sum(ks2), M2)).astype(np.float32), 64, ks2)
+            ea, eb, ec = make_engine(Gw, pw, 12), make_engine(Gw, pw, 12), make_engine(Gw, pw, 12)
+            if len(ks2) == 1:
+                assert len(eb._round_ranges(256, 1024, 3)) == 2
+            ix = torch.arange(12, dtype=torch.int32, device=dev)
+            for _ in range(3):
+                ea.train_step(ix, 12, 2e-3, True)
+                eb.train_step_ddp(ix, 12, 2e-3, 1, True)
+                ec.train_step_ddp(ix, 12, 2e-3, 1, True, defer_tail=True)
+                assert len(ec._pending_ddp) == 1
+            ec.finish_ddp()
+            torch.cuda.synchronize()
+            assert torch.equal(ea.big, eb.big) and torch.equal(ea.big, ec.big) and torch.equal(ea.small, ec.small)
+            assert torch.equal(ea.mbig, ec.mbig) and torch.equal(ea.vbig, ec.vbig)
     finally:
         if created:
             dist.destroy_process_group()
