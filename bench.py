@@ -8,7 +8,7 @@ Workload (BASELINE.json configs[3]): synthetic 100k samples x 500k SNPs, K=8, re
 in HBM (12.5 GB; sharded by samples over ranks), batch 800 PER GPU (weak scaling: the reference's
 global-batch-800 semantics would leave 100 rows per GPU at N=8).
 
-    python bench.py --gpus 1 --steps 100 --warmup 10
+    python bench.py --gpus 1 --steps 100 --warmup 30
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -31,7 +31,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=30)   # the first ~25 launches after start-up run ~7 % slow (clock ramp)
     ap.add_argument("--rows", type=int, default=100_000, help="total samples N (sharded over ranks)")
     ap.add_argument("--snps", type=int, default=500_000)
     ap.add_argument("--k", type=int, default=8)
