@@ -40,6 +40,7 @@ def split(idx):
 def cb_only(idx):
     eng.forward(idx, b); eng.backward(idx, b, True, on_grad_ready=lambda lo, hi: None, p_parts="rounds"); eng.adam(2e-3)
 def ddp(idx): eng.train_step_ddp(idx, b, 2e-3, 1, True)
+def ddp_defer(idx): eng.train_step_ddp(idx, b, 2e-3, 1, True, defer_tail=True)
 def ddp_nosplit(idx):
     works = []
     eng.forward(idx, b)
@@ -47,5 +48,5 @@ def ddp_nosplit(idx):
     for w in works: w.wait()
     eng.adam(2e-3)
 for _ in range(2):
-    run("(a) plain", plain); run("(b) pass 2 cut at round boundary", split); run("(c) ddp step, 1-rank group", ddp); run("(d) ddp, pass 2 uncut", ddp_nosplit)
+    run("(a) plain", plain); run("(b) pass 2 cut at round boundary", split); run("(c) ddp step, 1-rank group", ddp); run("(c') ddp step, deferred last P piece", ddp_defer); eng.finish_ddp(); run("(d) ddp, pass 2 uncut", ddp_nosplit)
 dist.destroy_process_group()
