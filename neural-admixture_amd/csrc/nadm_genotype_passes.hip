@@ -848,7 +848,7 @@ constexpr int BF_NTW = NADM_BF_NTW;     // 16-SNP tiles per wave
 constexpr int BF_TS = NADM_BF_TS;       // samples per LDS tile
 
 template <int KP, bool LOSS>
-__global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(KP > 8 ? 2 : NADM_BF_WPE, KP > 8 ? 2 : NADM_BF_WPE))) void decode_bce_bf16_kernel(
+__global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(NADM_BF_WPE, NADM_BF_WPE))) void decode_bce_bf16_kernel(
     const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
     const float* __restrict__ P, const float* __restrict__ Q, int SP,
     float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart) {
