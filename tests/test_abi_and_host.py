@@ -325,3 +325,34 @@ def test_parallel_gmm_fits_equal_sequential_ones():
     assert par is not None
     for k, m in zip(ks, par):
         assert m.shape == (k, 8) and np.array_equal(m, fit_means(X, k, 7))
+
+
+def test_host_converters_property_based():
+    """hypothesis: for ANY small shape and code distribution the host packer and the BED converter agree with the oracle's
+    restatement (ragged N and M, tail bits, pad bytes, the flip rule with missing calls kept at 3)."""
+    import ctypes as C
+    from hypothesis import given, settings, strategies as st
+    from neural_admixture_amd._lib import lib, check, ptr
+    from neural_admixture_amd.layout import ModelLayout
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 23), st.integers(1, 300), st.integers(0, 2 ** 31 - 1), st.floats(0.05, 0.9))
+    def prop(N, M, seed, p0):
+        rng = np.random.default_rng(seed)
+        rest = (1 - p0) / 3
+        Gm = rng.choice(4, size=(N, M), p=[p0, rest, rest, rest]).astype(np.uint8)
+        ld = ModelLayout.row_stride(M)
+        out = torch.full((N, ld), 255, dtype=torch.uint8)
+        check(lib.nadm_pack2bit_host(ptr(torch.from_numpy(Gm)), ptr(out), N, M, ld))
+        ref = O.pack2bit(Gm)
+        assert np.array_equal(out.numpy()[:, :ref.shape[1]], ref) and not out.numpy()[:, ref.shape[1]:].any()
+        assert np.array_equal(O.unpack2bit(out.numpy(), M), Gm)
+        bed = _bed_bytes(Gm)
+        out2 = torch.full((N, ld), 255, dtype=torch.uint8)
+        counts, flipped = (C.c_int64 * 4)(), C.c_int32(0)
+        check(lib.nadm_bed_to_packed(C.c_void_p(bed.ctypes.data), N, M, ptr(out2), ld, counts, 1, C.byref(flipped)))
+        want = np.where(Gm == 3, 3, 2 - Gm.astype(np.int16)).astype(np.uint8) if Gm.mean() >= 1 else Gm
+        assert bool(flipped.value) == bool(Gm.mean() >= 1)
+        assert np.array_equal(O.unpack2bit(out2.numpy(), M), want) and not out2.numpy()[:, (M + 3) // 4:].any()
+        assert [counts[i] for i in range(4)] == [int((Gm == c).sum()) for c in range(4)]
+    prop()
