@@ -1161,9 +1161,11 @@ extern "C" int nadm_bed_to_packed_dev(const uint8_t* bed_dev, int64_t N, int64_t
     hipLaunchKernelGGL(bed_to_packed_kernel, grid, dim3(256), 0, st, bed_dev, N, M, nb, out_dev, ld, (unsigned long long*)counts_dev);
     if (flip_if_mean_ge1) {
         const int64_t mp16 = ((M + 3) / 4 + 15) / 16;
-        dim3 g2((unsigned)((mp16 + 255) / 256 < 64 ? (mp16 + 255) / 256 : 64), (unsigned)N);
-        if (N > 65535) return fail("nadm_bed_to_packed_dev: more than 65535 samples need the flip in row chunks (not implemented)");
-        hipLaunchKernelGGL(bed_flip_kernel, g2, dim3(256), 0, st, out_dev, N, M, ld, (const unsigned long long*)counts_dev, flipped_dev);
+        for (int64_t r0 = 0; r0 < N; r0 += 65535) {           // grid.y limit: rows in chunks
+            const int64_t nr = N - r0 < 65535 ? N - r0 : 65535;
+            dim3 g2((unsigned)((mp16 + 255) / 256 < 64 ? (mp16 + 255) / 256 : 64), (unsigned)nr);
+            hipLaunchKernelGGL(bed_flip_kernel, g2, dim3(256), 0, st, out_dev + r0 * ld, N, M, ld, (const unsigned long long*)counts_dev, flipped_dev);
+        }
     }
     return check_launch("bed_to_packed_dev");
 }

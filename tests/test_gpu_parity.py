@@ -639,7 +639,8 @@ def test_bed_to_packed_on_device_equals_the_host_converter(tmp_path):
     from neural_admixture_amd.io import read_bed_packed
     dev = _dev()
     rng = np.random.default_rng(17)
-    for N, M, p_alt in ((1, 1, 0.2), (5, 3, 0.9), (131, 517, 0.15), (130, 2049, 0.8), (1000, 4100, 0.3)):
+    for N, M, p_alt in ((1, 1, 0.2), (5, 3, 0.9), (131, 517, 0.15), (130, 2049, 0.8), (1000, 4100, 0.3),
+                        (70_001, 67, 0.85)):                                # > 65535 rows with the flip: row-chunked launch
         nb = (N + 3) // 4
         # PLINK codes: 0 = hom A1 (-> 2), 1 = missing (-> 3), 2 = het (-> 1), 3 = hom A2 (-> 0); p_alt steers the mean across 1
         codes = rng.choice(4, size=(M, nb * 4), p=[p_alt * 0.9, 0.03, 0.07, 0.9 - p_alt * 0.9]).astype(np.uint8)
