@@ -43,6 +43,9 @@ def parse():
                     help="dp (default, the reference's scheme): samples sharded, gradient all-reduce; snp: SNPs sharded, every rank "
                          "processes the global batch of batch*N rows on its M/N SNPs, two small all-reduces per step")
     ap.add_argument("--force-ddp", action="store_true", help="single GPU: run the data-parallel step (sub-range launches + RCCL all-reduce on a 1-rank group)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="functional check of the N>1 flow on a ONE-GPU box: all ranks use cuda:0 and gloo carries the tensors "
+                         "(RCCL refuses two ranks per device); not a measurement")
     ap.add_argument("--cpu-rows", type=int, default=2400, help="rows of the same workload used for the bounded CPU baseline")
     return ap.parse_args()
 
@@ -112,6 +115,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         # RCCL prints a version banner through C stdio on stdout; keep stdout for the one JSON line: send fd 1 to stderr
         # while the communicator is created (eager with device_id=) and flush the C buffers before switching back
@@ -120,7 +125,10 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), rank=rank, world_size=world)
+            if args.share_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), rank=rank, world_size=world)
             t_ = torch.zeros(1, device=f"cuda:{local_rank}")
             dist.all_reduce(t_)
             torch.cuda.synchronize()
@@ -193,7 +201,7 @@ def main():
     # dominant kernel = decode_bce.  Algorithmic bytes per launch: one 2-bit pass over the
     # batch (b*M/4) + read P and write dP once (2 * 4*M*K).
     dom = "decode_bce"
-    alg_bytes = b * M / 4 + 2 * 4 * M * K
+    alg_bytes = (gb * eng.M / 4 + 2 * 4 * eng.M * K) if snp else (b * M / 4 + 2 * 4 * M * K)   # snp: global batch x own SNP slice
     traffic = None                                                      # HBM bytes/launch from the committed PMC passes (same workload)
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
@@ -226,6 +234,8 @@ def main():
                               "frac": b * M * args.steps / dt * (4 * 8 + 6 * K) / 1e12 / MFMA_BF16_PEAK_TFLOPS}},
         "loss_last_step": loss_last,
     }
+    if args.share_gpu:
+        out["config"]["share_gpu"] = "all ranks on cuda:0 over gloo: functional check, not a measurement"
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(eng, args, dev)
