@@ -212,12 +212,13 @@ def main():
         pass
     achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
     step_bytes = b * M * (0.75 + 36.0 * (8 + K) / b)                     # SURVEY.md 8d whole-step figure
+    cfg_name = {(100_000, 500_000, 8): "configs[3]", (500_000, 1_000_000, 16): "configs[4]"}.get((args.rows, M, K), "configs[3] shape, resized")
     out = {
         "metric": "genotypes/sec (samples x SNPs / epoch-sec) at K=%d" % K,
         "value": world * b * M * args.steps / dt, "unit": "genotypes/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[3]: synthetic {args.rows} samples x {M} SNPs, K={K}, 2-bit packed resident in HBM, "
+        "config": {"workload": f"{cfg_name}: synthetic {args.rows} samples x {M} SNPs, K={K}, 2-bit packed resident in HBM, "
                                f"{'SNP' if snp else 'sample'}-sharded over {world} GPU(s), batch {b}/GPU, hidden {args.hidden}, n_components 8, "
                                f"loss value {'every step' if with_loss else 'skipped'}",
                    "global_batch": b * world, "parallelism": f"{args.parallelism}{world}"},

@@ -812,3 +812,53 @@ def test_world2_real_engine_on_one_gpu_matches_reference_ddp(tmp_path, paralleli
     assert np.abs(r["V"] - d["V"]).max() < 1e-4
     if parallelism == "dp":
         assert np.allclose(r["losses"], d["losses_rank0"].reshape(int(d["epochs"]), -1).sum(1), rtol=1e-5)
+
+
+def test_rows_at_offsets_beyond_4_gib_in_a_resident_matrix_of_configs4_size():
+    """BASELINE configs[4]: 500k samples x 1M SNPs stay packed in HBM -- 125 GB, which ONE MI355X holds.  Rows of such a
+    matrix start at byte offsets far beyond 2^32; a step that gathers rows scattered over the whole allocation (first
+    row, the rows either side of the 2^31- and 2^32-byte marks, the last row) must give bit-identical results to the same
+    rows compacted into a small matrix.  Only the gathered rows are written; the rest of the allocation is never read."""
+    import neural_admixture_amd as na
+    from neural_admixture_amd._lib import lib, check, ptr
+    dev = _dev()
+    N, M, K, b = 500_000, 1_000_000, 16, 64
+    e_big, e_small = na.Engine(M, 8, 128, [K], dev, b), na.Engine(M, 8, 128, [K], dev, b)
+    free, _total = torch.cuda.mem_get_info()
+    if free < N * e_big.ld + (8 << 30):
+        pytest.skip("needs 125 GB of free HBM")
+    ld = e_big.ld
+    marks = [0, 1, (1 << 31) // ld, (1 << 31) // ld + 1, (1 << 32) // ld, (1 << 32) // ld + 1, (1 << 36) // ld + 1, N - 2, N - 1]
+    rng = np.random.default_rng(8)
+    rows = np.unique(np.concatenate([marks, rng.integers(0, N, size=b - len(marks))]))
+    while rows.size < b:
+        rows = np.unique(np.concatenate([rows, rng.integers(0, N, size=b - rows.size)]))
+    rows = rng.permutation(rows).astype(np.int64)                       # gather order is not sorted either
+    assert int(rows.max()) * ld > (1 << 36)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    Qt = torch.distributions.Dirichlet(torch.full((K,), 0.3)).sample((b,)).float().to(dev)
+    Fq = (0.5 * torch.rand(K, M, generator=g)).clamp(0.005, 0.5).to(dev)
+    big = torch.empty((N, ld), dtype=torch.uint8, device=dev)
+    small = torch.empty((b, ld), dtype=torch.uint8, device=dev)
+    for j, r in enumerate(rows):
+        check(lib.nadm_synth_packed(ptr(big[int(r):]), 1, int(r), M, ld, ptr(Qt[j:]), ptr(Fq), K, 0.01, 99, None))
+        check(lib.nadm_synth_packed(ptr(small[j:]), 1, int(r), M, ld, ptr(Qt[j:]), ptr(Fq), K, 0.01, 99, None))
+    torch.cuda.synchronize()
+    assert torch.equal(big[torch.from_numpy(rows).to(dev)], small)
+    V = (rng.standard_normal((M, 8)) / 1000).astype(np.float32)
+    P = rng.uniform(0.05, 0.95, (K, M)).astype(np.float32)
+    from neural_admixture_amd.model import init_encoder_weights
+    sm = init_encoder_weights(5, 8, 128, [K])
+    for e, xp in ((e_big, big), (e_small, small)):
+        e.set_packed(xp)
+        e.load_params(V, P, sm)
+    ib = torch.from_numpy(rows.astype(np.int32)).to(dev)
+    isml = torch.arange(b, dtype=torch.int32, device=dev)
+    for _ in range(2):
+        e_big.train_step(ib, b, 2e-3, True)
+        e_small.train_step(isml, b, 2e-3, True)
+    torch.cuda.synchronize()
+    assert torch.equal(e_big.big, e_small.big) and torch.equal(e_big.small, e_small.small)
+    assert e_big.read_loss() == e_small.read_loss()
+    qa, qb = e_big.infer_q(ib, b)[0], e_small.infer_q(isml, b)[0]
+    assert torch.equal(qa, qb) and abs(float(qa.sum()) - b) < 1e-3
