@@ -43,6 +43,9 @@ def parse():
                     help="dp (default, the reference's scheme): samples sharded, gradient all-reduce; snp: SNPs sharded, every rank "
                          "processes the global batch of batch*N rows on its M/N SNPs, two small all-reduces per step")
     ap.add_argument("--force-ddp", action="store_true", help="single GPU: run the data-parallel step (sub-range launches + RCCL all-reduce on a 1-rank group)")
+    ap.add_argument("--time-kernels", choices=("dominant", "all"), default="dominant",
+                    help="HIP events inside the timed region around the dominant kernel only (default: two event records per step) "
+                         "or around every kernel of the step (kernel_ms table; the records cost ~10 %% of the step)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="functional check of the N>1 flow on a ONE-GPU box: all ranks use cuda:0 and gloo carries the tensors "
                          "(RCCL refuses two ranks per device); not a measurement")
@@ -177,6 +180,7 @@ def main():
     for s in range(args.warmup):
         step(s)
     eng.timers = {}
+    eng.timed_names = None if args.time_kernels == "all" else {"decode_bce"}
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -198,6 +202,19 @@ def main():
     assert np.isfinite(loss_last) or not with_loss
 
     kms = {name: float(np.mean([a.elapsed_time(c) for a, c in evs])) for name, evs in timers.items()}
+    if args.time_kernels == "dominant":
+        # the other kernels of the step, for the kernel_ms table only: a short pass AFTER the timed region with events around
+        # every kernel (those records cost ~4 % of the step, which is why the timed region carries only the dominant kernel's)
+        eng.timers, eng.timed_names = {}, None
+        for s in range(min(args.steps, 20)):
+            step(args.warmup + args.steps + s)
+        if not snp and (world > 1 or args.force_ddp):
+            eng.finish_ddp()
+        torch.cuda.synchronize()
+        extra, eng.timers = eng.timers, None
+        for name, evs in extra.items():
+            if name != "decode_bce":
+                kms[name] = float(np.mean([a.elapsed_time(c) for a, c in evs]))
     # dominant kernel = decode_bce.  Algorithmic bytes per launch: one 2-bit pass over the
     # batch (b*M/4) + read P and write dP once (2 * 4*M*K).
     dom = "decode_bce"

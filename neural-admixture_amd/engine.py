@@ -61,7 +61,8 @@ class Engine:
         self.xp: Optional[torch.Tensor] = None          # packed genotypes [rows, ld]
         self.step_count = 0
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event) on the launch stream
-        self.timers: Optional[dict] = None
+        self.timers: Optional[dict] = None                    # {name: [(start, end) HIP events]} when a dict (bench.py)
+        self.timed_names = None                               # restrict the timers to these kernel names (None = all)
         # train_step(): optional second stream for the work that does not depend on pass 3.  Measured on MI355X (b=800,
         # M=500k, K=8): the ~35 us of hidden kernels are cancelled by the cross-stream event waits (0.569 vs 0.563 ms/step),
         # so it is off by default.
@@ -71,7 +72,7 @@ class Engine:
         self._pending_ddp: list = []
 
     def _timed(self, name):
-        if self.timers is None:
+        if self.timers is None or (self.timed_names is not None and name not in self.timed_names):
             return None
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         self.timers.setdefault(name, []).append(ev)

@@ -116,6 +116,17 @@ def hudsons_fst(p1: torch.Tensor, p2: torch.Tensor) -> float:
     return (num / den).item()
 
 
+def epoch_order(generator: torch.Generator, n: int) -> torch.Tensor:
+    """The sample order ``iter(RandomSampler(range(n), generator=generator))`` yields for one epoch, as an int32 tensor,
+    leaving ``generator`` in the state the sampler leaves it in: torch's sampler draws ``randperm(n)`` for the epoch and
+    then a SECOND ``randperm(n)`` for the empty ``[:num_samples % n]`` tail (utils/data/sampler.py, RandomSampler.__iter__),
+    so every epoch advances the stream by two draws.  Iterating the sampler object itself costs 60-120 ms per epoch at
+    n = 100k (one Python ``yield`` per sample) -- more than the 57 ms the GPU needs for that epoch."""
+    perm = torch.randperm(n, generator=generator)
+    torch.randperm(n, generator=generator)
+    return perm.to(torch.int32)
+
+
 class NeuralAdmixture:
     """Trainer mirror (constructor signature of neural_admixture.py:248-249)."""
     engine_cls = Engine          # tests swap in an oracle-backed double to run the DDP orchestration on gloo
@@ -148,7 +159,6 @@ class NeuralAdmixture:
     def launch_training(self, P, data, hidden_size, num_features, V, M, N, pops=None):
         """P torch [sum(ks), M]; data uint8 CPU [N,M] (unpacked; this method packs the rank's rows);
         V torch [M,C].  Returns (Qs, Ps, model) like neural_admixture.py:392,530 (numpy lists on master)."""
-        from torch.utils.data import RandomSampler
         from torch.utils.data.distributed import DistributedSampler
         world, rank = self._world()
         dev = self.device
@@ -171,7 +181,6 @@ class NeuralAdmixture:
             eng.pack_from_host(data)
             n_local = N
             generator = torch.Generator().manual_seed(self.seed)     # neural_admixture.py:283
-            sampler = RandomSampler(range(N), generator=generator)
         if pops is not None:                               # supervised mode (:352-356, :434-474): labels follow the rows
             y = torch.as_tensor(pops).detach().cpu().numpy().astype(np.int64)
             eng.set_labels(y if shard is None else y[shard], self.ks_list[0], self.supervised_loss_weight)
@@ -189,7 +198,7 @@ class NeuralAdmixture:
             if world > 1:
                 order = seq                                # rows are stored in shard order
             else:
-                order = torch.as_tensor(np.asarray(list(iter(sampler)), dtype=np.int32)).to(dev)
+                order = epoch_order(generator, N).to(dev)
             for s in range(0, n_local, b):
                 bb = min(b, n_local - s)
                 if world > 1:

@@ -46,7 +46,8 @@ def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_comp
     """P_init [sum(ks), M] = clip(GMM means @ V, 5e-6, 1-5e-6) in the PCA subspace (train.py:49-68).
     Note the projection keeps missing (3) as 1.5, exactly like the reference (train.py:52).
     ``data_np``: uint8 [N,M] array or an io.PackedGenotypes.  With a GPU ``device`` and n_components <= 8 the
-    projection runs on the GPU (pca_project_gpu); otherwise on the host, 1024 rows at a time like the reference."""
+    projection runs on the GPU (pca_project_gpu); otherwise on the host, 1024 rows at a time like the reference.
+    The mixture fit is scikit-learn's on a CPU device and its restatement in device ops (_gmm_em.py) on a GPU."""
     N = data_np.shape[0]
     if device is not None and device.type == "cuda" and n_components <= 8:
         X_pca = pca_project_gpu(data_np, V_CM, device)
@@ -57,7 +58,16 @@ def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_comp
             X_pca[i:i + 1024] = (rows(i, min(N, i + 1024)).astype(np.float32) / 2) @ V_CM.T
     X_pca = X_pca.astype("float64")
     ks = [K] if K is not None else list(range(min_k, max_k + 1))
-    means = _gmm_means_parallel(X_pca, ks, seed) if len(ks) > 2 else None
+    import os
+    how = os.environ.get("NADM_GMM", "auto")                    # "em" | "sklearn" force one; both give the same means (1e-13)
+    on_gpu = device is not None and device.type == "cuda"
+    # device EM: ~0.6 ms per iteration whatever N (launch-bound); library fit: proportional to N, and several K can run as
+    # concurrent child processes -> the device wins for one or two K and for large N, the children for many K on few samples
+    if how == "em" or (how == "auto" and on_gpu and (len(ks) <= 2 or N > 20_000)):
+        from ._gmm_em import fit_means as fit_means_device
+        means = [fit_means_device(X_pca, k, seed, device) for k in ks]
+    else:
+        means = _gmm_means_parallel(X_pca, ks, seed) if len(ks) > 2 else None
     if means is None:
         from ._gmm_fit import fit_means
         means = [fit_means(X_pca, k, seed) for k in ks]

@@ -356,3 +356,37 @@ def test_host_converters_property_based():
         assert np.array_equal(O.unpack2bit(out2.numpy(), M), want) and not out2.numpy()[:, (M + 3) // 4:].any()
         assert [counts[i] for i in range(4)] == [int((Gm == c).sum()) for c in range(4)]
     prop()
+
+
+def test_device_em_restatement_gives_the_library_mixture_means():
+    """_gmm_em.fit_means (float64 tensor ops; used when the device is a GPU) against sklearn's GaussianMixture with the
+    reference's arguments (train.py:61): same k-means++ picks, same EM, same restart selection -> means equal to 1e-10."""
+    from neural_admixture_amd._gmm_em import fit_means as em
+    from neural_admixture_amd._gmm_fit import fit_means as sk
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)                               # tiny ops: a wide CPU thread pool only adds overhead
+    try:
+        rng = np.random.default_rng(0)
+        for N, k, seed, sep in ((600, 3, 42, 3.0), (1500, 7, 42, 1.0), (200, 2, 3, 0.1)):
+            cent = rng.standard_normal((k, 8)) * sep
+            X = (rng.dirichlet(np.full(k, 0.5), N) @ cent + 0.3 * rng.standard_normal((N, 8))).astype(np.float32).astype(np.float64)
+            assert np.abs(em(X, k, seed) - sk(X, k, seed)).max() < 1e-10
+        with pytest.raises(ValueError):
+            em(np.zeros((2, 8)), 3, 0)
+    finally:
+        torch.set_num_threads(nt)
+
+
+def test_epoch_order_is_the_random_sampler_sequence():
+    """model.epoch_order replaces iterating torch's RandomSampler (loaders.py:29-31): same indices, same generator state
+    after every epoch (the sampler's discarded second draw included)."""
+    from torch.utils.data import RandomSampler
+    from neural_admixture_amd.model import epoch_order
+    for n in (1, 7, 600, 2504):
+        g1, g2 = torch.Generator().manual_seed(42), torch.Generator().manual_seed(42)
+        sampler = RandomSampler(range(n), generator=g1)
+        for _ in range(4):
+            want = np.asarray(list(iter(sampler)), dtype=np.int32)
+            got = epoch_order(g2, n)
+            assert got.dtype == torch.int32 and np.array_equal(got.numpy(), want)
+            assert torch.equal(g1.get_state(), g2.get_state())

@@ -862,3 +862,28 @@ def test_rows_at_offsets_beyond_4_gib_in_a_resident_matrix_of_configs4_size():
     assert e_big.read_loss() == e_small.read_loss()
     qa, qb = e_big.infer_q(ib, b)[0], e_small.infer_q(isml, b)[0]
     assert torch.equal(qa, qb) and abs(float(qa.sum()) - b) < 1e-3
+
+
+def test_mixture_means_on_the_gpu_equal_the_library_fit():
+    """train.gmm_p_init on a GPU device fits the mixture with _gmm_em (float64 device ops); NADM_GMM=sklearn selects the
+    library fit the reference calls (train.py:61).  Same means -> same P init."""
+    from neural_admixture_amd._gmm_em import fit_means as em
+    from neural_admixture_amd._gmm_fit import fit_means as sk
+    from neural_admixture_amd.train import gmm_p_init
+    dev = _dev()
+    rng = np.random.default_rng(4)
+    for N, k, seed in ((4000, 8, 42), (900, 3, 7)):
+        cent = rng.standard_normal((k, 8))
+        X = (rng.dirichlet(np.full(k, 0.4), N) @ cent + 0.25 * rng.standard_normal((N, 8))).astype(np.float32).astype(np.float64)
+        assert np.abs(em(X, k, seed, dev) - sk(X, k, seed)).max() < 1e-9
+    Gm = O.synth_genotypes(300, 4000, 3, seed=2)
+    V = np.linalg.svd(Gm.astype(np.float32), full_matrices=False)[2][:8].astype(np.float32)
+    res = {}
+    for how in ("em", "sklearn"):
+        os.environ["NADM_GMM"] = how
+        try:
+            res[how] = gmm_p_init(Gm, V, None, 2, 4, 8, 42, dev)
+        finally:
+            del os.environ["NADM_GMM"]
+    a, b = res["em"], res["sklearn"]
+    assert a.shape == b.shape == (9, 4000) and np.abs(a - b).max() < 1e-6

@@ -19,6 +19,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "c2"
     epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 250
+    if os.environ.get("NADM_LOG"):                     # timestamps of the reference-style progress messages on stderr
+        import logging
+        logging.basicConfig(format="%(asctime)s.%(msecs)03d %(message)s", datefmt="%H:%M:%S", level=logging.INFO, stream=sys.stderr)
     import neural_admixture_amd as na
     from neural_admixture_amd._lib import lib, check, ptr
     from neural_admixture_amd.io import PackedGenotypes, write_outputs, save_model
