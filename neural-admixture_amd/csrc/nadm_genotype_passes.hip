@@ -132,11 +132,24 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int EM_WAVES = 8;
 constexpr int EM_SLICE = 256;                         // SNPs per wave
 constexpr int EM_CHUNK_SNPS = EM_WAVES * EM_SLICE;    // 2048
-constexpr int EM_TILES_PER_BLOCK = 28;                // upper bound of 16-sample tiles per block (grid.y splits the batch)
+constexpr int EM_TILES_PER_BLOCK = 52;                // upper bound of 16-sample tiles per block (grid.y splits the batch)
 #ifndef NADM_EM_D
 #define NADM_EM_D 4
 #endif
 constexpr int EM_D = NADM_EM_D;                       // X tiles in flight per lane
+
+// byte `sel` of w holds two nibbles 00cc: -> the bf16 pair (c_lo/2, c_hi/2) in one instruction
+__device__ __forceinline__ uint32_t fp4_bf16_pair(const uint32_t w, const int sel) {
+    typedef __bf16 bf16x2_native __attribute__((ext_vector_type(2)));
+    bf16x2_native r;
+    switch (sel) {
+        case 0: r = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, 1.0f, 0); break;
+        case 1: r = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, 1.0f, 1); break;
+        case 2: r = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, 1.0f, 2); break;
+        default: r = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, 1.0f, 3); break;
+    }
+    return __builtin_bit_cast(uint32_t, r);
+}
 
 __device__ __forceinline__ uint32_t bf16_trunc_bits(float v) { return __float_as_uint(v) & 0xFFFF0000u; }
 
@@ -146,7 +159,6 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
                                                               const float* __restrict__ V, float* __restrict__ zpart, int tiles_per_block,
                                                               uint32_t missing_bf16) {
     static_assert(CP <= 8, "two MFMA column groups hold hi|mid and lo|0");
-    __shared__ uint32_t s_lut[16];
     static_assert(EM_D * 128 == 64 * EM_WAVES, "one output element per thread in the cross-wave combine");
     __shared__ __attribute__((aligned(16))) float s_z[2][EM_WAVES][EM_D][16 * 8];
     __shared__ float s_out[EM_TILES_PER_BLOCK][16 * 8];
@@ -156,14 +168,10 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
     const int64_t slice0 = chunk * EM_CHUNK_SNPS + wave * EM_SLICE;
     const int tile_begin = blockIdx.y * tiles_per_block;
     const int tile_end = min((b + 15) / 16, tile_begin + tiles_per_block);
-    if (tid < 16) {
-        const uint32_t lo = tid & 3, hi = tid >> 2;
-        // bf16 of code/2; a missing call (3) is 0 in the model (neural_admixture.py:170) and 1.5 = 0x3FC0 in the
-        // init-time PCA projection (train.py:52), selected by the caller
-        const uint32_t blo = lo == 1 ? 0x3F00u : (lo == 2 ? 0x3F80u : (lo == 3 ? missing_bf16 : 0u));
-        const uint32_t bhi = hi == 1 ? 0x3F00u : (hi == 2 ? 0x3F80u : (hi == 3 ? missing_bf16 : 0u));
-        s_lut[tid] = blo | (bhi << 16);
-    }
+    // A missing call (code 3) is 0 in the model (neural_admixture.py:170) and 1.5 = bf16 0x3FC0 in the init-time PCA
+    // projection (train.py:52), selected by the caller.  FP4 (E2M1) reads the nibble 00cc as c/2 -- 0, 0.5, 1, 1.5 -- so
+    // the 1.5 case is the conversion's native result and the 0 case clears both bits of every code 3 first.
+    const uint32_t kmiss = missing_bf16 == 0u ? 0x55555555u : 0u;
     // ---- B operands: V rows of this wave's slice, split hi/mid/lo, for the 8 k-steps ----
     // k-step s, lane (q, j): rows kk = 8q + e  <->  SNP slice0 + 64q + 8s + e ; column j: c = j & 7
     bf16x8 b1[8], b2[8];
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
                 uint32_t p1[2], p2[2];
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
-                    const int64_t m = slice0 + 64 * q + 8 * s8 + 2 * d + hh;
+                    const int64_t m = slice0 + 64 * q + 8 * s8 + 4 * (d & 1) + 2 * hh + (d >> 1);   // element order of the A operand
                     const float v = (m < M && c < CP) ? V[m * CP + c] : 0.f;
                     const uint32_t hi = bf16_trunc_bits(v);
                     const float r1 = v - __uint_as_float(hi);
@@ -232,14 +240,22 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
                 const uint32_t raw[4] = {ok ? cur.x : 0u, ok ? cur.y : 0u, ok ? cur.z : 0u, ok ? cur.w : 0u};
                 f32x4_t d1 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, d2 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s8 = 0; s8 < 8; ++s8) {
-                    const uint32_t h16 = (raw[s8 >> 1] >> (16 * (s8 & 1))) & 0xFFFFu;
-                    uint32_t aw[4];
+                for (int w = 0; w < 4; ++w) {
+                    // 16 genotypes of the word -> two A operands.  Nibble-spread the 2-bit codes (even SNPs, odd SNPs), then
+                    // v_cvt_scalef32_pk_bf16_fp4 turns one byte = two nibbles into a bf16 pair: 8 + 16 VALU instructions
+                    // per 16 genotypes, no LDS table.  Element order within a k-step: SNPs 0 2 4 6 1 3 5 7 (B matches).
+                    uint32_t r = raw[w];
+                    const uint32_t m3 = r & (r >> 1) & kmiss;                 // low bit of every code that is 3
+                    r ^= m3 | (m3 << 1);
+                    const uint32_t ev = r & 0x33333333u, od = (r >> 2) & 0x33333333u;
 #pragma unroll
-                    for (int p4 = 0; p4 < 4; ++p4) aw[p4] = s_lut[(h16 >> (4 * p4)) & 15u];
-                    const bf16x8 av = __builtin_bit_cast(bf16x8, make_uint4(aw[0], aw[1], aw[2], aw[3]));
-                    d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1[s8], d1, 0, 0, 0);
-                    d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b2[s8], d2, 0, 0, 0);
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int s8 = 2 * w + hf;
+                        const bf16x8 av = __builtin_bit_cast(bf16x8, make_uint4(fp4_bf16_pair(ev, 2 * hf), fp4_bf16_pair(ev, 2 * hf + 1),
+                                                                                fp4_bf16_pair(od, 2 * hf), fp4_bf16_pair(od, 2 * hf + 1)));
+                        d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b1[s8], d1, 0, 0, 0);
+                        d2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b2[s8], d2, 0, 0, 0);
+                    }
                 }
                 // D rows = samples 4q + r, column = i: fold [hi | mid] + [lo | 0] -> columns 0..7
 #pragma unroll
@@ -1449,10 +1465,11 @@ static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
     if (CP <= 8 && use_mfma_encode()) {
         // Every block first splits its 2048 x CP slice of V into bf16 operands (about as much work as 12 sample tiles), so
         // a block should see many tiles; but ~2 blocks per CU are needed to fill the chip.  grid.y = as few batch splits as
-        // give >= 512 blocks (never fewer than 4 tiles per block, at most EM_TILES_PER_BLOCK).
+        // give >= 480 blocks (never fewer than 4 tiles per block, at most EM_TILES_PER_BLOCK).  At M = 500k, b = 800:
+        // grid.y = 1 / 2 / 3 / 4 -> 45.1 / 40.7 / 44.5 / 46.1 us.
         const int64_t chunks = nadm_encode_chunks(M);
         const int ntiles = (b + 15) / 16;
-        int64_t gy = (512 + chunks - 1) / chunks;
+        int64_t gy = (480 + chunks - 1) / chunks;
         if (gy > (ntiles + 3) / 4) gy = (ntiles + 3) / 4;
         if (gy < 1) gy = 1;
         int tpb = (int)((ntiles + gy - 1) / gy);
