@@ -1195,8 +1195,9 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
 //     1. the tile loader reads 4 rows x 4 bytes per thread, transposes the 4x4 bytes with v_perm and
 //        stores the tile SNP-byte-major in LDS, so a lane gets 4 consecutive samples of its byte
 //        column with one ds_read_b32;
-//     2. per 2-bit field j the 4 codes are gathered into one byte with two shift-or steps and a
-//        256-entry LDS table turns that byte into 4 bf16 values (missing -> 0): half a B operand.
+//     2. per 2-bit field j the codes of two consecutive samples are put into the two nibbles of a byte and
+//        v_cvt_scalef32_pk_bf16_fp4 turns that byte into a bf16 pair (nibble 00cc = c/2 in FP4): four such
+//        conversions per B operand, no lookup table.
 //   One byte column feeds 4 MFMA column sets (fields j = 0..3).  dZ operands are split once per
 //   32-sample tile by one wave and shared through LDS.  block = 4 waves x 128 SNPs; tiles are
 //   double-buffered, global loads for tile t+1 are issued before tile t is computed.
@@ -1219,16 +1220,14 @@ __global__ __launch_bounds__(256) void encode_bwd_mfma_kernel(const uint8_t* __r
     static_assert(CP <= 8, "hi|mid and lo|0 share the 16 MFMA rows");
     __shared__ __attribute__((aligned(16))) uint8_t s_xt[2][EB_COLS * EB_CS];
     __shared__ __attribute__((aligned(16))) uint4 s_a[2][2][64];
-    __shared__ __attribute__((aligned(8))) uint2 s_lut[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mcol = lane & 15, q = lane >> 4;
     const int64_t chunk = blockIdx.x;
     const int64_t byte0 = chunk * EB_COLS;
-    {   // byte of four 2-bit codes -> 4 bf16 (x = code/2; missing -> 0 in the model, 1.5 in the init-time products)
-        auto bf = [missing_bf16](uint32_t c) -> uint32_t { return c == 1 ? 0x3F00u : (c == 2 ? 0x3F80u : (c == 3 ? missing_bf16 : 0u)); };
-        const uint32_t t = tid;
-        s_lut[tid] = make_uint2(bf(t & 3) | (bf((t >> 2) & 3) << 16), bf((t >> 4) & 3) | (bf(t >> 6) << 16));
-    }
+    // x = code/2; a missing call (code 3) is 0 in the model and 1.5 in the init-time products.  The codes become bf16
+    // through v_cvt_scalef32_pk_bf16_fp4 (nibble 00cc = c/2 in FP4, so 1.5 is the native value of code 3); for the model
+    // the loader clears both bits of every code 3 before the tile goes to LDS.
+    const uint32_t kmiss = missing_bf16 == 0u ? 0x55555555u : 0u;
     // ---- loader mapping: thread -> 4 rows x 4 byte columns ----
     const int cg = tid & 31, rg = tid >> 5;                   // byte columns 4cg..4cg+3, rows 4rg..4rg+3 of the tile
     const int64_t loff = byte0 + 4 * cg;
@@ -1256,7 +1255,11 @@ __global__ __launch_bounds__(256) void encode_bwd_mfma_kernel(const uint8_t* __r
     auto commit = [&](int buf, int i0, const uint32_t (&xs)[4], const float zs) {
         uint32_t d[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) d[k] = (lcol_ok && i0 + 4 * rg + k < b) ? xs[k] : 0u;
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t r = (lcol_ok && i0 + 4 * rg + k < b) ? xs[k] : 0u;
+            const uint32_t m3 = r & (r >> 1) & kmiss;
+            d[k] = r ^ (m3 | (m3 << 1));
+        }
         // 4x4 byte transpose: e[c] = byte c of rows 0..3
         const uint32_t t01l = __builtin_amdgcn_perm(d[1], d[0], 0x05010400u);   // d0.b0 d1.b0 d0.b1 d1.b1
         const uint32_t t01h = __builtin_amdgcn_perm(d[1], d[0], 0x07030602u);   // d0.b2 d1.b2 d0.b3 d1.b3
@@ -1327,11 +1330,11 @@ __global__ __launch_bounds__(256) void encode_bwd_mfma_kernel(const uint8_t* __r
                     const uint32_t w1 = *reinterpret_cast<const uint32_t*>(colp + 4);    // samples 8q+4..8q+7
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        uint32_t t0 = (w0 >> (2 * j)) & 0x03030303u, t1 = (w1 >> (2 * j)) & 0x03030303u;
-                        t0 |= t0 >> 6; t1 |= t1 >> 6;
-                        t0 |= t0 >> 12; t1 |= t1 >> 12;
-                        const uint2 lo = s_lut[t0 & 0xFFu], hi = s_lut[t1 & 0xFFu];
-                        const bf16x8 bv = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+                        // field j of samples (s, s+1) into the two nibbles of bytes 0 and 2, then one conversion per pair
+                        const uint32_t p0 = ((w0 >> (2 * j)) & 0x00030003u) | ((w0 >> (2 * j + 4)) & 0x00300030u);
+                        const uint32_t p1 = ((w1 >> (2 * j)) & 0x00030003u) | ((w1 >> (2 * j + 4)) & 0x00300030u);
+                        const bf16x8 bv = __builtin_bit_cast(bf16x8, make_uint4(fp4_bf16_pair(p0, 0), fp4_bf16_pair(p0, 2),
+                                                                                fp4_bf16_pair(p1, 0), fp4_bf16_pair(p1, 2)));
                         acc1[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bv, acc1[g][j], 0, 0, 0);
                         acc2[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bv, acc2[g][j], 0, 0, 0);
                     }
