@@ -40,7 +40,7 @@ extern "C" {
 
 #define NADM_MAX_HEADS 32
 #define NADM_MAX_K 64
-#define NADM_ABI_VERSION 2   /* 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
+#define NADM_ABI_VERSION 3   /* 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
@@ -133,6 +133,15 @@ int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const float* zpart,
 int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                     const float* P, int32_t kp, const float* Q, int32_t SP,
                     float* dP, float* dqpart, float* losspart, int32_t with_loss, void* stream);
+
+/* The same pass with a by-product for pass 3: the batch's gathered rows written back to back into xg [b, ld] (row i of
+ * the batch -> row i of xg, same byte columns, same row stride; an SNP sub-range launch passes xg + m0/4 like xp).  Pass 3
+ * (nadm_encode_bwd) can then be given xg with idx = 0,1,..,b-1: it reads one compact 100 MB region instead of rows
+ * scattered over the resident matrix (at 12.5 GB resident the scattered reads cost it 13 % translation-cache misses and
+ * 16 us of 68).  No reference counterpart: the reference re-gathers the unpacked batch per pass (utils.pyx:43-67). */
+int nadm_decode_bce_gather(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                           const float* P, int32_t kp, const float* Q, int32_t SP,
+                           float* dP, float* dqpart, float* losspart, int32_t with_loss, uint8_t* xg, void* stream);
 
 /* ---- a11: MLP backward (softmax, Linear, ReLU, RMSNorm) ---------------------------------- */
 /* Reduces dqpart (the heads' slabs laid back to back in head order, head h holding

@@ -867,7 +867,7 @@ template <int KP, bool LOSS>
 __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(NADM_BF_WPE, NADM_BF_WPE))) void decode_bce_bf16_kernel(
     const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
     const float* __restrict__ P, const float* __restrict__ Q, int SP,
-    float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart) {
+    float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart, uint8_t* __restrict__ xg) {
     static_assert(KP <= 16, "one or two 8-wide k slots");
     // W (KP 9..16): k spans two 8-wide MFMA slots.  The pieces can no longer share an MFMA's 16 rows / columns, so
     //   R^T  = [Ph Ph' Ph Ph'].[Qh Qh' Qm Qm'] + [Pm Pm' Pm Pm'].[Qh Qh' Qm Qm'] + [Ph Ph' Pl Pl'].[Ql Ql' Qh Qh']   (X' = k 8..15)
@@ -987,6 +987,10 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     auto commit = [&](int i0) {
         const bool ok = pcol_ok && (i0 + pr < b);
         if (has_piece) *reinterpret_cast<uint4*>(&s_x[pr * RS + pc16 * 16]) = ok ? stage : make_uint4(0, 0, 0, 0);
+        // by-product for pass 3: the gathered rows written back to back (row i of the batch -> row i of xg).  Pass 3 then
+        // reads 100 MB in one place instead of 800 rows scattered over the resident matrix, which at 12.5 GB costs it 13 %
+        // misses in the per-CU translation cache (UTCL1) and 16 us; here the store is one instruction per tile and thread.
+        if (xg != nullptr && has_piece && ok) *reinterpret_cast<uint4*>(xg + (int64_t)(i0 + pr) * ld + poff) = stage;
         if (!has_q) return;
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
@@ -1381,19 +1385,36 @@ static bool use_bf16_decode() {
     return v;
 }
 
+// rows idx[0..b) of xp, the byte columns that hold SNPs [0, M) -> rows 0..b-1 of xg (same row stride): what the bf16 pass-2
+// kernel writes as a by-product, as a kernel of its own for the K > 16 / A-B-reference variants of pass 2
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx,
+                                                          int b, int64_t pieces, uint8_t* __restrict__ xg) {
+    const int64_t row = idx[blockIdx.y];
+    for (int64_t p = blockIdx.x * 256 + threadIdx.x; p < pieces; p += (int64_t)gridDim.x * 256)
+        *reinterpret_cast<uint4*>(xg + (int64_t)blockIdx.y * ld + p * 16) = *reinterpret_cast<const uint4*>(xp + row * ld + p * 16);
+}
+
+static int launch_gather_rows(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, uint8_t* xg, hipStream_t st) {
+    const int64_t pieces = (M + 63) / 64;                          // 16-byte pieces that hold SNPs below M (ld is a multiple of 16)
+    int64_t gx = (pieces + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)gx, (unsigned)b), dim3(256), 0, st, xp, ld, idx, b, pieces, xg);
+    return check_launch("gather_rows");
+}
+
 template <int KP>
 static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, const float* P,
                               const float* Q, int SP, float* dP, float* dqpart, float* losspart, int with_loss,
-                              hipStream_t st) {
+                              hipStream_t st, uint8_t* xg) {
     if constexpr (KP <= 16) {
         if (use_bf16_decode()) {
             static_assert(mf_chunk_snps(KP) == BF_WAVES * 16 * BF_NTW, "same chunking as the f32 MFMA kernel");
             const int64_t chunks = (M + mf_chunk_snps(KP) - 1) / mf_chunk_snps(KP);
             dim3 grid((unsigned)chunks), block(64 * BF_WAVES);
             if (with_loss)
-                hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
+                hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg);
             else
-                hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
+                hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg);
             return check_launch("decode_bce_bf16");
         }
     }
@@ -1403,13 +1424,14 @@ static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx,
         hipLaunchKernelGGL((decode_bce_mfma_kernel<KP, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
     else
         hipLaunchKernelGGL((decode_bce_mfma_kernel<KP, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
-    return check_launch("decode_bce_mfma");
+    if (check_launch("decode_bce_mfma")) return 1;
+    return xg ? launch_gather_rows(xp, ld, idx, b, M, xg, st) : 0;
 }
 
 template <int KP>
 static int launch_decode(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, const float* P,
                          const float* Q, int SP, float* dP, float* dqpart, float* losspart, int with_loss,
-                         hipStream_t st) {
+                         hipStream_t st, uint8_t* xg) {
     constexpr int SPL = dec_spl(KP);
     const int64_t chunks = (M + 256 * SPL - 1) / (256 * SPL);
     dim3 grid((unsigned)chunks), block(256);
@@ -1417,7 +1439,8 @@ static int launch_decode(const uint8_t* xp, int64_t ld, const int32_t* idx, int 
         hipLaunchKernelGGL((decode_bce_kernel<KP, SPL, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
     else
         hipLaunchKernelGGL((decode_bce_kernel<KP, SPL, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
-    return check_launch("decode_bce");
+    if (check_launch("decode_bce")) return 1;
+    return xg ? launch_gather_rows(xp, ld, idx, b, M, xg, st) : 0;
 }
 
 }  // namespace nadm
@@ -1521,9 +1544,9 @@ extern "C" int nadm_pca_project(const uint8_t* xp, int64_t ld, const int32_t* id
     return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0x3FC0u);
 }
 
-extern "C" int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                               const float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
-                               float* losspart, int32_t with_loss, void* stream) {
+static int decode_bce_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                           const float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
+                           float* losspart, int32_t with_loss, void* stream, uint8_t* xg) {
     if (!xp || !idx || !P || !Q || !dP || !dqpart) return fail("nadm_decode_bce: null pointer");
     if (with_loss && !losspart) return fail("nadm_decode_bce: with_loss needs losspart");
     if (b <= 0 || M <= 0) return fail("nadm_decode_bce: empty batch or M");
@@ -1531,24 +1554,37 @@ extern "C" int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx
     hipStream_t st = (hipStream_t)stream;
     if (kp <= 16 && use_mfma_decode()) {
         switch (kp) {
-            case 4: return launch_decode_mfma<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
-            case 8: return launch_decode_mfma<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
-            case 12: return launch_decode_mfma<12>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
-            case 16: return launch_decode_mfma<16>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
+            case 4: return launch_decode_mfma<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
+            case 8: return launch_decode_mfma<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
+            case 12: return launch_decode_mfma<12>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
+            case 16: return launch_decode_mfma<16>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
             default: return fail("nadm_decode_bce: unsupported padded K (use nadm_pad_k)");
         }
     }
     switch (kp) {
-        case 4: return launch_decode<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
-        case 8: return launch_decode<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
-        case 12: return launch_decode<12>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
-        case 16: return launch_decode<16>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
-        case 24: return launch_decode<24>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
-        case 32: return launch_decode<32>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
-        case 48: return launch_decode<48>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
-        case 64: return launch_decode<64>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st);
+        case 4: return launch_decode<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
+        case 8: return launch_decode<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
+        case 12: return launch_decode<12>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
+        case 16: return launch_decode<16>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
+        case 24: return launch_decode<24>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
+        case 32: return launch_decode<32>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
+        case 48: return launch_decode<48>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
+        case 64: return launch_decode<64>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
         default: return fail("nadm_decode_bce: unsupported padded K (use nadm_pad_k)");
     }
+}
+
+extern "C" int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                               const float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
+                               float* losspart, int32_t with_loss, void* stream) {
+    return decode_bce_impl(xp, ld, idx, b, M, P, kp, Q, SP, dP, dqpart, losspart, with_loss, stream, nullptr);
+}
+
+extern "C" int nadm_decode_bce_gather(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                                      const float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
+                                      float* losspart, int32_t with_loss, uint8_t* xg, void* stream) {
+    if (!xg) return fail("nadm_decode_bce_gather: null pointer");
+    return decode_bce_impl(xp, ld, idx, b, M, P, kp, Q, SP, dP, dqpart, losspart, with_loss, stream, xg);
 }
 
 static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,

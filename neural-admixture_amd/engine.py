@@ -61,6 +61,12 @@ class Engine:
         self.xp: Optional[torch.Tensor] = None          # packed genotypes [rows, ld]
         self.step_count = 0
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event) on the launch stream
+        # pass 2 writes the batch's gathered rows back to back into xg and pass 3 reads them from there (include/nadm.h,
+        # nadm_decode_bce_gather): same bytes, same results, no scattered reads over the resident matrix in pass 3
+        self.gather_batch = device.type == "cuda"
+        self._xg: Optional[torch.Tensor] = None
+        self._iota: Optional[torch.Tensor] = None
+        self._xg_key = None
         self.timers: Optional[dict] = None                    # {name: [(start, end) HIP events]} when a dict (bench.py)
         self.timed_names = None                               # restrict the timers to these kernel names (None = all)
         # train_step(): optional second stream for the work that does not depend on pass 3.  Measured on MI355X (b=800,
@@ -70,6 +76,12 @@ class Engine:
         self._side, self._ev = None, None
         self._n_cu: Optional[int] = None
         self._pending_ddp: list = []
+
+    def _xg_buf(self) -> torch.Tensor:
+        if self._xg is None:
+            self._xg = torch.empty((self.bmax, self.ld), dtype=torch.uint8, device=self.device)
+            self._iota = torch.arange(self.bmax, dtype=torch.int32, device=self.device)
+        return self._xg
 
     def _timed(self, name):
         if self.timers is None or (self.timed_names is not None and name not in self.timed_names):
@@ -219,16 +231,20 @@ class Engine:
             align = csnps * 1024 // math.gcd(csnps, 1024)
             for m0, m1 in (self._round_ranges(csnps, align, 3 if kp <= 8 else 2) if p_parts == "rounds" else self._snp_ranges(p_parts, align)):
                 c0 = m0 // csnps
-                check(lib.nadm_decode_bce(
-                    C.c_void_p(self.xp.data_ptr() + m0 // 4), self.ld, ptr(idx), b, m1 - m0,
-                    C.c_void_p(self.big.data_ptr() + (L.p_off[h] + m0 * kp) * fsz), kp,
-                    C.c_void_p(self.Q.data_ptr() + L.qoff[h] * fsz), L.SP,
-                    C.c_void_p(self.gbig.data_ptr() + (L.p_off[h] + m0 * kp) * fsz),
-                    C.c_void_p(self.dqpart.data_ptr() + (dq_offs[h] + c0 * b * kp) * fsz),
-                    C.c_void_p(self.losspart.data_ptr() + (loss_offs[h] + c0) * fsz), 1 if with_loss else 0, st), "decode_bce")
+                args = (C.c_void_p(self.xp.data_ptr() + m0 // 4), self.ld, ptr(idx), b, m1 - m0,
+                        C.c_void_p(self.big.data_ptr() + (L.p_off[h] + m0 * kp) * fsz), kp,
+                        C.c_void_p(self.Q.data_ptr() + L.qoff[h] * fsz), L.SP,
+                        C.c_void_p(self.gbig.data_ptr() + (L.p_off[h] + m0 * kp) * fsz),
+                        C.c_void_p(self.dqpart.data_ptr() + (dq_offs[h] + c0 * b * kp) * fsz),
+                        C.c_void_p(self.losspart.data_ptr() + (loss_offs[h] + c0) * fsz), 1 if with_loss else 0)
+                if h == 0 and self.gather_batch:              # head 0's pass also leaves the batch's rows back to back in xg
+                    check(lib.nadm_decode_bce_gather(*args, C.c_void_p(self._xg_buf().data_ptr() + m0 // 4), st), "decode_bce_gather")
+                else:
+                    check(lib.nadm_decode_bce(*args, st), "decode_bce")
                 if on_grad_ready is not None:
                     on_grad_ready(self._ns_pad + L.p_off[h] + m0 * kp, self._ns_pad + L.p_off[h] + m1 * kp)
         if ev: ev[1].record()
+        self._xg_key = (idx.data_ptr(), b) if self.gather_batch else None   # pass 3 of THIS step, same batch: may read the copy
         n_loss = L.n_loss
         if self.labels is not None and supervised:
             check(lib.nadm_supervised_ce(ptr(self.Q), L.SP, L.ks[0], L.kp[0], ptr(self.labels), ptr(idx), b, self.n_classes,
@@ -253,8 +269,14 @@ class Engine:
         """Pass 3: dV = X^T.dZ (optionally on SNP sub-ranges)."""
         L, st, fsz = self.lay, _stream(), 4
         ev = self._timed("encode_bwd")
+        # rows: the compact copy pass 2 of this step left in xg (rows 0..b-1 = the batch in order), else the resident matrix
+        if self._xg_key == (idx.data_ptr(), b) and self._xg is not None:
+            src, rows = self._xg, self._iota
+        else:
+            src, rows = self.xp, idx
+        self._xg_key = None
         for i, (m0, m1) in enumerate(self._snp_ranges(v_parts, 1024)):
-            check(lib.nadm_encode_bwd(C.c_void_p(self.xp.data_ptr() + m0 // 4), self.ld, ptr(idx), b, m1 - m0, ptr(self.dZ), L.CP,
+            check(lib.nadm_encode_bwd(C.c_void_p(src.data_ptr() + m0 // 4), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), L.CP,
                                       C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz), st), "encode_bwd")
             if on_grad_ready is not None:                     # the first piece carries the small gradients in front of it
                 on_grad_ready(0 if i == 0 else self._ns_pad + m0 * L.CP, self._ns_pad + m1 * L.CP)

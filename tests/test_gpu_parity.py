@@ -887,3 +887,64 @@ def test_mixture_means_on_the_gpu_equal_the_library_fit():
             del os.environ["NADM_GMM"]
     a, b = res["em"], res["sklearn"]
     assert a.shape == b.shape == (9, 4000) and np.abs(a - b).max() < 1e-6
+
+
+@pytest.mark.parametrize("K", [5, 13, 20])
+def test_pass2_gather_byproduct_and_pass3_on_the_compact_copy(K):
+    """nadm_decode_bce_gather = nadm_decode_bce + the batch's rows written back to back: same gradients / loss bit for bit,
+    the copy equals the gathered rows on every byte column that holds SNPs, and pass 3 on (copy, 0..b-1) gives the bits of
+    pass 3 on (resident matrix, idx).  K = 5 / 13: the bf16 kernel writes the copy itself; K = 20: separate gather kernel.
+    M = 2301 leaves a ragged last byte; the SNP sub-range form (pointer + m0/4) is covered as well."""
+    import ctypes as C
+    import neural_admixture_amd as na
+    from neural_admixture_amd._lib import lib, check, ptr
+    dev = _dev()
+    N, M, b = 90, 2301, 37
+    Gm = O.synth_genotypes(N, M, 4, seed=21)
+    rng = np.random.default_rng(6)
+    p = O.make_params(3, (rng.standard_normal((M, 8)) / 48).astype(np.float32), rng.uniform(0.05, 0.95, (K, M)).astype(np.float32), 64, [K])
+    e = make_engine(Gm, p, b)
+    e.gather_batch = False
+    idx = torch.from_numpy(rng.permutation(N)[:b].astype(np.int32)).to(dev)
+    e.forward(idx, b)
+    L = e.lay
+    kp = L.kp[0]
+    nch = int(lib.nadm_decode_chunks(M, kp))
+    outs = []
+    for gather in (False, True):
+        dP = torch.zeros(M * kp, dtype=torch.float32, device=dev)
+        dq = torch.zeros(nch * b * kp, dtype=torch.float32, device=dev)
+        ls = torch.zeros(nch, dtype=torch.float32, device=dev)
+        xg = torch.full((b, e.ld), 0xEE, dtype=torch.uint8, device=dev)
+        args = (ptr(e.xp), e.ld, ptr(idx), b, M, C.c_void_p(e.big.data_ptr() + L.p_off[0] * 4), kp, ptr(e.Q), L.SP, ptr(dP), ptr(dq), ptr(ls), 1)
+        if gather:
+            check(lib.nadm_decode_bce_gather(*args, ptr(xg), None))
+        else:
+            check(lib.nadm_decode_bce(*args, None))
+        torch.cuda.synchronize()
+        outs.append((dP, dq, ls, xg))
+    for a_, b_ in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a_, b_)
+    nbytes = (M + 3) // 4
+    want = e.xp[idx.long()]
+    assert torch.equal(outs[1][3][:, :nbytes], want[:, :nbytes])
+    assert bool((outs[0][3] == 0xEE).all())                      # the plain entry point leaves xg alone
+    # pass 3: resident matrix + idx vs compact copy + iota
+    dZ = torch.from_numpy(rng.standard_normal((b, L.CP)).astype(np.float32)).to(dev)
+    iota = torch.arange(b, dtype=torch.int32, device=dev)
+    dv = []
+    for src, rows in ((e.xp, idx), (outs[1][3], iota)):
+        o = torch.zeros(M * L.CP, dtype=torch.float32, device=dev)
+        check(lib.nadm_encode_bwd(ptr(src), e.ld, ptr(rows), b, M, ptr(dZ), L.CP, ptr(o), None))
+        dv.append(o)
+    torch.cuda.synchronize()
+    assert torch.equal(dv[0], dv[1])
+    # whole steps: engine with the by-product on (default on a GPU) vs off, two steps, bit-identical state
+    e1, e2 = make_engine(Gm, p, b), make_engine(Gm, p, b)
+    assert e1.gather_batch
+    e2.gather_batch = False
+    for _ in range(2):
+        e1.train_step(idx, b, 2e-3, True)
+        e2.train_step(idx, b, 2e-3, True)
+    torch.cuda.synchronize()
+    assert torch.equal(e1.big, e2.big) and torch.equal(e1.small, e2.small) and e1.read_loss() == e2.read_loss()
