@@ -61,9 +61,10 @@ def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_comp
     import os
     how = os.environ.get("NADM_GMM", "auto")                    # "em" | "sklearn" force one; both give the same means (1e-13)
     on_gpu = device is not None and device.type == "cuda"
-    # device EM: ~0.6 ms per iteration whatever N (launch-bound); library fit: proportional to N, and several K can run as
-    # concurrent child processes -> the device wins for one or two K and for large N, the children for many K on few samples
-    if how == "em" or (how == "auto" and on_gpu and (len(ks) <= 2 or N > 20_000)):
+    # device EM: ~0.6 ms per iteration whatever N (launch-bound) + ~0.8 s of one-off start-up (first float64 batched GEMMs);
+    # library fit: proportional to N (1 s at N = 2504, 22-45 s at N = 100k), and several K can run as concurrent child
+    # processes -> the device for large N, the library for 1000-Genomes-sized inputs
+    if how == "em" or (how == "auto" and on_gpu and N > 20_000):
         from ._gmm_em import fit_means as fit_means_device
         means = [fit_means_device(X_pca, k, seed, device) for k in ks]
     else:
