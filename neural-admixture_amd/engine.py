@@ -11,6 +11,7 @@ import ctypes as C
 from typing import List, Optional, Sequence
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -67,6 +68,7 @@ class Engine:
         self._xg: Optional[torch.Tensor] = None
         self._iota: Optional[torch.Tensor] = None
         self._xg_key = None
+        self.sync_tail_message = os.environ.get("NADM_DDP_SYNC_TAIL", "1") != "0"   # see train_step_ddp.send
         self.timers: Optional[dict] = None                    # {name: [(start, end) HIP events]} when a dict (bench.py)
         self.timed_names = None                               # restrict the timers to these kernel names (None = all)
         # train_step(): optional second stream for the work that does not depend on pass 3.  Measured on MI355X (b=800,
@@ -390,21 +392,30 @@ class Engine:
         L = self.lay
         works, pieces = [], []
         deferred = []
+        p_start, p_end = self._ns_pad + L.clamp_from, self._ns_pad + L.n_big
 
         def send(lo, hi):
-            works.append(dist.all_reduce(self.gflat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            # P pieces: asynchronous, on the process group's own stream, underneath the kernels that follow.  The [small | dV]
+            # message is the one the next kernels (Adam on V, the next step's pass 1) wait for: issued synchronously it runs
+            # on the COMPUTE stream, right behind pass 3 and right in front of Adam, with no cross-stream event hand-off on
+            # either side (each costs 20-30 us on this stack; torch >= 2.8 runs async_op=False collectives on the caller's
+            # current stream).
+            on_compute_stream = self.sync_tail_message and lo < p_start
+            works.append(dist.all_reduce(self.gflat[lo:hi], op=dist.ReduceOp.SUM, async_op=not on_compute_stream))
             pieces.append((lo, hi))
 
-        held = []                                             # defer_tail: the most recent P piece, not yet sent
+        held = []                                             # defer_tail: the LAST P piece, not yet sent
 
         def reduce_piece(lo, hi):                             # gflat = [small | pad | V | P heads]
-            if lo >= self._ns_pad + L.clamp_from and defer_tail:
-                if held:
-                    send(*held.pop())
+            # Every piece goes to RCCL right when the kernel that completes it has been enqueued -- BEFORE the next kernel is:
+            # the collective waits on an event recorded at this point of the compute stream, so a piece handed over later
+            # would also wait for whatever was enqueued in between (the first part of a cut pass 2 must go out before the
+            # second part is launched, or it travels after it instead of underneath it).
+            if defer_tail and lo >= p_start and hi == p_end:
                 held.append((lo, hi))
                 return
             send(lo, hi)
-            if held:                                          # first [small | dV] piece is on its way: now the last P piece
+            if held and lo < p_start:                         # first [small | dV] piece is on its way: now the last P piece
                 deferred.append(held[-1])
                 send(*held.pop())
         self.forward(idx, b)
@@ -416,14 +427,14 @@ class Engine:
         self.step_count += 1
         off = self._ns_pad
         ev = self._timed("adam")
-        p_start = self._ns_pad + L.clamp_from
         deferred_set = set(deferred)
         pending = []
         for w, (lo, hi) in zip(works, pieces):                # messages complete in the order they were enqueued
             if (lo, hi) in deferred_set:
                 pending.append((w, lo - off, hi - off, lr, scale, self.step_count))
                 continue
-            w.wait()
+            if w is not None:
+                w.wait()
             if lo >= p_start:                                 # a P piece: Adam on it while later messages are still in flight
                 self.adam_p_range(lo - off, hi - off, lr, scale, self.step_count)
         self.adam_part("V", lr, scale)                        # every [small | dV] piece is in
@@ -434,7 +445,8 @@ class Engine:
     def finish_ddp(self) -> None:
         """Apply the Adam update of a P piece whose all-reduce was deferred by train_step_ddp(defer_tail=True)."""
         for w, lo, hi, lr, scale, step in self._pending_ddp:
-            w.wait()
+            if w is not None:
+                w.wait()
             self.adam_p_range(lo, hi, lr, scale, step)
         self._pending_ddp = []
 
