@@ -831,7 +831,14 @@ __device__ __forceinline__ f32x2_t bce_elem2(const float d0, const float d1, con
     const f32x2_t r = {__builtin_amdgcn_fmed3f(d0, 0.f, 1.f), __builtin_amdgcn_fmed3f(d1, 0.f, 1.f)};
     const f32x2_t omr = (f32x2_t){1.f, 1.f} - r;
     const f32x2_t den = omr * r;
-    const f32x2_t inv = {__builtin_amdgcn_rcpf(fmaxf(den.x, 1e-12f)), __builtin_amdgcn_rcpf(fmaxf(den.y, 1e-12f))};
+    // The gradient is masked where the unclamped value lies outside [0, 1] (the reference's clamp_ backward, inclusive
+    // bounds).  The mask rides on the denominator: t = (d - r) * inf is NaN where d was in range (0 * inf) and +-inf where
+    // it was not; max(den, 1e-12, |t|) ignores the NaN (IEEE maxNum) and becomes inf otherwise, so 1/denominator -- and with
+    // it the gradient -- is exactly 0 there.  One packed subtract, one packed multiply and a three-input max instead of
+    // max + compare + select per genotype.
+    const f32x2_t t = ((f32x2_t){d0, d1} - r) * (f32x2_t){__builtin_inff(), __builtin_inff()};
+    const f32x2_t inv = {__builtin_amdgcn_rcpf(__builtin_fmaxf(__builtin_fmaxf(den.x, 1e-12f), __builtin_fabsf(t.x))),
+                         __builtin_amdgcn_rcpf(__builtin_fmaxf(__builtin_fmaxf(den.y, 1e-12f), __builtin_fabsf(t.y)))};
     const f32x2_t g = (r - x) * inv;
     if constexpr (LOSS) {
         // lossacc accumulates x*max(log2 r, c) + (1-x)*max(log2(1-r), c), c = -100/ln2 (the caller applies -ln2).
@@ -845,7 +852,7 @@ __device__ __forceinline__ f32x2_t bce_elem2(const float d0, const float d1, con
         asm volatile("" : "+v"(lossacc));     // pin the accumulation here: otherwise LLVM sinks all the logs of a tile pair
                                               // to the end of the loop body and keeps their 32 inputs alive (+60 VGPRs)
     }
-    return (f32x2_t){(r.x == d0) ? g.x : 0.f, (r.y == d1) ? g.y : 0.f};
+    return g;
 }
 
 // Two genotypes -> two floats in ONE instruction: a nibble 00cc read as FP4 (E2M1) is exactly cc/2 (0, .5, 1), so
