@@ -40,7 +40,7 @@ extern "C" {
 
 #define NADM_MAX_HEADS 32
 #define NADM_MAX_K 64
-#define NADM_ABI_VERSION 3   /* 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
+#define NADM_ABI_VERSION 4   /* 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t); 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
@@ -142,6 +142,29 @@ int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b
 int nadm_decode_bce_gather(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                            const float* P, int32_t kp, const float* Q, int32_t SP,
                            float* dP, float* dqpart, float* losspart, int32_t with_loss, uint8_t* xg, void* stream);
+
+/* ---- single-GPU step: Adam applied where the gradient is completed -----------------------------------------------------
+ * In a step on one GPU the gradient of a P row is final when the pass-2 block that owns it finishes, and nothing else in
+ * the step reads that row again; likewise for V rows and pass 3.  The *_step entry points take the Adam state of those
+ * rows and apply optimizer.step() + restrict_P (neural_admixture.py:187-204,411-412) to them in the kernel's epilogue --
+ * the same element update as nadm_adam, bit for bit -- instead of writing the gradient out for a separate launch (which
+ * the data-parallel step still does: its gradients have to be all-reduced first).  adam == NULL: exactly
+ * nadm_decode_bce(_gather) / nadm_encode_bwd.  With adam, m and v point at the Adam moments of the SAME rows as P / V
+ * (sub-range launches advance them like P / V), the gradient buffer is left untouched by the matrix-core kernels
+ * (K <= 16, C <= 8; the other variants write it and run the update as a second kernel), xg may be NULL. */
+typedef struct {
+    float*  m;            /* first moment of the rows being updated  */
+    float*  v;            /* second moment                            */
+    float   lr;
+    int32_t step;         /* 1-based step count                       */
+    float   grad_scale;   /* gradients are multiplied by this first   */
+} nadm_adam_t;
+int nadm_decode_bce_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                         float* P, int32_t kp, const float* Q, int32_t SP,
+                         float* dP, float* dqpart, float* losspart, int32_t with_loss,
+                         uint8_t* xg, const nadm_adam_t* adam, void* stream);
+int nadm_encode_bwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                         const float* dZ, int32_t CP, float* V, float* dV, const nadm_adam_t* adam, void* stream);
 
 /* ---- a11: MLP backward (softmax, Linear, ReLU, RMSNorm) ---------------------------------- */
 /* Reduces dqpart (the heads' slabs laid back to back in head order, head h holding

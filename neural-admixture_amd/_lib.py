@@ -24,6 +24,11 @@ class Heads(C.Structure):
                 ("g_off", C.c_int32), ("w1_off", C.c_int32), ("b1_off", C.c_int32)]
 
 
+class AdamArgs(C.Structure):
+    """nadm_adam_t (include/nadm.h)."""
+    _fields_ = [("m", C.c_void_p), ("v", C.c_void_p), ("lr", C.c_float), ("step", C.c_int32), ("grad_scale", C.c_float)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
@@ -55,6 +60,8 @@ def _load():
         "nadm_mlp_fwd": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]),
         "nadm_decode_bce": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
         "nadm_decode_bce_gather": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp]),
+        "nadm_decode_bce_step": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
+        "nadm_encode_bwd_step": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp, vp, vp]),
         "nadm_mlp_bwd": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]),
         "nadm_mlp_bwd_weights": (C.c_int, [HP, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         "nadm_supervised_ce": (C.c_int, [vp, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp]),
@@ -66,7 +73,7 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.nadm_abi_version() != 3:
+    if lib.nadm_abi_version() != 4:
         raise RuntimeError("neural_admixture_amd: libnadm.so ABI version mismatch")
     return lib, tuple(sig)
 

@@ -37,6 +37,40 @@ __device__ __forceinline__ double wave_sum_all_f64(double v) {
     return v;
 }
 
+// ---- Adam element (torch.optim.Adam closed form, betas .9/.95, eps 1e-8; neural_admixture.py:187-204) + restrict_P ----
+// One definition for the stand-alone kernel and for the epilogues of passes 2 and 3 that apply the update to the rows whose
+// gradient they have just completed: the same operations in the same order, hence the same bits.
+struct AdamFused {            // m == nullptr: no fused update
+    float* m;
+    float* v;
+    float step_size, bc2_sqrt, grad_scale;
+};
+__device__ __forceinline__ float adam_element(float p, float g, float& m, float& v, float step_size, float bc2_sqrt,
+                                              float grad_scale, bool clamp01) {
+    const float b2 = 0.95f, eps = 1e-8f;
+    const float omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.95);
+    const float gr = g * grad_scale;
+    m = m + (gr - m) * omb1;
+    v = v * b2 + gr * gr * omb2;
+    const float den = sqrtf(v) / bc2_sqrt + eps;
+    float np_ = p - step_size * (m / den);
+    if (clamp01) np_ = fminf(fmaxf(np_, 0.f), 1.f);
+    return np_;
+}
+__device__ __forceinline__ void adam_float4(float* __restrict__ p, const float4 G4, float* __restrict__ m, float* __restrict__ v,
+                                            float step_size, float bc2_sqrt, float grad_scale, bool clamp01) {
+    const float4 P4 = *reinterpret_cast<const float4*>(p);
+    const float4 M4 = *reinterpret_cast<const float4*>(m);
+    const float4 V4 = *reinterpret_cast<const float4*>(v);
+    float pp[4] = {P4.x, P4.y, P4.z, P4.w}, gg[4] = {G4.x, G4.y, G4.z, G4.w};
+    float mm[4] = {M4.x, M4.y, M4.z, M4.w}, vv[4] = {V4.x, V4.y, V4.z, V4.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pp[q] = adam_element(pp[q], gg[q], mm[q], vv[q], step_size, bc2_sqrt, grad_scale, clamp01);
+    *reinterpret_cast<float4*>(p) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    *reinterpret_cast<float4*>(m) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    *reinterpret_cast<float4*>(v) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+}
+
 // ---- BCE element: clamp, loss term, gradient w.r.t. the pre-clamp reconstruction ------------
 // dR = (r - x) / max(r(1-r), 1e-12) masked to 0 <= r_raw <= 1 (inclusive, on the PRE-clamp value);
 // ATen binary_cross_entropy(_backward) + clamp_ backward, behind neural_admixture.py:97,288,410.

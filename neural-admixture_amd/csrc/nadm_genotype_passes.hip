@@ -873,8 +873,8 @@ constexpr int BF_TS = NADM_BF_TS;       // samples per LDS tile
 template <int KP, bool LOSS>
 __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(NADM_BF_WPE, NADM_BF_WPE))) void decode_bce_bf16_kernel(
     const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
-    const float* __restrict__ P, const float* __restrict__ Q, int SP,
-    float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart, uint8_t* __restrict__ xg) {
+    float* P, const float* __restrict__ Q, int SP,
+    float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart, uint8_t* __restrict__ xg, AdamFused ad) {
     static_assert(KP <= 16, "one or two 8-wide k slots");
     // W (KP 9..16): k spans two 8-wide MFMA slots.  The pieces can no longer share an MFMA's 16 rows / columns, so
     //   R^T  = [Ph Ph' Ph Ph'].[Qh Qh' Qm Qm'] + [Pm Pm' Pm Pm'].[Qh Qh' Qm Qm'] + [Ph Ph' Pl Pl'].[Ql Ql' Qh Qh']   (X' = k 8..15)
@@ -1181,7 +1181,14 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
         constexpr int ROW4 = KP / 4;                                  // float4 per SNP row
         for (int e = tid; e < MF_WAVES * 16 * NTW * ROW4; e += NTHR) {
             const int64_t m = snp_blk0 + e / ROW4;
-            if (m < M) *reinterpret_cast<float4*>(dP + m * KP + 4 * (e % ROW4)) = *reinterpret_cast<const float4*>(s_dp + 4 * e);
+            if (m < M) {
+                const float4 g4 = *reinterpret_cast<const float4*>(s_dp + 4 * e);
+                const int64_t o = m * KP + 4 * (e % ROW4);
+                // single-GPU step: the gradient of these rows is final here and nothing else in the step reads P again, so
+                // Adam + clamp is applied on the spot (no dP round trip through HBM, no separate launch for the P matrices)
+                if (ad.m != nullptr) adam_float4(P + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.bc2_sqrt, ad.grad_scale, true);
+                else *reinterpret_cast<float4*>(dP + o) = g4;
+            }
         }
     }
     if constexpr (LOSS) {
@@ -1224,13 +1231,14 @@ constexpr int EB_CHUNK_SNPS = EB_COLS * 4;
 constexpr int EB_D = NADM_EB_D;             // X tiles in flight per thread (global loads issued EB_D - 1 tiles ahead)
 
 template <int CP>
-__global__ __launch_bounds__(256) void encode_bwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void encode_bwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
                                                               const int32_t* __restrict__ idx, int b, int64_t M,
                                                               const float* __restrict__ dZ, float* __restrict__ dV,
-                                                              uint32_t missing_bf16) {
+                                                              uint32_t missing_bf16, float* __restrict__ Vrw, AdamFused ad) {
     static_assert(CP <= 8, "hi|mid and lo|0 share the 16 MFMA rows");
     __shared__ __attribute__((aligned(16))) uint8_t s_xt[2][EB_COLS * EB_CS];
     __shared__ __attribute__((aligned(16))) uint4 s_a[2][2][64];
+    __shared__ __attribute__((aligned(16))) float4 s_dvbuf[EB_CHUNK_SNPS * CP / 4];       // the block's dV rows (epilogue)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mcol = lane & 15, q = lane >> 4;
     const int64_t chunk = blockIdx.x;
@@ -1356,7 +1364,11 @@ __global__ __launch_bounds__(256) void encode_bwd_mfma_kernel(const uint8_t* __r
         }
     }
 
-    // ---- fold hi + mid + lo: rows c and c+8 sit 32 lanes apart; lanes with 4*(lane>>4) < CP store ----
+    // ---- fold hi + mid + lo (rows c and c+8 sit 32 lanes apart) into an LDS image of the block's dV rows [512 SNPs][CP],
+    // then every thread handles whole float4s of that contiguous region: full 16 B/lane lines for the gradient store, or
+    // -- single-GPU step -- for Adam on these V rows (3 reads + 3 writes per element: it has to be coalesced) ----
+    __syncthreads();                                           // all waves are done with s_xt / s_a of the last tile
+    float* s_dv = reinterpret_cast<float*>(&s_dvbuf[0]);
 #pragma unroll
     for (int g = 0; g < EB_G; ++g) {
 #pragma unroll
@@ -1367,8 +1379,22 @@ __global__ __launch_bounds__(256) void encode_bwd_mfma_kernel(const uint8_t* __r
                 const float u = acc1[g][j][r] + acc2[g][j][r];
                 o[r] = u + __shfl_xor(u, 32, 64);
             }
-            const int64_t m = chunk * EB_CHUNK_SNPS + (wave * (16 * EB_G) + g * 16 + mcol) * 4 + j;
-            if (q < 2 && 4 * q < CP && m < M) *reinterpret_cast<float4*>(dV + m * CP + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+            const int ml = (wave * (16 * EB_G) + g * 16 + mcol) * 4 + j;          // SNP within the block's 512
+            if (q < 2 && 4 * q < CP) *reinterpret_cast<float4*>(s_dv + ml * CP + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int ROW4 = CP / 4;
+        const int64_t m0 = chunk * EB_CHUNK_SNPS;
+        for (int e = tid; e < EB_CHUNK_SNPS * ROW4; e += 256) {
+            const int64_t m = m0 + e / ROW4;
+            if (m < M) {
+                const float4 g4 = *reinterpret_cast<const float4*>(s_dv + 4 * e);
+                const int64_t o = m * CP + 4 * (e % ROW4);
+                if (ad.m != nullptr) adam_float4(Vrw + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.bc2_sqrt, ad.grad_scale, false);
+                else *reinterpret_cast<float4*>(dV + o) = g4;
+            }
         }
     }
 }
@@ -1392,6 +1418,21 @@ static bool use_bf16_decode() {
     return v;
 }
 
+// Adam on n floats for the variants of passes 2 and 3 that have no fused epilogue (same element function)
+__global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ p, const float* __restrict__ g, AdamFused ad, int64_t n, int clamp01) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        float mq = ad.m[e], vq = ad.v[e];
+        p[e] = adam_element(p[e], g[e], mq, vq, ad.step_size, ad.bc2_sqrt, ad.grad_scale, clamp01 != 0);
+        ad.m[e] = mq; ad.v[e] = vq;
+    }
+}
+static int launch_adam_range(float* p, const float* g, AdamFused ad, int64_t n, hipStream_t st, int clamp01 = 1) {
+    int64_t gx = (n + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(adam_range_kernel, dim3((unsigned)gx), dim3(256), 0, st, p, g, ad, n, clamp01);
+    return check_launch("adam_range");
+}
+
 // rows idx[0..b) of xp, the byte columns that hold SNPs [0, M) -> rows 0..b-1 of xg (same row stride): what the bf16 pass-2
 // kernel writes as a by-product, as a kernel of its own for the K > 16 / A-B-reference variants of pass 2
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx,
@@ -1410,18 +1451,18 @@ static int launch_gather_rows(const uint8_t* xp, int64_t ld, const int32_t* idx,
 }
 
 template <int KP>
-static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, const float* P,
+static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, float* P,
                               const float* Q, int SP, float* dP, float* dqpart, float* losspart, int with_loss,
-                              hipStream_t st, uint8_t* xg) {
+                              hipStream_t st, uint8_t* xg, AdamFused ad) {
     if constexpr (KP <= 16) {
         if (use_bf16_decode()) {
             static_assert(mf_chunk_snps(KP) == BF_WAVES * 16 * BF_NTW, "same chunking as the f32 MFMA kernel");
             const int64_t chunks = (M + mf_chunk_snps(KP) - 1) / mf_chunk_snps(KP);
             dim3 grid((unsigned)chunks), block(64 * BF_WAVES);
             if (with_loss)
-                hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg);
+                hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad);
             else
-                hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg);
+                hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad);
             return check_launch("decode_bce_bf16");
         }
     }
@@ -1432,13 +1473,14 @@ static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx,
     else
         hipLaunchKernelGGL((decode_bce_mfma_kernel<KP, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
     if (check_launch("decode_bce_mfma")) return 1;
-    return xg ? launch_gather_rows(xp, ld, idx, b, M, xg, st) : 0;
+    if (xg && launch_gather_rows(xp, ld, idx, b, M, xg, st)) return 1;
+    return ad.m ? launch_adam_range(P, dP, ad, M * KP, st) : 0;
 }
 
 template <int KP>
-static int launch_decode(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, const float* P,
+static int launch_decode(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, float* P,
                          const float* Q, int SP, float* dP, float* dqpart, float* losspart, int with_loss,
-                         hipStream_t st, uint8_t* xg) {
+                         hipStream_t st, uint8_t* xg, AdamFused ad) {
     constexpr int SPL = dec_spl(KP);
     const int64_t chunks = (M + 256 * SPL - 1) / (256 * SPL);
     dim3 grid((unsigned)chunks), block(256);
@@ -1447,7 +1489,8 @@ static int launch_decode(const uint8_t* xp, int64_t ld, const int32_t* idx, int 
     else
         hipLaunchKernelGGL((decode_bce_kernel<KP, SPL, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
     if (check_launch("decode_bce")) return 1;
-    return xg ? launch_gather_rows(xp, ld, idx, b, M, xg, st) : 0;
+    if (xg && launch_gather_rows(xp, ld, idx, b, M, xg, st)) return 1;
+    return ad.m ? launch_adam_range(P, dP, ad, M * KP, st) : 0;
 }
 
 }  // namespace nadm
@@ -1552,8 +1595,8 @@ extern "C" int nadm_pca_project(const uint8_t* xp, int64_t ld, const int32_t* id
 }
 
 static int decode_bce_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                           const float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
-                           float* losspart, int32_t with_loss, void* stream, uint8_t* xg) {
+                           float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
+                           float* losspart, int32_t with_loss, void* stream, uint8_t* xg, AdamFused ad) {
     if (!xp || !idx || !P || !Q || !dP || !dqpart) return fail("nadm_decode_bce: null pointer");
     if (with_loss && !losspart) return fail("nadm_decode_bce: with_loss needs losspart");
     if (b <= 0 || M <= 0) return fail("nadm_decode_bce: empty batch or M");
@@ -1561,22 +1604,22 @@ static int decode_bce_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
     hipStream_t st = (hipStream_t)stream;
     if (kp <= 16 && use_mfma_decode()) {
         switch (kp) {
-            case 4: return launch_decode_mfma<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
-            case 8: return launch_decode_mfma<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
-            case 12: return launch_decode_mfma<12>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
-            case 16: return launch_decode_mfma<16>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
+            case 4: return launch_decode_mfma<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
+            case 8: return launch_decode_mfma<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
+            case 12: return launch_decode_mfma<12>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
+            case 16: return launch_decode_mfma<16>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
             default: return fail("nadm_decode_bce: unsupported padded K (use nadm_pad_k)");
         }
     }
     switch (kp) {
-        case 4: return launch_decode<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
-        case 8: return launch_decode<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
-        case 12: return launch_decode<12>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
-        case 16: return launch_decode<16>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
-        case 24: return launch_decode<24>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
-        case 32: return launch_decode<32>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
-        case 48: return launch_decode<48>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
-        case 64: return launch_decode<64>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg);
+        case 4: return launch_decode<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
+        case 8: return launch_decode<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
+        case 12: return launch_decode<12>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
+        case 16: return launch_decode<16>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
+        case 24: return launch_decode<24>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
+        case 32: return launch_decode<32>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
+        case 48: return launch_decode<48>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
+        case 64: return launch_decode<64>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
         default: return fail("nadm_decode_bce: unsupported padded K (use nadm_pad_k)");
     }
 }
@@ -1584,18 +1627,39 @@ static int decode_bce_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
 extern "C" int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                                const float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
                                float* losspart, int32_t with_loss, void* stream) {
-    return decode_bce_impl(xp, ld, idx, b, M, P, kp, Q, SP, dP, dqpart, losspart, with_loss, stream, nullptr);
+    return decode_bce_impl(xp, ld, idx, b, M, const_cast<float*>(P), kp, Q, SP, dP, dqpart, losspart, with_loss, stream, nullptr, AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f});
 }
 
 extern "C" int nadm_decode_bce_gather(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                                       const float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
                                       float* losspart, int32_t with_loss, uint8_t* xg, void* stream) {
     if (!xg) return fail("nadm_decode_bce_gather: null pointer");
-    return decode_bce_impl(xp, ld, idx, b, M, P, kp, Q, SP, dP, dqpart, losspart, with_loss, stream, xg);
+    return decode_bce_impl(xp, ld, idx, b, M, const_cast<float*>(P), kp, Q, SP, dP, dqpart, losspart, with_loss, stream, xg, AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f});
+}
+
+static int adam_fused_args(const nadm_adam_t* adam, const char* who, AdamFused* out) {
+    *out = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f};
+    if (!adam) return 0;
+    if (!adam->m || !adam->v) return fail(who);
+    if (adam->step < 1) return fail("nadm_*_step: Adam step is 1-based");
+    if (((uintptr_t)adam->m | (uintptr_t)adam->v) & 15) return fail("nadm_*_step: Adam state must be 16-byte aligned");
+    out->m = adam->m; out->v = adam->v; out->grad_scale = adam->grad_scale;
+    adam_scalars(adam->lr, adam->step, &out->step_size, &out->bc2_sqrt);
+    return 0;
+}
+
+extern "C" int nadm_decode_bce_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                                    float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
+                                    float* losspart, int32_t with_loss, uint8_t* xg, const nadm_adam_t* adam, void* stream) {
+    AdamFused ad;
+    if (adam_fused_args(adam, "nadm_decode_bce_step: Adam state is NULL", &ad)) return 1;
+    if ((uintptr_t)P & 15) return fail("nadm_decode_bce_step: P must be 16-byte aligned");
+    return decode_bce_impl(xp, ld, idx, b, M, P, kp, Q, SP, dP, dqpart, losspart, with_loss, stream, xg, ad);
 }
 
 static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                           const float* dZ, int32_t CP, float* dV, void* stream, uint32_t missing_bf16) {
+                           const float* dZ, int32_t CP, float* dV, void* stream, uint32_t missing_bf16,
+                           float* Vrw = nullptr, AdamFused ad = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f}) {
     if (!xp || !idx || !dZ || !dV) return fail("nadm_encode_bwd: null pointer");
     if (b <= 0 || M <= 0) return fail("nadm_encode_bwd: empty batch or M");
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_encode_bwd: ld must be a multiple of 16 and >= ceil(M/4)");
@@ -1603,8 +1667,8 @@ static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
     hipStream_t st = (hipStream_t)stream;
     if (CP <= 8 && use_mfma_encode()) {
         dim3 g2((unsigned)((M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS));
-        if (CP == 4) hipLaunchKernelGGL((encode_bwd_mfma_kernel<4>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV, missing_bf16);
-        else hipLaunchKernelGGL((encode_bwd_mfma_kernel<8>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV, missing_bf16);
+        if (CP == 4) hipLaunchKernelGGL((encode_bwd_mfma_kernel<4>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV, missing_bf16, Vrw, ad);
+        else hipLaunchKernelGGL((encode_bwd_mfma_kernel<8>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV, missing_bf16, Vrw, ad);
         return check_launch("encode_bwd_mfma");
     }
     switch (CP) {
@@ -1616,7 +1680,16 @@ static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
         case 32: hipLaunchKernelGGL((encode_bwd_kernel<32>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
         default: return fail("nadm_encode_bwd: unsupported CP (4,8,12,16,24,32)");
     }
-    return check_launch("encode_bwd");
+    if (check_launch("encode_bwd")) return 1;
+    return ad.m ? launch_adam_range(Vrw, dV, ad, M * CP, st, 0) : 0;      // fp32 variants of pass 3: stand-alone update
+}
+
+extern "C" int nadm_encode_bwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                                    const float* dZ, int32_t CP, float* V, float* dV, const nadm_adam_t* adam, void* stream) {
+    AdamFused ad;
+    if (adam_fused_args(adam, "nadm_encode_bwd_step: Adam state is NULL", &ad)) return 1;
+    if (ad.m && (!V || ((uintptr_t)V & 15))) return fail("nadm_encode_bwd_step: V must be non-NULL and 16-byte aligned");
+    return encode_bwd_impl(xp, ld, idx, b, M, dZ, CP, dV, stream, 0u, V, ad);
 }
 
 extern "C" int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,

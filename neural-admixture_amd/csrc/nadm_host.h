@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
 
 namespace nadm {
 
@@ -21,6 +22,14 @@ inline int check_launch(const char* what) {
         return 2;
     }
     return 0;
+}
+
+// step-dependent scalars of the Adam update (bias corrections folded in), as nadm_adam has always computed them
+inline void adam_scalars(float lr, int step, float* step_size, float* bc2_sqrt) {
+    const double bc1 = 1.0 - pow(0.9, (double)step);
+    const double bc2 = 1.0 - pow(0.95, (double)step);
+    *step_size = (float)((double)lr / bc1);
+    *bc2_sqrt = (float)sqrt(bc2);
 }
 
 }  // namespace nadm

@@ -878,8 +878,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    int64_t clamp_from, float step_size, float bc2_sqrt,
                                                    float grad_scale) {
-    const float b2 = 0.95f, eps = 1e-8f;
-    const float omb1 = (float)(1.0 - 0.9), omb2 = (float)(1.0 - 0.95);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
     for (int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < n; e += stride) {
         if (e + 4 <= n) {
@@ -890,27 +888,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             float pp[4] = {P4.x, P4.y, P4.z, P4.w}, gg[4] = {G4.x, G4.y, G4.z, G4.w};
             float mm[4] = {M4.x, M4.y, M4.z, M4.w}, vv[4] = {V4.x, V4.y, V4.z, V4.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float gr = gg[q] * grad_scale;
-                mm[q] = mm[q] + (gr - mm[q]) * omb1;
-                vv[q] = vv[q] * b2 + gr * gr * omb2;
-                const float den = sqrtf(vv[q]) / bc2_sqrt + eps;
-                float np_ = pp[q] - step_size * (mm[q] / den);
-                if (e + q >= clamp_from) np_ = fminf(fmaxf(np_, 0.f), 1.f);
-                pp[q] = np_;
-            }
+            for (int q = 0; q < 4; ++q) pp[q] = adam_element(pp[q], gg[q], mm[q], vv[q], step_size, bc2_sqrt, grad_scale, e + q >= clamp_from);
             *reinterpret_cast<float4*>(p + e) = make_float4(pp[0], pp[1], pp[2], pp[3]);
             *reinterpret_cast<float4*>(m + e) = make_float4(mm[0], mm[1], mm[2], mm[3]);
             *reinterpret_cast<float4*>(v + e) = make_float4(vv[0], vv[1], vv[2], vv[3]);
         } else {
             for (int64_t q = e; q < n; ++q) {
-                const float gr = g[q] * grad_scale;
-                const float mq = m[q] + (gr - m[q]) * omb1;
-                const float vq = v[q] * b2 + gr * gr * omb2;
-                const float den = sqrtf(vq) / bc2_sqrt + eps;
-                float np_ = p[q] - step_size * (mq / den);
-                if (q >= clamp_from) np_ = fminf(fmaxf(np_, 0.f), 1.f);
-                p[q] = np_; m[q] = mq; v[q] = vq;
+                float mq = m[q], vq = v[q];
+                p[q] = adam_element(p[q], g[q], mq, vq, step_size, bc2_sqrt, grad_scale, q >= clamp_from);
+                m[q] = mq; v[q] = vq;
             }
         }
     }
@@ -1339,10 +1325,8 @@ extern "C" int nadm_adam(float* param, const float* grad, float* m, float* v, in
     if (step < 1) return fail("nadm_adam: step is 1-based");
     if (n <= 0) return 0;
     if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) return fail("nadm_adam: buffers must be 16-byte aligned");
-    const double bc1 = 1.0 - pow(0.9, (double)step);
-    const double bc2 = 1.0 - pow(0.95, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
+    float step_size, bc2_sqrt;
+    adam_scalars(lr, step, &step_size, &bc2_sqrt);
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks < 1) blocks = 1;

@@ -16,7 +16,7 @@ import os
 import numpy as np
 import torch
 
-from ._lib import lib, check, ptr
+from ._lib import lib, check, ptr, AdamArgs
 from .layout import ModelLayout
 
 _f32 = torch.float32
@@ -68,6 +68,7 @@ class Engine:
         self._xg: Optional[torch.Tensor] = None
         self._iota: Optional[torch.Tensor] = None
         self._xg_key = None
+        self.fused_adam = device.type == "cuda" and os.environ.get("NADM_FUSED_ADAM", "1") != "0"   # see train_step
         self.sync_tail_message = os.environ.get("NADM_DDP_SYNC_TAIL", "1") != "0"   # see train_step_ddp.send
         self.timers: Optional[dict] = None                    # {name: [(start, end) HIP events]} when a dict (bench.py)
         self.timed_names = None                               # restrict the timers to these kernel names (None = all)
@@ -218,8 +219,13 @@ class Engine:
             return [(0, M)]
         return [(0, m_cut), (m_cut, M)]
 
+    def _adam_args(self, off_floats: int, fused) -> "AdamArgs":
+        """nadm_adam_t for the rows of the big buffer that start at float offset ``off_floats``; fused = (lr, grad_scale)."""
+        lr, scale = fused
+        return AdamArgs(self.mbig.data_ptr() + off_floats * 4, self.vbig.data_ptr() + off_floats * 4, lr, self.step_count, scale)
+
     def decode_all(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_grad_ready=None, p_parts=1,
-                   supervised: bool = True) -> int:
+                   supervised: bool = True, fused_adam=None) -> int:
         """Pass 2 for every head (optionally on SNP sub-ranges, see backward) + the supervised term.  Returns the number of
         loss slots the MLP backward has to add up."""
         L, st = self.lay, _stream()
@@ -239,8 +245,11 @@ class Engine:
                         C.c_void_p(self.gbig.data_ptr() + (L.p_off[h] + m0 * kp) * fsz),
                         C.c_void_p(self.dqpart.data_ptr() + (dq_offs[h] + c0 * b * kp) * fsz),
                         C.c_void_p(self.losspart.data_ptr() + (loss_offs[h] + c0) * fsz), 1 if with_loss else 0)
-                if h == 0 and self.gather_batch:              # head 0's pass also leaves the batch's rows back to back in xg
-                    check(lib.nadm_decode_bce_gather(*args, C.c_void_p(self._xg_buf().data_ptr() + m0 // 4), st), "decode_bce_gather")
+                xg = C.c_void_p(self._xg_buf().data_ptr() + m0 // 4) if (h == 0 and self.gather_batch) else None
+                if fused_adam is not None:                    # single-GPU step: Adam + clamp on these P rows in the kernel's epilogue
+                    check(lib.nadm_decode_bce_step(*args, xg, C.byref(self._adam_args(L.p_off[h] + m0 * kp, fused_adam)), st), "decode_bce_step")
+                elif xg is not None:                          # head 0's pass also leaves the batch's rows back to back in xg
+                    check(lib.nadm_decode_bce_gather(*args, xg, st), "decode_bce_gather")
                 else:
                     check(lib.nadm_decode_bce(*args, st), "decode_bce")
                 if on_grad_ready is not None:
@@ -267,7 +276,7 @@ class Engine:
                                ptr(self.dZ), ptr(self.gsmall) if weights else None, ptr(self.losspart),
                                n_loss, ptr(self.loss_acc), st), "mlp_bwd")
 
-    def encode_backward(self, idx: torch.Tensor, b: int, on_grad_ready=None, v_parts: int = 1) -> None:
+    def encode_backward(self, idx: torch.Tensor, b: int, on_grad_ready=None, v_parts: int = 1, fused_adam=None) -> None:
         """Pass 3: dV = X^T.dZ (optionally on SNP sub-ranges)."""
         L, st, fsz = self.lay, _stream(), 4
         ev = self._timed("encode_bwd")
@@ -278,14 +287,20 @@ class Engine:
             src, rows = self.xp, idx
         self._xg_key = None
         for i, (m0, m1) in enumerate(self._snp_ranges(v_parts, 1024)):
-            check(lib.nadm_encode_bwd(C.c_void_p(src.data_ptr() + m0 // 4), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), L.CP,
-                                      C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz), st), "encode_bwd")
+            if fused_adam is not None:                        # single-GPU step: Adam on these V rows in the kernel's epilogue
+                check(lib.nadm_encode_bwd_step(C.c_void_p(src.data_ptr() + m0 // 4), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), L.CP,
+                                               C.c_void_p(self.big.data_ptr() + m0 * L.CP * fsz),
+                                               C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz),
+                                               C.byref(self._adam_args(m0 * L.CP, fused_adam)), st), "encode_bwd_step")
+            else:
+                check(lib.nadm_encode_bwd(C.c_void_p(src.data_ptr() + m0 // 4), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), L.CP,
+                                          C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz), st), "encode_bwd")
             if on_grad_ready is not None:                     # the first piece carries the small gradients in front of it
                 on_grad_ready(0 if i == 0 else self._ns_pad + m0 * L.CP, self._ns_pad + m1 * L.CP)
         if ev: ev[1].record()
 
     def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_decoder_done=None, on_mlp_bwd_done=None,
-                 on_grad_ready=None, p_parts=1, v_parts: int = 1) -> None:
+                 on_grad_ready=None, p_parts=1, v_parts: int = 1, fused_adam=None) -> None:
         """Decoder + BCE fwd/bwd per head, MLP backward, dV.  Gradients land in gbig / gsmall (views of gflat).
         ``on_decoder_done`` (optional callable) is invoked after all the dP kernels are enqueued.  With
         ``on_mlp_bwd_done`` the MLP weight gradients are left to that callback (nadm_mlp_bwd_weights on another stream).
@@ -293,13 +308,13 @@ class Engine:
         enqueued; passes 2 and 3 are launched on ``p_parts`` / ``v_parts`` SNP sub-ranges so that the data-parallel step can
         all-reduce one piece while the next is being computed (each head's P, or the two parts of a single head's P; the
         small gradients travel with the first piece of dV)."""
-        n_loss = self.decode_all(idx, b, with_loss, on_grad_ready, p_parts)
+        n_loss = self.decode_all(idx, b, with_loss, on_grad_ready, p_parts, fused_adam=fused_adam)
         if on_decoder_done is not None:
             on_decoder_done()
         self.mlp_backward(b, n_loss if with_loss else 0, weights=on_mlp_bwd_done is None)
         if on_mlp_bwd_done is not None:
             on_mlp_bwd_done()
-        self.encode_backward(idx, b, on_grad_ready, v_parts)
+        self.encode_backward(idx, b, on_grad_ready, v_parts, fused_adam=fused_adam)
 
     def adam_part(self, part: str, lr: float, grad_scale: float = 1.0, stream=None) -> None:
         """Adam (+ clamp for P) on one part of the parameters -- "P", "V" or "small" -- for the CURRENT step_count."""
@@ -341,6 +356,16 @@ class Engine:
         pieces that do not depend on pass 3 run on a second HIP stream underneath it: Adam + clamp of the P matrices as soon as pass 2 is
         done (HBM-bound, while passes 2'/3 are issue-bound), the MLP weight gradients and the small Adam as soon as the
         MLP backward has produced dZ.  Enabled with ``Engine.overlap = True`` (off by default, see __init__)."""
+        if self.fused_adam and not self.overlap:
+            # Adam on P and V where their gradients are completed (epilogues of passes 2 and 3, nadm_*_step): same element
+            # update, same bits as the separate launches; the big gradient buffer is not written in this mode
+            self.forward(idx, b)
+            self.step_count += 1
+            self.backward(idx, b, with_loss, fused_adam=(lr, 1.0))
+            ev = self._timed("adam")
+            self.adam_part("small", lr, 1.0)
+            if ev: ev[1].record()
+            return
         if not self.overlap or self.device.type != "cuda":
             self.forward(idx, b)
             self.backward(idx, b, with_loss)

@@ -948,3 +948,28 @@ def test_pass2_gather_byproduct_and_pass3_on_the_compact_copy(K):
         e2.train_step(idx, b, 2e-3, True)
     torch.cuda.synchronize()
     assert torch.equal(e1.big, e2.big) and torch.equal(e1.small, e2.small) and e1.read_loss() == e2.read_loss()
+
+
+@pytest.mark.parametrize("ks,C", [([5], 8), ([13], 8), ([20], 8), ([2, 3, 4], 8), ([6], 12)])
+def test_adam_in_the_epilogues_of_passes_2_and_3_equals_the_separate_launches(ks, C):
+    """Single-GPU step: nadm_decode_bce_step / nadm_encode_bwd_step apply Adam (+ clamp of P) to the rows whose gradient the
+    block has just completed; the step must leave parameters and Adam moments bit-identical to passes + nadm_adam.  Covers
+    the matrix-core kernels (K <= 8, K 9..16), the variants that run the update as a second kernel (K = 20, C = 12), and
+    several heads; M = 2301 is ragged, b = 37 leaves a partial sample tile."""
+    dev = _dev()
+    N, M, b = 90, 2301, 37
+    Gm = O.synth_genotypes(N, M, 4, seed=31)
+    rng = np.random.default_rng(9)
+    p = O.make_params(3, (rng.standard_normal((M, C)) / 48).astype(np.float32), rng.uniform(0.0, 1.0, (sum(ks), M)).astype(np.float32), 64, ks)
+    e1, e2 = make_engine(Gm, p, b), make_engine(Gm, p, b)
+    assert e1.fused_adam
+    e2.fused_adam = False
+    for s in range(4):
+        idx = torch.from_numpy(rng.permutation(N)[:b].astype(np.int32)).to(dev)
+        e1.train_step(idx, b, 2e-3, s % 2 == 0)
+        e2.train_step(idx, b, 2e-3, s % 2 == 0)
+    torch.cuda.synchronize()
+    assert e1.step_count == e2.step_count == 4
+    assert torch.equal(e1.big, e2.big) and torch.equal(e1.mbig, e2.mbig) and torch.equal(e1.vbig, e2.vbig)
+    assert torch.equal(e1.small, e2.small) and e1.read_loss() == e2.read_loss()
+    assert float(e1.P(0).min()) >= 0.0 and float(e1.P(0).max()) <= 1.0
