@@ -81,11 +81,12 @@ class SnpShardedEngine(Engine):
         self._all_reduce(zs)
         self.mlp_forward(b, zs, 1)
 
-    def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True, **_unused) -> None:
+    def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True, fused_adam=None, **_unused) -> None:
         """Pass 2 on the slice (dP is final and local), partial dQ -> sum over ranks -> replicated MLP backward (dZ and the
         small gradients come out identical on every rank), pass 3 on the slice (dV final and local)."""
         L = self.lay
-        n_loss = self.decode_all(idx, b, with_loss, supervised=(self.rank == 0))   # the supervised term must enter the sum once
+        fa = {} if fused_adam is None else {"fused_adam": fused_adam}
+        n_loss = self.decode_all(idx, b, with_loss, supervised=(self.rank == 0), **fa)   # the supervised term must enter the sum once
         dq_offs, _ = L.dq_offsets(b)
         dqs = self._dqsum[: b * L.SP]
         o = 0
@@ -95,11 +96,16 @@ class SnpShardedEngine(Engine):
             o += b * kp
         self._all_reduce(dqs)
         self.mlp_backward(b, n_loss if with_loss else 0, dq_src=dqs, dq_M=1)
-        self.encode_backward(idx, b)
+        self.encode_backward(idx, b, **fa)
 
     def train_step(self, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True) -> None:
         """One step on the global batch idx; the 1/world gradient scale reproduces DDP's mean over ranks."""
         self.forward(idx, b)
+        if self.fused_adam:          # dP and dV of the slice are final and local: Adam in the epilogues of passes 2 and 3
+            self.step_count += 1
+            self.backward(idx, b, with_loss, fused_adam=(lr, 1.0 / self.world))
+            self.adam_part("small", lr, 1.0 / self.world)
+            return
         self.backward(idx, b, with_loss)
         self.adam(lr, 1.0 / self.world)
 
