@@ -40,7 +40,7 @@ extern "C" {
 
 #define NADM_MAX_HEADS 32
 #define NADM_MAX_K 64
-#define NADM_ABI_VERSION 4   /* 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t); 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
+#define NADM_ABI_VERSION 4   /* 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
@@ -163,8 +163,20 @@ int nadm_decode_bce_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int3
                          float* P, int32_t kp, const float* Q, int32_t SP,
                          float* dP, float* dqpart, float* losspart, int32_t with_loss,
                          uint8_t* xg, const nadm_adam_t* adam, void* stream);
+/* `weights` (may be NULL): the MLP weight-gradient partials -- the first half of nadm_mlp_bwd_weights, which like pass 3
+ * depends only on the outputs of nadm_mlp_bwd(grad_small = NULL) -- are computed by extra blocks of the same launch (they
+ * fill the under-occupied last round of pass 3) into small_part [nadm_sample_splits(b), n_small]; nadm_small_grads then
+ * sums them into grad_small and, with Adam state, updates the small parameters in the same launch. */
+typedef struct {
+    const nadm_heads_t* hd;
+    const float *Zn, *H, *dL, *dHpre, *dgp;   /* as for nadm_mlp_bwd_weights */
+    float* small_part;
+} nadm_mlp_weights_t;
 int nadm_encode_bwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                         const float* dZ, int32_t CP, float* V, float* dV, const nadm_adam_t* adam, void* stream);
+                         const float* dZ, int32_t CP, float* V, float* dV, const nadm_adam_t* adam,
+                         const nadm_mlp_weights_t* weights, void* stream);
+int nadm_small_grads(const float* small_part, int32_t splits, int32_t n_small, float* grad_small, float* small,
+                     const nadm_adam_t* adam, void* stream);
 
 /* ---- a11: MLP backward (softmax, Linear, ReLU, RMSNorm) ---------------------------------- */
 /* Reduces dqpart (the heads' slabs laid back to back in head order, head h holding

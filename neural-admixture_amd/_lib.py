@@ -29,6 +29,12 @@ class AdamArgs(C.Structure):
     _fields_ = [("m", C.c_void_p), ("v", C.c_void_p), ("lr", C.c_float), ("step", C.c_int32), ("grad_scale", C.c_float)]
 
 
+class MlpWeights(C.Structure):
+    """nadm_mlp_weights_t (include/nadm.h)."""
+    _fields_ = [("hd", C.POINTER(Heads)), ("Zn", C.c_void_p), ("H", C.c_void_p), ("dL", C.c_void_p), ("dHpre", C.c_void_p),
+                ("dgp", C.c_void_p), ("small_part", C.c_void_p)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
@@ -61,7 +67,8 @@ def _load():
         "nadm_decode_bce": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
         "nadm_decode_bce_gather": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp]),
         "nadm_decode_bce_step": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
-        "nadm_encode_bwd_step": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp, vp, vp]),
+        "nadm_encode_bwd_step": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp, vp, vp, vp]),
+        "nadm_small_grads": (C.c_int, [vp, i32, i32, vp, vp, vp, vp]),
         "nadm_mlp_bwd": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]),
         "nadm_mlp_bwd_weights": (C.c_int, [HP, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         "nadm_supervised_ce": (C.c_int, [vp, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp]),

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/nadm.h"
 
 namespace nadm {
 
@@ -69,6 +70,63 @@ __device__ __forceinline__ void adam_float4(float* __restrict__ p, const float4 
     *reinterpret_cast<float4*>(p) = make_float4(pp[0], pp[1], pp[2], pp[3]);
     *reinterpret_cast<float4*>(m) = make_float4(mm[0], mm[1], mm[2], mm[3]);
     *reinterpret_cast<float4*>(v) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+}
+
+// ---- MLP weight gradients, one block of the (hidden/256, sample splits) grid: see mlp_bwd_b_kernel (nadm_small_kernels.hip).
+// A device function so that pass 3 can run these blocks as extra blocks of its own launch (both depend only on the MLP
+// backward's outputs; the ~200 small blocks fill the under-occupied last round of pass 3 instead of a launch of their own).
+constexpr int SJ = 16;          // samples per split in the weight-gradient kernel
+__device__ __forceinline__ void mlp_bwd_b_block(const nadm_heads_t& hd, int b, const float* __restrict__ Zn,
+                                                const float* __restrict__ H, const float* __restrict__ dL,
+                                                const float* __restrict__ dHpre, const float* __restrict__ dgp,
+                                                float* __restrict__ small_part, const int bx, const int by) {
+    const int C = hd.C, CP = hd.CP, Hd = hd.Hd, SP = hd.SP;
+    const int tid = threadIdx.x;
+    const int h = bx * 256 + tid;
+    const int j = by;
+    const int i0 = j * SJ, i1 = min(b, i0 + SJ);
+    float* out = small_part + (int64_t)j * hd.n_small;
+    if (h < Hd) {
+        float hv[SJ], dv[SJ];                 // this thread's column of H / dHpre for the split (coalesced loads, issued together)
+#pragma unroll
+        for (int ii = 0; ii < SJ; ++ii) {
+            const bool ok = i0 + ii < i1;
+            hv[ii] = ok ? H[(int64_t)(i0 + ii) * Hd + h] : 0.f;
+            dv[ii] = ok ? dHpre[(int64_t)(i0 + ii) * Hd + h] : 0.f;
+        }
+        float ab = 0.f;
+#pragma unroll
+        for (int ii = 0; ii < SJ; ++ii) ab += dv[ii];
+        out[hd.b1_off + h] = ab;
+        for (int c = 0; c < C; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int ii = 0; ii < SJ; ++ii) a = fmaf(dv[ii], (i0 + ii < i1) ? Zn[(int64_t)(i0 + ii) * CP + c] : 0.f, a);
+            out[hd.w1_off + h * C + c] = a;
+        }
+        for (int hh = 0; hh < hd.n_heads; ++hh) {
+            const int o = hd.qoff[hh];
+            for (int k = 0; k < hd.k[hh]; ++k) {
+                float a = 0.f;
+#pragma unroll
+                for (int ii = 0; ii < SJ; ++ii) a = fmaf((i0 + ii < i1) ? dL[(int64_t)(i0 + ii) * SP + o + k] : 0.f, hv[ii], a);
+                out[hd.wk_off[hh] + k * Hd + h] = a;
+            }
+        }
+    }
+    if (bx == 0) {
+        for (int hh = 0; hh < hd.n_heads; ++hh)
+            for (int k = tid; k < hd.k[hh]; k += 256) {
+                float a = 0.f;
+                for (int i = i0; i < i1; ++i) a += dL[(int64_t)i * SP + hd.qoff[hh] + k];
+                out[hd.bk_off[hh] + k] = a;
+            }
+        for (int c = tid; c < C; c += 256) {
+            float a = 0.f;
+            for (int i = i0; i < i1; ++i) a += dgp[(int64_t)i * CP + c];
+            out[hd.g_off + c] = a;
+        }
+    }
 }
 
 // ---- BCE element: clamp, loss term, gradient w.r.t. the pre-clamp reconstruction ------------

@@ -14,6 +14,8 @@
 #include "nadm_common.h"
 #include "../../include/nadm.h"
 #include "nadm_host.h"
+extern "C" int nadm_mlp_bwd_weight_parts(const nadm_heads_t* hd, int32_t b, const float* Zn, const float* H, const float* dL,
+                                         const float* dHpre, const float* dgp, float* small_part, void* stream);
 #include <stdlib.h>
 #include <string.h>
 
@@ -1220,6 +1222,12 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
 //   32-sample tile by one wave and shared through LDS.  block = 4 waves x 128 SNPs; tiles are
 //   double-buffered, global loads for tile t+1 are issued before tile t is computed.
 // =================================================================================================
+struct MlpSide {               // small_part == nullptr: no side work
+    nadm_heads_t hd;
+    int b, gx;
+    const float *Zn, *H, *dL, *dHpre, *dgp;
+    float* small_part;
+};
 constexpr int EB_TS = 32;                 // samples per k-step / tile
 constexpr int EB_G = 2;                   // 64-SNP groups per wave
 constexpr int EB_COLS = 4 * EB_G * 16;    // packed byte columns per block (128)
@@ -1234,8 +1242,16 @@ template <int CP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void encode_bwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
                                                               const int32_t* __restrict__ idx, int b, int64_t M,
                                                               const float* __restrict__ dZ, float* __restrict__ dV,
-                                                              uint32_t missing_bf16, float* __restrict__ Vrw, AdamFused ad) {
+                                                              uint32_t missing_bf16, float* __restrict__ Vrw, AdamFused ad, MlpSide side) {
     static_assert(CP <= 8, "hi|mid and lo|0 share the 16 MFMA rows");
+    {   // blocks past the SNP chunks: the MLP weight-gradient partials (independent of pass 3; see mlp_bwd_b_block)
+        const int64_t nchunks = (M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS;
+        if ((int64_t)blockIdx.x >= nchunks) {
+            const int e = (int)(blockIdx.x - nchunks);
+            mlp_bwd_b_block(side.hd, side.b, side.Zn, side.H, side.dL, side.dHpre, side.dgp, side.small_part, e % side.gx, e / side.gx);
+            return;
+        }
+    }
     __shared__ __attribute__((aligned(16))) uint8_t s_xt[2][EB_COLS * EB_CS];
     __shared__ __attribute__((aligned(16))) uint4 s_a[2][2][64];
     __shared__ __attribute__((aligned(16))) float4 s_dvbuf[EB_CHUNK_SNPS * CP / 4];       // the block's dV rows (epilogue)
@@ -1659,16 +1675,25 @@ extern "C" int nadm_decode_bce_step(const uint8_t* xp, int64_t ld, const int32_t
 
 static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                            const float* dZ, int32_t CP, float* dV, void* stream, uint32_t missing_bf16,
-                           float* Vrw = nullptr, AdamFused ad = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f}) {
+                           float* Vrw = nullptr, AdamFused ad = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f},
+                           const nadm_mlp_weights_t* mw = nullptr) {
     if (!xp || !idx || !dZ || !dV) return fail("nadm_encode_bwd: null pointer");
     if (b <= 0 || M <= 0) return fail("nadm_encode_bwd: empty batch or M");
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_encode_bwd: ld must be a multiple of 16 and >= ceil(M/4)");
     dim3 grid((unsigned)((M + 1023) / 1024)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (CP <= 8 && use_mfma_encode()) {
-        dim3 g2((unsigned)((M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS));
-        if (CP == 4) hipLaunchKernelGGL((encode_bwd_mfma_kernel<4>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV, missing_bf16, Vrw, ad);
-        else hipLaunchKernelGGL((encode_bwd_mfma_kernel<8>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV, missing_bf16, Vrw, ad);
+        MlpSide side;
+        memset(&side, 0, sizeof(side));
+        int64_t extra = 0;
+        if (mw) {
+            side.hd = *mw->hd; side.b = b; side.gx = (mw->hd->Hd + 255) / 256;
+            side.Zn = mw->Zn; side.H = mw->H; side.dL = mw->dL; side.dHpre = mw->dHpre; side.dgp = mw->dgp; side.small_part = mw->small_part;
+            extra = (int64_t)side.gx * nadm_sample_splits(b);
+        }
+        dim3 g2((unsigned)((M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS + extra));
+        if (CP == 4) hipLaunchKernelGGL((encode_bwd_mfma_kernel<4>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV, missing_bf16, Vrw, ad, side);
+        else hipLaunchKernelGGL((encode_bwd_mfma_kernel<8>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV, missing_bf16, Vrw, ad, side);
         return check_launch("encode_bwd_mfma");
     }
     switch (CP) {
@@ -1681,15 +1706,19 @@ static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
         default: return fail("nadm_encode_bwd: unsupported CP (4,8,12,16,24,32)");
     }
     if (check_launch("encode_bwd")) return 1;
-    return ad.m ? launch_adam_range(Vrw, dV, ad, M * CP, st, 0) : 0;      // fp32 variants of pass 3: stand-alone update
+    if (ad.m && launch_adam_range(Vrw, dV, ad, M * CP, st, 0)) return 1;  // fp32 variants of pass 3: stand-alone update
+    return mw ? nadm_mlp_bwd_weight_parts(mw->hd, b, mw->Zn, mw->H, mw->dL, mw->dHpre, mw->dgp, mw->small_part, stream) : 0;
 }
 
 extern "C" int nadm_encode_bwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                                    const float* dZ, int32_t CP, float* V, float* dV, const nadm_adam_t* adam, void* stream) {
+                                    const float* dZ, int32_t CP, float* V, float* dV, const nadm_adam_t* adam,
+                                    const nadm_mlp_weights_t* weights, void* stream) {
     AdamFused ad;
     if (adam_fused_args(adam, "nadm_encode_bwd_step: Adam state is NULL", &ad)) return 1;
     if (ad.m && (!V || ((uintptr_t)V & 15))) return fail("nadm_encode_bwd_step: V must be non-NULL and 16-byte aligned");
-    return encode_bwd_impl(xp, ld, idx, b, M, dZ, CP, dV, stream, 0u, V, ad);
+    if (weights && (!weights->hd || !weights->Zn || !weights->H || !weights->dL || !weights->dHpre || !weights->dgp || !weights->small_part))
+        return fail("nadm_encode_bwd_step: null pointer in the MLP weight-gradient arguments");
+    return encode_bwd_impl(xp, ld, idx, b, M, dZ, CP, dV, stream, 0u, V, ad, weights);
 }
 
 extern "C" int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,

@@ -14,7 +14,6 @@
 
 namespace nadm {
 
-constexpr int SJ = 16;          // samples per split in the weight-gradient kernel
 constexpr int MLP_SB = 4;       // samples per block in mlp_fwd / mlp_bwd_a
 struct DqChunks { int64_t n[NADM_MAX_HEADS]; };   // per-head chunk counts of the dQ partial slabs
 
@@ -813,53 +812,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_b_kernel(nadm_heads_t hd, int b, 
                                                         const float* __restrict__ H, const float* __restrict__ dL,
                                                         const float* __restrict__ dHpre, const float* __restrict__ dgp,
                                                         float* __restrict__ small_part) {
-    const int C = hd.C, CP = hd.CP, Hd = hd.Hd, SP = hd.SP;
-    const int tid = threadIdx.x;
-    const int h = blockIdx.x * 256 + tid;
-    const int j = blockIdx.y;
-    const int i0 = j * SJ, i1 = min(b, i0 + SJ);
-    float* out = small_part + (int64_t)j * hd.n_small;
-    if (h < Hd) {
-        float hv[SJ], dv[SJ];                 // this thread's column of H / dHpre for the split (coalesced loads, issued together)
-#pragma unroll
-        for (int ii = 0; ii < SJ; ++ii) {
-            const bool ok = i0 + ii < i1;
-            hv[ii] = ok ? H[(int64_t)(i0 + ii) * Hd + h] : 0.f;
-            dv[ii] = ok ? dHpre[(int64_t)(i0 + ii) * Hd + h] : 0.f;
-        }
-        float ab = 0.f;
-#pragma unroll
-        for (int ii = 0; ii < SJ; ++ii) ab += dv[ii];
-        out[hd.b1_off + h] = ab;
-        for (int c = 0; c < C; ++c) {
-            float a = 0.f;
-#pragma unroll
-            for (int ii = 0; ii < SJ; ++ii) a = fmaf(dv[ii], (i0 + ii < i1) ? Zn[(int64_t)(i0 + ii) * CP + c] : 0.f, a);
-            out[hd.w1_off + h * C + c] = a;
-        }
-        for (int hh = 0; hh < hd.n_heads; ++hh) {
-            const int o = hd.qoff[hh];
-            for (int k = 0; k < hd.k[hh]; ++k) {
-                float a = 0.f;
-#pragma unroll
-                for (int ii = 0; ii < SJ; ++ii) a = fmaf((i0 + ii < i1) ? dL[(int64_t)(i0 + ii) * SP + o + k] : 0.f, hv[ii], a);
-                out[hd.wk_off[hh] + k * Hd + h] = a;
-            }
-        }
-    }
-    if (blockIdx.x == 0) {
-        for (int hh = 0; hh < hd.n_heads; ++hh)
-            for (int k = tid; k < hd.k[hh]; k += 256) {
-                float a = 0.f;
-                for (int i = i0; i < i1; ++i) a += dL[(int64_t)i * SP + hd.qoff[hh] + k];
-                out[hd.bk_off[hh] + k] = a;
-            }
-        for (int c = tid; c < C; c += 256) {
-            float a = 0.f;
-            for (int i = i0; i < i1; ++i) a += dgp[(int64_t)i * CP + c];
-            out[hd.g_off + c] = a;
-        }
-    }
+    mlp_bwd_b_block(hd, b, Zn, H, dL, dHpre, dgp, small_part, blockIdx.x, blockIdx.y);
 }
 
 __global__ void small_reduce_kernel(const float* __restrict__ part, int splits, int n, float* __restrict__ out) {
@@ -1248,6 +1201,47 @@ extern "C" int nadm_mlp_bwd_weights(const nadm_heads_t* hd, int32_t b, const flo
     hipLaunchKernelGGL(mlp_bwd_b_kernel, dim3((hd->Hd + 255) / 256, splits), dim3(256), 0, st, *hd, b, Zn, H, dL, dHpre, dgp, small_part);
     hipLaunchKernelGGL(small_reduce_kernel, dim3((hd->n_small + 255) / 256), dim3(256), 0, st, small_part, splits, hd->n_small, grad_small);
     return check_launch("mlp_bwd_weights");
+}
+
+// the partial sums only (the first kernel of nadm_mlp_bwd_weights): used by the variants of pass 3 that cannot host them
+extern "C" int nadm_mlp_bwd_weight_parts(const nadm_heads_t* hd, int32_t b, const float* Zn, const float* H, const float* dL,
+                                         const float* dHpre, const float* dgp, float* small_part, void* stream) {
+    hipLaunchKernelGGL(mlp_bwd_b_kernel, dim3((hd->Hd + 255) / 256, nadm_sample_splits(b)), dim3(256), 0, (hipStream_t)stream, *hd, b, Zn, H, dL,
+                       dHpre, dgp, small_part);
+    return check_launch("mlp_bwd_weight_parts");
+}
+
+// sum of the sample-split partials (fixed order, as small_reduce_kernel) -> grad_small, then -- when Adam state is given --
+// the Adam update of the small parameters in the same thread: one launch for the tail of a single-GPU step
+__global__ void small_reduce_adam_kernel(const float* __restrict__ part, int splits, int n, float* __restrict__ out,
+                                         float* __restrict__ p, AdamFused ad) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float a = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < splits; ++j) a += part[(int64_t)j * n + e];
+    out[e] = a;
+    if (ad.m != nullptr) {
+        float mq = ad.m[e], vq = ad.v[e];
+        p[e] = adam_element(p[e], a, mq, vq, ad.step_size, ad.bc2_sqrt, ad.grad_scale, false);
+        ad.m[e] = mq; ad.v[e] = vq;
+    }
+}
+
+extern "C" int nadm_small_grads(const float* small_part, int32_t splits, int32_t n_small, float* grad_small, float* small,
+                                const nadm_adam_t* adam, void* stream) {
+    if (!small_part || !grad_small) return fail("nadm_small_grads: null pointer");
+    if (splits <= 0 || n_small <= 0) return fail("nadm_small_grads: empty");
+    AdamFused ad{nullptr, nullptr, 0.f, 0.f, 0.f};
+    if (adam) {
+        if (!adam->m || !adam->v || !small) return fail("nadm_small_grads: Adam state / parameters are NULL");
+        if (adam->step < 1) return fail("nadm_small_grads: Adam step is 1-based");
+        ad.m = adam->m; ad.v = adam->v; ad.grad_scale = adam->grad_scale;
+        adam_scalars(adam->lr, adam->step, &ad.step_size, &ad.bc2_sqrt);
+    }
+    hipLaunchKernelGGL(small_reduce_adam_kernel, dim3((n_small + 255) / 256), dim3(256), 0, (hipStream_t)stream, small_part, splits, n_small,
+                       grad_small, small, ad);
+    return check_launch("small_grads");
 }
 
 extern "C" int nadm_supervised_ce(const float* Q, int32_t SP, int32_t k, int32_t kp, const int32_t* labels, const int32_t* idx,

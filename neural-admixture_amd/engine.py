@@ -16,7 +16,7 @@ import os
 import numpy as np
 import torch
 
-from ._lib import lib, check, ptr, AdamArgs
+from ._lib import lib, check, ptr, AdamArgs, MlpWeights
 from .layout import ModelLayout
 
 _f32 = torch.float32
@@ -68,6 +68,7 @@ class Engine:
         self._xg: Optional[torch.Tensor] = None
         self._iota: Optional[torch.Tensor] = None
         self._xg_key = None
+        self.side_weights = device.type == "cuda"            # MLP weight-gradient partials as extra blocks of pass 3's launch
         self.fused_adam = device.type == "cuda" and os.environ.get("NADM_FUSED_ADAM", "1") != "0"   # see train_step
         self.sync_tail_message = os.environ.get("NADM_DDP_SYNC_TAIL", "1") != "0"   # see train_step_ddp.send
         self.timers: Optional[dict] = None                    # {name: [(start, end) HIP events]} when a dict (bench.py)
@@ -276,9 +277,16 @@ class Engine:
                                ptr(self.dZ), ptr(self.gsmall) if weights else None, ptr(self.losspart),
                                n_loss, ptr(self.loss_acc), st), "mlp_bwd")
 
-    def encode_backward(self, idx: torch.Tensor, b: int, on_grad_ready=None, v_parts: int = 1, fused_adam=None) -> None:
-        """Pass 3: dV = X^T.dZ (optionally on SNP sub-ranges)."""
+    def encode_backward(self, idx: torch.Tensor, b: int, on_grad_ready=None, v_parts: int = 1, fused_adam=None,
+                        side_weights: bool = False) -> None:
+        """Pass 3: dV = X^T.dZ (optionally on SNP sub-ranges).  ``side_weights``: the MLP weight-gradient partials (left out by
+        mlp_backward(weights=False)) are computed by extra blocks of the first launch, then summed into gsmall -- and, with
+        ``fused_adam``, applied to the small parameters -- by one small launch (nadm_small_grads)."""
         L, st, fsz = self.lay, _stream(), 4
+        mw = None
+        if side_weights:
+            mw = MlpWeights(C.pointer(L.heads), self.Zn.data_ptr(), self.H.data_ptr(), self.dL.data_ptr(), self.dHpre.data_ptr(),
+                            self.dgp.data_ptr(), self.small_part.data_ptr())
         ev = self._timed("encode_bwd")
         # rows: the compact copy pass 2 of this step left in xg (rows 0..b-1 = the batch in order), else the resident matrix
         if self._xg_key == (idx.data_ptr(), b) and self._xg is not None:
@@ -287,11 +295,19 @@ class Engine:
             src, rows = self.xp, idx
         self._xg_key = None
         for i, (m0, m1) in enumerate(self._snp_ranges(v_parts, 1024)):
-            if fused_adam is not None:                        # single-GPU step: Adam on these V rows in the kernel's epilogue
+            side = mw if i == 0 else None
+            if fused_adam is not None or side is not None:    # Adam on these V rows in the epilogue and / or the side blocks
                 check(lib.nadm_encode_bwd_step(C.c_void_p(src.data_ptr() + m0 // 4), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), L.CP,
                                                C.c_void_p(self.big.data_ptr() + m0 * L.CP * fsz),
                                                C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz),
-                                               C.byref(self._adam_args(m0 * L.CP, fused_adam)), st), "encode_bwd_step")
+                                               C.byref(self._adam_args(m0 * L.CP, fused_adam)) if fused_adam is not None else None,
+                                               C.byref(side) if side is not None else None, st), "encode_bwd_step")
+                if side is not None:
+                    sa = None
+                    if fused_adam is not None:
+                        sa = C.byref(AdamArgs(self.msmall.data_ptr(), self.vsmall.data_ptr(), fused_adam[0], self.step_count, fused_adam[1]))
+                    check(lib.nadm_small_grads(ptr(self.small_part), int(lib.nadm_sample_splits(b)), L.n_small, ptr(self.gsmall),
+                                               ptr(self.small), sa, st), "small_grads")
             else:
                 check(lib.nadm_encode_bwd(C.c_void_p(src.data_ptr() + m0 // 4), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), L.CP,
                                           C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz), st), "encode_bwd")
@@ -300,7 +316,7 @@ class Engine:
         if ev: ev[1].record()
 
     def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_decoder_done=None, on_mlp_bwd_done=None,
-                 on_grad_ready=None, p_parts=1, v_parts: int = 1, fused_adam=None) -> None:
+                 on_grad_ready=None, p_parts=1, v_parts: int = 1, fused_adam=None, side_weights: bool = False) -> None:
         """Decoder + BCE fwd/bwd per head, MLP backward, dV.  Gradients land in gbig / gsmall (views of gflat).
         ``on_decoder_done`` (optional callable) is invoked after all the dP kernels are enqueued.  With
         ``on_mlp_bwd_done`` the MLP weight gradients are left to that callback (nadm_mlp_bwd_weights on another stream).
@@ -311,10 +327,10 @@ class Engine:
         n_loss = self.decode_all(idx, b, with_loss, on_grad_ready, p_parts, fused_adam=fused_adam)
         if on_decoder_done is not None:
             on_decoder_done()
-        self.mlp_backward(b, n_loss if with_loss else 0, weights=on_mlp_bwd_done is None)
+        self.mlp_backward(b, n_loss if with_loss else 0, weights=on_mlp_bwd_done is None and not side_weights)
         if on_mlp_bwd_done is not None:
             on_mlp_bwd_done()
-        self.encode_backward(idx, b, on_grad_ready, v_parts, fused_adam=fused_adam)
+        self.encode_backward(idx, b, on_grad_ready, v_parts, fused_adam=fused_adam, side_weights=side_weights)
 
     def adam_part(self, part: str, lr: float, grad_scale: float = 1.0, stream=None) -> None:
         """Adam (+ clamp for P) on one part of the parameters -- "P", "V" or "small" -- for the CURRENT step_count."""
@@ -361,10 +377,7 @@ class Engine:
             # update, same bits as the separate launches; the big gradient buffer is not written in this mode
             self.forward(idx, b)
             self.step_count += 1
-            self.backward(idx, b, with_loss, fused_adam=(lr, 1.0))
-            ev = self._timed("adam")
-            self.adam_part("small", lr, 1.0)
-            if ev: ev[1].record()
+            self.backward(idx, b, with_loss, fused_adam=(lr, 1.0), side_weights=True)    # small parameters: nadm_small_grads
             return
         if not self.overlap or self.device.type != "cuda":
             self.forward(idx, b)
@@ -447,7 +460,8 @@ class Engine:
         self.finish_ddp()                                     # the previous step's deferred P piece: needed from pass 2 on
         # message plan: one per head (a head's all-reduce runs under the next head's pass 2); a single head is cut where
         # its last round of blocks starts (_round_ranges); then the small gradients + dV as one message
-        self.backward(idx, b, with_loss, on_grad_ready=reduce_piece, p_parts="rounds" if len(L.ks) == 1 else 1, v_parts=1)
+        self.backward(idx, b, with_loss, on_grad_ready=reduce_piece, p_parts="rounds" if len(L.ks) == 1 else 1, v_parts=1,
+                      **({"side_weights": True} if self.side_weights else {}))
         scale = 1.0 / world
         self.step_count += 1
         off = self._ns_pad

@@ -95,16 +95,16 @@ class SnpShardedEngine(Engine):
             torch.sum(self.dqpart[dq_offs[h]: dq_offs[h] + ch * b * kp].view(ch, b * kp), dim=0, out=dqs[o: o + b * kp])
             o += b * kp
         self._all_reduce(dqs)
-        self.mlp_backward(b, n_loss if with_loss else 0, dq_src=dqs, dq_M=1)
-        self.encode_backward(idx, b, **fa)
+        side = fused_adam is not None                         # fused step: weight-gradient partials ride on pass 3's launch
+        self.mlp_backward(b, n_loss if with_loss else 0, dq_src=dqs, dq_M=1, weights=not side)
+        self.encode_backward(idx, b, **fa, **({"side_weights": True} if side else {}))
 
     def train_step(self, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True) -> None:
         """One step on the global batch idx; the 1/world gradient scale reproduces DDP's mean over ranks."""
         self.forward(idx, b)
         if self.fused_adam:          # dP and dV of the slice are final and local: Adam in the epilogues of passes 2 and 3
             self.step_count += 1
-            self.backward(idx, b, with_loss, fused_adam=(lr, 1.0 / self.world))
-            self.adam_part("small", lr, 1.0 / self.world)
+            self.backward(idx, b, with_loss, fused_adam=(lr, 1.0 / self.world))    # small parameters: nadm_small_grads
             return
         self.backward(idx, b, with_loss)
         self.adam(lr, 1.0 / self.world)
