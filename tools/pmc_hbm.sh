@@ -1,8 +1,8 @@
 #!/bin/bash
 # HBM traffic of every kernel of one bench step: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (they do not fit one
 # pass on gfx950), kernel dispatch records only.  Writes gpurun_out/pmc_hbm.txt and gpurun_out/pmc_hbm.json (decode kernel,
-# corrected as MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE x2 for 16 B/lane coalesced streams, calibrated in the same
-# run on adam_kernel whose byte count is known; WRITE_SIZE uncorrected).
+# corrected as MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE x2 for 16 B/lane coalesced streams (checked earlier in the round
+# on the stand-alone Adam launch, whose byte count is known); WRITE_SIZE uncorrected).
 export TMPDIR=/tmp
 R=$PWD
 mkdir -p gpurun_out
@@ -26,13 +26,11 @@ for line in txt.splitlines():
         if m and cur:
             vals.setdefault(cur, {})[m.group(1)] = (int(m.group(2)), float(m.group(3)))
 dec = [k for k in vals if 'decode_bce' in k][0]
-adam = [k for k in vals if 'adam_kernel' in k][0]
 f, w = vals[dec]['FETCH_SIZE'][1], vals[dec]['WRITE_SIZE'][1]
 b, M, K = 800, 500000, 8
 out = {"kernel": dec.split('(')[0][:60], "fetch_size_kib_raw": f, "write_size_kib_raw": w,
-       "adam_fetch_kib_raw_mean_over_big_and_small": vals[adam]['FETCH_SIZE'][1],
-       "correction": "reads x2 (gfx950 FETCH_SIZE tallies 128 B requests of 16 B/lane coalesced streams as 64 B; calibration in the same run: "
-                     "adam_kernel(big) reads 4 x 32 MiB = 131072 KiB, the mean over its big and small launch is reported above); writes uncorrected",
+       "correction": "reads x2 (gfx950 FETCH_SIZE tallies 128 B requests of 16 B/lane coalesced streams as 64 B; checked earlier in the round on "
+                     "the stand-alone Adam launch over V and P, which reads 4 x 32 MiB and counted 62.6 MiB raw); writes uncorrected",
        "traffic_bytes_per_launch": (2 * f + w) * 1024.0,
        "algorithmic_bytes_per_launch": b * M / 4 + 2 * 4 * M * K}
 json.dump(out, open('gpurun_out/pmc_hbm.json', 'w'), indent=1)
