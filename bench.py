@@ -218,7 +218,14 @@ def main():
     # dominant kernel = decode_bce.  Algorithmic bytes per launch: one 2-bit pass over the
     # batch (b*M/4) + read P and write dP once (2 * 4*M*K).
     dom = "decode_bce"
-    alg_bytes = (gb * eng.M / 4 + 2 * 4 * eng.M * K) if snp else (b * M / 4 + 2 * 4 * M * K)   # snp: global batch x own SNP slice
+    # Algorithmic bytes of one pass-2 launch, in the accounting of SURVEY.md 8d (whole step = 0.75 B/genotype of packed X +
+    # 36 B per parameter of parameter/optimizer traffic): one 2-bit pass over the batch + the pass's share of the
+    # per-parameter traffic.  Single-GPU and SNP-sharded steps run Adam on the P rows in the kernel's epilogue, so the launch
+    # carries ALL 36 B of a P parameter (read p; write/read g; read/write p, m, v); in the data-parallel step Adam is a
+    # launch of its own behind the all-reduce and pass 2 keeps only read p + write g = 8 B.
+    fused = (snp or not (world > 1 or args.force_ddp)) and getattr(eng, "fused_adam", False)
+    rows_b, m_loc = (gb, eng.M) if snp else (b, M)                       # snp: global batch x own SNP slice
+    alg_bytes = rows_b * m_loc / 4 + (36 if fused else 8) * m_loc * K
     traffic = None                                                      # HBM bytes/launch from the committed PMC passes (same workload)
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
@@ -242,6 +249,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kms, "alg_bytes_per_launch": alg_bytes,
+                     "alg_bytes_note": "2-bit pass over the batch + %d B per P parameter (%s)" % (
+                         36 if fused else 8, "Adam on P fused into the launch" if fused else "read P, write dP; Adam is a separate launch"),
                      "whole_step": {"alg_bytes": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
                                     "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
                      # algorithmic flops per genotype = 4C + 6K (X.V, Q.P^T, dP, dQ, dV); the pass-2 kernel

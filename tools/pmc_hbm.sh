@@ -32,7 +32,7 @@ out = {"kernel": dec.split('(')[0][:60], "fetch_size_kib_raw": f, "write_size_ki
        "correction": "reads x2 (gfx950 FETCH_SIZE tallies 128 B requests of 16 B/lane coalesced streams as 64 B; checked earlier in the round on "
                      "the stand-alone Adam launch over V and P, which reads 4 x 32 MiB and counted 62.6 MiB raw); writes uncorrected",
        "traffic_bytes_per_launch": (2 * f + w) * 1024.0,
-       "algorithmic_bytes_per_launch": b * M / 4 + 2 * 4 * M * K}
+       "algorithmic_bytes_per_launch": b * M / 4 + 36 * M * K}     # single-GPU step: Adam on P inside the launch (bench.py, alg_bytes)
 json.dump(out, open('gpurun_out/pmc_hbm.json', 'w'), indent=1)
 print(json.dumps(out))
 PY
