@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Wall-clock of full default runs (250 epochs, batch 800) on the 1000-Genomes-scale configs of BASELINE.json:
 c2 = 2504 samples x 600k SNPs, K=7 single head; c3 = same matrix, multi-head K=2..10; c4 = 100k x 500k, K=8 (the
-bench workload, here as a complete run on ONE GPU).  Synthetic admixture-model
+bench workload, here as a complete run on ONE GPU); c5 = 500k x 1M, K=16 (configs[4], 125 GB packed, on ONE GPU).  Synthetic admixture-model
 genotypes generated on the device; RSVD (GPU, from packed) + GMM init + training + final Q + log-likelihood + writing
-.Q/.P, i.e. everything `neural-admixture train` does after reading the file.  Usage: full_run.py [c2|c3|c4] [epochs]"""
+.Q/.P, i.e. everything `neural-admixture train` does after reading the file.  Usage: full_run.py [c2|c3|c4|c5] [epochs]"""
 import json
 import os
 import sys
@@ -28,21 +28,24 @@ def main():
     from neural_admixture_amd.layout import ModelLayout
     from neural_admixture_amd.svd import RSVD
     dev = torch.device("cuda:0")
-    N, M, Ktrue = (100_000, 500_000, 8) if which == "c4" else (2504, 600_000, 7)
+    N, M, Ktrue = {"c4": (100_000, 500_000, 8), "c5": (500_000, 1_000_000, 16)}.get(which, (2504, 600_000, 7))
     ld = ModelLayout.row_stride(M)
     torch.manual_seed(1234)
     Fq = (0.5 * torch.distributions.Beta(torch.tensor(0.5), torch.tensor(0.5)).sample((Ktrue, M))).clamp(0.005, 0.5).float().to(dev)
     Qt = torch.distributions.Dirichlet(torch.full((Ktrue,), 0.2)).sample((N,)).float().to(dev)
     xp = torch.empty((N, ld), dtype=torch.uint8, device=dev)
-    check(lib.nadm_synth_packed(ptr(xp), N, 0, M, ld, ptr(Qt), ptr(Fq), Ktrue, 0.01, 1234, None))
+    for r0 in range(0, N, 50_000):                                      # row blocks: the generator takes Qt per block
+        n = min(50_000, N - r0)
+        check(lib.nadm_synth_packed(ptr(xp[r0:]), n, r0, M, ld, ptr(Qt[r0:]), ptr(Fq), Ktrue, 0.01, 1234, None))
     torch.cuda.synchronize()
-    data = PackedGenotypes(xp if which == "c4" else xp.cpu(), N, M)     # c4: 12.5 GB, left resident in HBM (as after io.read_bed_packed(keep_on_device=True))
+    big = which in ("c4", "c5")
+    data = PackedGenotypes(xp if big else xp.cpu(), N, M)     # c4 / c5: 12.5 / 125 GB, left resident in HBM (as after io.read_bed_packed(keep_on_device=True))
     del xp
     out = {"config": which, "N": N, "M": M, "epochs": epochs}
     t0 = time.time()
     V = RSVD(data, N, M, 8, 42)
     out["rsvd_s"] = time.time() - t0
-    K, mn, mx = (7, None, None) if which == "c2" else ((8, None, None) if which == "c4" else (None, 2, 10))
+    K, mn, mx = {"c2": (7, None, None), "c4": (8, None, None), "c5": (16, None, None)}.get(which, (None, 2, 10))
     # phase timers inside train(): wrap the module-level helpers it calls
     import importlib
     tr_mod = importlib.import_module("neural_admixture_amd.train")
@@ -78,12 +81,12 @@ def main():
     idx = torch.randperm(N, device=dev).to(torch.int32)
     torch.cuda.synchronize()
     t3 = time.time()
-    for _ in range(10 if which != "c4" else 2):
+    for _ in range(10 if not big else (2 if which == "c4" else 1)):
         for s in range(0, N, 800):
             bb = min(800, N - s)
             eng.train_step(idx[s:s + bb], bb, 2e-3, False)
     torch.cuda.synchronize()
-    ep = (time.time() - t3) / (10 if which != "c4" else 2)
+    ep = (time.time() - t3) / (10 if not big else (2 if which == "c4" else 1))
     out["epoch_s"] = ep
     out["genotypes_per_s_epoch_loop"] = N * M / ep
     print(json.dumps(out))
