@@ -973,3 +973,53 @@ def test_adam_in_the_epilogues_of_passes_2_and_3_equals_the_separate_launches(ks
     assert torch.equal(e1.big, e2.big) and torch.equal(e1.mbig, e2.mbig) and torch.equal(e1.vbig, e2.vbig)
     assert torch.equal(e1.small, e2.small) and e1.read_loss() == e2.read_loss()
     assert float(e1.P(0).min()) >= 0.0 and float(e1.P(0).max()) <= 1.0
+
+
+def test_full_size_properties_of_the_step():
+    """BASELINE configs[3] width (M = 500k, b = 800, K = 8), properties that do not need an oracle of that size:
+    (1) equivariance: permuting the batch permutes Z / Q rows bit for bit (a row's sums do not depend on its tile position)
+        and leaves the loss and dP / dV unchanged up to the summation order over samples;
+    (2) additivity: loss, dP and dV of the batch = the sums over its two halves (BCE(sum) is a sum over samples);
+    (3) every Q row is a distribution per head; P stays in [0, 1] after an update; pad columns stay zero."""
+    import neural_admixture_amd as na
+    from neural_admixture_amd._lib import lib, check, ptr
+    dev = _dev()
+    b, M, K = 800, 500_000, 8
+    e = na.Engine(M, 8, 1024, [K], dev, b)
+    e.fused_adam = False                                  # gradients are inspected: keep them in gbig
+    g = torch.Generator(device="cpu").manual_seed(3)
+    Qt = torch.distributions.Dirichlet(torch.full((K,), 0.3)).sample((b,)).float().to(dev)
+    Fq = (0.5 * torch.rand(K, M, generator=g)).clamp(0.005, 0.5).to(dev)
+    xp = torch.empty((b, e.ld), dtype=torch.uint8, device=dev)
+    check(lib.nadm_synth_packed(ptr(xp), b, 0, M, e.ld, ptr(Qt), ptr(Fq), K, 0.02, 77, None))
+    e.set_packed(xp)
+    e.load_params((torch.randn(M, 8, generator=g) / M ** 0.5).numpy(), torch.rand(K, M, generator=g).mul(0.98).add(0.01).numpy(),
+                  na.model.init_encoder_weights(7, 8, 1024, [K]))
+    L = e.lay
+
+    def run(idx_t, n):
+        e.forward(idx_t, n)
+        Z = e.Z[: n * L.CP].view(n, L.CP).clone()
+        Q = e.Q[: n * L.SP].view(n, L.SP).clone()
+        e.backward(idx_t, n, True)
+        torch.cuda.synchronize()
+        return Z, Q, e.read_loss()[1], e.gP(0).clone(), e.gV().clone()
+
+    ident = torch.arange(b, dtype=torch.int32, device=dev)
+    Z0, Q0, l0, dP0, dV0 = run(ident, b)
+    perm = torch.randperm(b, generator=g).to(torch.int32).to(dev)
+    Z1, Q1, l1, dP1, dV1 = run(perm, b)
+    assert torch.equal(Z1, Z0[perm.long()]) and torch.equal(Q1, Q0[perm.long()])
+    assert abs(l1 - l0) / abs(l0) < 1e-6
+    sP, sV = float(dP0.abs().max()), float(dV0.abs().max())
+    assert float((dP1 - dP0).abs().max()) < 2e-5 * sP and float((dV1 - dV0).abs().max()) < 2e-5 * sV
+    h = b // 2
+    _, _, la, dPa, dVa = run(ident[:h].contiguous(), h)
+    _, _, lb, dPb, dVb = run(ident[h:].contiguous(), b - h)
+    assert abs((la + lb) - l0) / abs(l0) < 1e-6
+    assert float((dPa + dPb - dP0).abs().max()) < 2e-5 * sP and float((dVa + dVb - dV0).abs().max()) < 2e-5 * sV
+    assert float((Q0[:, :K].sum(dim=1) - 1).abs().max()) < 1e-5 and float(Q0.min()) >= 0.0
+    assert not bool(e.gbig[: M * L.CP].view(M, L.CP)[:, L.C:].any())
+    e.adam(2e-3)
+    torch.cuda.synchronize()
+    assert float(e.P(0).min()) >= 0.0 and float(e.P(0).max()) <= 1.0
