@@ -1239,7 +1239,7 @@ constexpr int EB_CHUNK_SNPS = EB_COLS * 4;
 constexpr int EB_D = NADM_EB_D;             // X tiles in flight per thread (global loads issued EB_D - 1 tiles ahead)
 
 template <int CP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void encode_bwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void encode_bwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
                                                               const int32_t* __restrict__ idx, int b, int64_t M,
                                                               const float* __restrict__ dZ, float* __restrict__ dV,
                                                               uint32_t missing_bf16, float* __restrict__ Vrw, AdamFused ad, MlpSide side) {
