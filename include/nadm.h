@@ -225,6 +225,11 @@ int64_t nadm_loglik_blocks(int64_t M);
 int nadm_loglik(const uint8_t* xp, int64_t ld, int64_t rows, int64_t M, const float* P, const float* Q, int32_t K,
                 int32_t q_stride, double eps, double* partial, void* stream);
 
+/* ---- VCF genotypes (src/snp_reader.py:73-87: scikit-allel read_vcf, calldata/GT as int8 with -1 fills, summed over the two
+ * alleles, negative sums -> 3).  buf = the whole decompressed file; out == NULL only counts samples and variant lines;
+ * out = uint8 [n_samples, n_variants], sample-major like the reference's matrix.  Host code (threads), no GPU. */
+int nadm_vcf_parse_gt(const char* buf, int64_t len, int64_t* n_samples, int64_t* n_variants, uint8_t* out);
+
 /* ---- 8(f)-4: ADMIXTURE-compatible text output ------------------------------------------------------------
  * np.savetxt(path, A, delimiter=' ') for a float32 host matrix, byte for byte ('%.18e' of the value widened to
  * double, src/utils.py:56-66); multi-threaded.  a [rows, cols] with row stride row_stride (elements). */

@@ -55,9 +55,16 @@ def parse_infer_args(argv):
 
 
 def _read(path, device=None, keep_on_device=False):
-    from .io import read_bed_packed
-    if ".bed" not in os.path.basename(path):
-        raise SystemExit("    Invalid format: this build reads PLINK .bed input (VCF/PGEN readers are the reference's own).")
+    from .io import read_bed_packed, read_vcf_packed
+    name = os.path.basename(path)
+    if ".vcf" in name:                                   # src/snp_reader.py:103
+        log.info("    Input format is VCF.")
+        data = read_vcf_packed(path, device, keep_on_device)
+        log.info(f"    Data contains {data.N} samples and {data.M} SNPs.")
+        return data
+    if ".bed" not in name:
+        raise SystemExit("    Invalid format. Unrecognized file format. Make sure file ends with .bed or .vcf (.pgen needs pgenlib "
+                         "through the reference's own reader).")
     log.info("    Input format is BED.")
     data = read_bed_packed(path, device, keep_on_device)
     log.info(f"    Data contains {data.N} samples and {data.M} SNPs.")

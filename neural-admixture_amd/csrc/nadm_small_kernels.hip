@@ -1254,6 +1254,74 @@ extern "C" int nadm_supervised_ce(const float* Q, int32_t SP, int32_t k, int32_t
     return check_launch("supervised_ce");
 }
 
+// VCF text -> genotype codes, the semantics of the reference's reader (src/snp_reader.py:73-87): scikit-allel's
+// read_vcf(fields=["calldata/GT"], types i1, fills -1) gives two allele indices per call (a missing or absent allele is -1),
+// the reader sums them and maps negative sums to 3.  So 0/0 -> 0, 0/1 -> 1, 1|1 -> 2, ./. -> 3, and -- as there -- a
+// half-missing call ./1 or a haploid call 1 sums to 0.  buf holds the whole (decompressed) file; out == NULL: only count.
+// Output is sample-major uint8 [n_samples, n_variants] like the reference's G.  Variant lines are parsed by std::threads.
+extern "C" int nadm_vcf_parse_gt(const char* buf, int64_t len, int64_t* n_samples, int64_t* n_variants, uint8_t* out) {
+    if (!buf || !n_samples || !n_variants) return fail("nadm_vcf_parse_gt: null pointer");
+    std::vector<int64_t> starts;                       // offsets of the variant lines
+    int64_t N = -1;
+    for (int64_t p = 0; p < len;) {
+        const char* nl = (const char*)memchr(buf + p, '\n', (size_t)(len - p));
+        const int64_t e = nl ? (nl - buf) : len;
+        if (e > p && buf[p] != '#') starts.push_back(p);
+        else if (e > p + 6 && memcmp(buf + p, "#CHROM", 6) == 0) {
+            int tabs = 0;
+            for (int64_t q = p; q < e; ++q) tabs += buf[q] == '\t';
+            N = tabs >= 9 ? tabs - 8 : 0;
+        }
+        p = e + 1;
+    }
+    if (N < 0) return fail("nadm_vcf_parse_gt: no #CHROM header line");
+    const int64_t M = (int64_t)starts.size();
+    *n_samples = N; *n_variants = M;
+    if (!out) return 0;
+    int bad = 0;
+    auto work = [&](int64_t v0, int64_t v1) {
+        for (int64_t v = v0; v < v1; ++v) {
+            int64_t p = starts[v];
+            int col = 0;
+            bool gt_first = false;
+            while (p < len && buf[p] != '\n' && col < 9) {          // skip the 9 fixed columns; FORMAT must start with GT
+                if (col == 8) gt_first = (p + 1 < len && buf[p] == 'G' && buf[p + 1] == 'T' && (p + 2 >= len || buf[p + 2] == ':' || buf[p + 2] == '\t'));
+                while (p < len && buf[p] != '\t' && buf[p] != '\n') ++p;
+                if (p < len && buf[p] == '\t') ++p;
+                ++col;
+            }
+            for (int64_t s = 0; s < N; ++s) {
+                int a[2] = {-1, -1}, na = 0;
+                if (p < len && buf[p] != '\n') {
+                    if (gt_first) {
+                        while (p < len && buf[p] != '\t' && buf[p] != '\n' && buf[p] != ':') {
+                            if (buf[p] == '/' || buf[p] == '|') { ++p; continue; }
+                            int val = -1;
+                            if (buf[p] == '.') ++p;
+                            else if (buf[p] >= '0' && buf[p] <= '9') { val = 0; while (p < len && buf[p] >= '0' && buf[p] <= '9') val = val * 10 + (buf[p++] - '0'); }
+                            else { __atomic_store_n(&bad, 1, __ATOMIC_RELAXED); ++p; }
+                            if (na < 2) a[na] = val;
+                            ++na;
+                        }
+                    }
+                    while (p < len && buf[p] != '\t' && buf[p] != '\n') ++p;
+                    if (p < len && buf[p] == '\t') ++p;
+                }
+                const int sum = a[0] + a[1];
+                out[s * M + v] = (uint8_t)(sum < 0 ? 3 : (sum > 255 ? 255 : sum));
+            }
+        }
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 32) nt = 32;
+    if ((int64_t)nt > M) nt = (unsigned)(M > 0 ? M : 1);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, M * t / nt, M * (t + 1) / nt);
+    for (auto& t : th) t.join();
+    return bad ? fail("nadm_vcf_parse_gt: unexpected character in a GT field") : 0;
+}
+
 // np.savetxt(path, A, delimiter=' ') for a float32 matrix, byte for byte: numpy formats every element with
 // '%.18e' applied to the value widened to double, one row per line, '\n' line ends (reference: src/utils.py:56-66).
 // Rows are formatted by std::threads into per-thread buffers and written in order.

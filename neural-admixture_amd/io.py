@@ -115,3 +115,47 @@ def read_bed_packed(path: str, device: Optional[torch.device] = None, keep_on_de
     if counts[1] == 0 and counts[2] == 0 and counts[3] == 0:
         raise AssertionError("Only biallelic SNPs are supported.")
     return PackedGenotypes(out, N, M, flipped)
+
+
+def orient_minor_allele(G: np.ndarray) -> np.ndarray:
+    """The reference's orientation rule (src/snp_reader.py:109-110): ``G if G.mean() < 1 else 2 - G``.  There the
+    subtraction is done in uint8, which turns a missing call 3 into 255; every consumer masks the code with 3 again
+    (pack2bit.cu:29), i.e. missing stays missing -- written out here."""
+    assert int(G.min()) == 0 and int(G.max()) in (2, 3), \
+        "Only biallelic SNPs are supported. Please make sure multiallelic sites have been removed."
+    if G.mean() < 1:
+        return G
+    return np.where(G == 3, 3, 2 - G).astype(np.uint8)
+
+
+def read_vcf(path: str) -> np.ndarray:
+    """.vcf / .vcf.gz -> uint8 [n_samples, n_variants] with the reference reader's conventions (src/snp_reader.py:73-87,
+    108-110): per call the two allele indices are summed, a missing allele counts -1 and a negative sum becomes 3 -- which
+    makes ./1 and a haploid 1 come out as 0, exactly as scikit-allel + the reference's sum do.  The GT fields are parsed
+    by nadm_vcf_parse_gt (host threads); scikit-allel itself is not needed."""
+    import ctypes as C
+    import gzip
+    from ._lib import lib, check
+    with (gzip.open(path, "rb") if str(path).endswith(".gz") else open(path, "rb")) as f:
+        buf = f.read()
+    n, m = C.c_int64(0), C.c_int64(0)
+    check(lib.nadm_vcf_parse_gt(buf, len(buf), C.byref(n), C.byref(m), None), "vcf_parse_gt")
+    if n.value <= 0 or m.value <= 0:
+        raise RuntimeError(f"{path}: no samples or no variant lines")
+    G = np.empty((n.value, m.value), dtype=np.uint8)
+    check(lib.nadm_vcf_parse_gt(buf, len(buf), C.byref(n), C.byref(m), C.c_void_p(G.ctypes.data)), "vcf_parse_gt")
+    return orient_minor_allele(G)
+
+
+def read_vcf_packed(path: str, device: Optional[torch.device] = None, keep_on_device: bool = False) -> PackedGenotypes:
+    """read_vcf + the 2-bit packing of the rest of the pipeline (what read_bed_packed returns for a .bed)."""
+    from ._lib import lib, check, ptr
+    from .layout import ModelLayout
+    G = read_vcf(path)
+    N, M = G.shape
+    ld = ModelLayout.row_stride(M)
+    out = torch.zeros((N, ld), dtype=torch.uint8)
+    check(lib.nadm_pack2bit_host(G.ctypes.data, ptr(out), N, M, ld), "pack2bit_host")
+    if keep_on_device and device is not None and device.type == "cuda":
+        out = out.to(device)
+    return PackedGenotypes(out, N, M, False)

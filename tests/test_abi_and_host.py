@@ -390,3 +390,49 @@ def test_epoch_order_is_the_random_sampler_sequence():
             got = epoch_order(g2, n)
             assert got.dtype == torch.int32 and np.array_equal(got.numpy(), want)
             assert torch.equal(g1.get_state(), g2.get_state())
+
+
+def test_vcf_reader_follows_the_reference_reader_conventions(tmp_path):
+    """io.read_vcf (nadm_vcf_parse_gt) against a plain-Python statement of what the reference's reader computes
+    (src/snp_reader.py:73-87,108-110: scikit-allel GT as int8 with -1 fills, summed over two alleles, negatives -> 3, then
+    the minor-allele orientation).  scikit-allel is not installed here, so the expected values are spelled out: phased and
+    unphased calls, extra FORMAT keys, missing, half-missing (sums to 0), haploid (sums to 0), .gz input."""
+    import gzip
+    from neural_admixture_amd.io import read_vcf, read_vcf_packed
+    hdr = "##fileformat=VCFv4.2\n##source=test\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\ts1\ts2\ts3\ts4\ts5\n"
+    rows = [
+        ("GT",       ["0/0", "0/1", "1/1", "./.", "1|0"]),
+        ("GT:DP:GQ", ["0|0:12:99", "1|1:3:20", "0/1:7:50", ".:0:0", "./1:1:1"]),
+        ("GT",       ["1", "0", ".", "0/0", "0/0"]),
+        ("GT:AD",    ["0/0:1,0", "0/0:2,0", "0/1:1,1", "0/0:.", ".|.:."]),
+    ]
+    body = "".join(f"1\t{100 + i}\trs{i}\tA\tG\t.\tPASS\t.\t{fmt}\t" + "\t".join(calls) + "\n" for i, (fmt, calls) in enumerate(rows))
+
+    def allel_sum(call):                                   # two alleles, -1 for a missing / absent one, summed; < 0 -> 3
+        gt = call.split(":")[0].replace("|", "/").split("/")
+        a = [(-1 if x == "." else int(x)) for x in gt][:2]
+        a += [-1] * (2 - len(a))
+        return 3 if sum(a) < 0 else sum(a)
+    def oriented(raw):                                     # snp_reader.py:110 (uint8 2 - G, codes masked with 3 downstream)
+        return raw if raw.mean() < 1 else np.where(raw == 3, 3, 2 - raw).astype(np.uint8)
+    raw1 = np.array([[allel_sum(c) for c in calls] for _, calls in rows], dtype=np.uint8).T       # [samples, variants]
+    want = oriented(raw1)
+    p = tmp_path / "t.vcf"
+    p.write_text(hdr + body)
+    got = read_vcf(str(p))
+    assert got.dtype == np.uint8 and np.array_equal(got, want)
+    with gzip.open(tmp_path / "t.vcf.gz", "wt") as f:
+        f.write(hdr + body)
+    assert np.array_equal(read_vcf(str(tmp_path / "t.vcf.gz")), want)
+    pk = read_vcf_packed(str(p))
+    assert (pk.N, pk.M) == want.shape and np.array_equal(pk.unpack_rows(0, pk.N), want)
+    # orientation: mostly-alternate genotypes are flipped, missing stays missing (snp_reader.py:110 + the &3 of the packer)
+    rows2 = [("GT", ["0/0", "0/0", "0/1", "./.", "0/0"]), ("GT", ["0/0", "1/1", "0/0", "0/0", "0/0"])]
+    body2 = "".join(f"1\t{i}\t.\tA\tG\t.\t.\t.\t{fmt}\t" + "\t".join(c) + "\n" for i, (fmt, c) in enumerate(rows2))
+    (tmp_path / "u.vcf").write_text(hdr + body2)
+    raw = np.array([[allel_sum(c) for c in calls] for _, calls in rows2], dtype=np.uint8).T
+    assert raw.mean() < 1 <= raw1.mean()                   # one file of each kind: kept as is / flipped
+    assert np.array_equal(read_vcf(str(tmp_path / "u.vcf")), raw)
+    (tmp_path / "bad.vcf").write_text(hdr + "1\t1\t.\tA\tG,T\t.\t.\t.\tGT\t2/2\t0/0\t0/0\t0/0\t0/0\n")
+    with pytest.raises(AssertionError):
+        read_vcf(str(tmp_path / "bad.vcf"))

@@ -1023,3 +1023,32 @@ def test_full_size_properties_of_the_step():
     e.adam(2e-3)
     torch.cuda.synchronize()
     assert float(e.P(0).min()) >= 0.0 and float(e.P(0).max()) <= 1.0
+
+
+def test_cli_train_from_vcf_equals_the_boundary_call(tmp_path):
+    """`train --data_path x.vcf.gz`: the supervised fixture's matrix written as a VCF (GT 0/0, 0/1, 1|1, ./.), read by
+    io.read_vcf_packed (nadm_vcf_parse_gt); the run must equal train() on the matrix itself."""
+    import gzip
+    import neural_admixture_amd as na
+    from neural_admixture_amd import cli
+    from neural_admixture_amd.io import read_vcf_packed
+    from neural_admixture_amd.svd import RSVD
+    dev = _dev()
+    d = np.load(f"{G}/supervised_k4.npz")
+    N, M, K = int(d["N"]), int(d["M"]), int(d["K"])
+    Gm = O.unpack2bit(d["G_packed"], M)
+    assert Gm.mean() < 1.0                                                   # no allele flip in the reader
+    gt = np.array(["0/0", "0/1", "1|1", "./."])
+    with gzip.open(tmp_path / "x.vcf.gz", "wt") as f:
+        f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(f"s{i}" for i in range(N)) + "\n")
+        for j in range(M):
+            f.write(f"1\t{j + 1}\t.\tA\tG\t.\t.\t.\tGT\t" + "\t".join(gt[Gm[:, j]]) + "\n")
+    data = read_vcf_packed(str(tmp_path / "x.vcf.gz"))
+    assert np.array_equal(data.unpack_rows(0, N), Gm)
+    out = tmp_path / "out"
+    assert cli.main(["train", "--epochs", "3", "--k", str(K), "--name", "v", "--data_path", str(tmp_path / "x.vcf.gz"), "--save_dir", str(out),
+                     "--seed", "13", "--batch_size", "100", "--hidden_size", "128"]) == 0
+    Q = np.loadtxt(out / f"v.{K}.Q", dtype=np.float32)
+    V = RSVD(data, N, M, 8, 13)
+    Ps, Qs, _ = na.train(3, 100, 2e-3, K, 13, data, dev, 1, 128, True, V, None, None, None, 8)
+    assert np.array_equal(Q, Qs[0])
