@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: genotypes/s (samples x SNPs per second of training) at K=8.
 
-A "step" is one training step of the hot path on one batch: gather 800 rows of the 2-bit packed
+A "step" is one training step of the hot path on one batch: gather the batch's rows of the 2-bit packed
 matrix, encoder X.V, RMSNorm+MLP+softmax, decoder Q.P^T + clamp + BCE forward/backward (loss value
 included), MLP backward, dV = X^T.dZ, gradient all-reduce (N>1), Adam on every parameter, P clamp.
 Workload (BASELINE.json configs[3]): synthetic 100k samples x 500k SNPs, K=8, resident 2-bit packed
-in HBM (12.5 GB; sharded by samples over ranks), batch 800 PER GPU (weak scaling: the reference's
-global-batch-800 semantics would leave 100 rows per GPU at N=8).
+in HBM (12.5 GB; sharded by samples over ranks).
+
+Two multi-GPU modes, both sample-sharded with an RCCL all-reduce of the gradients every step:
+  default            batch 800 PER GPU ("weak": the work per GPU is fixed, --batch_size 800*N in reference terms)
+  --global-batch B   the reference's own semantics (neural_admixture.py:287: batch_size // num_gpus rows per GPU, i.e.
+                     100 rows/GPU at N=8 for the default B=800; "strong": the work per step is fixed)
 
     python bench.py --gpus 1 --steps 100 --warmup 30
+    python bench.py --gpus 8                       # spawns 8 ranks itself (re-exec under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --min-k 2 --max-k 10 --rows 2504 --snps 600000      # configs[2]: nine heads over one pass of X
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import sys
 import time
 
@@ -25,17 +33,27 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak (same guide); the three GEMM-shaped products run as bf16 pieces
+N_SIMD = 256 * 4          # 256 CUs x 4 SIMDs
+VALU_CYCLES_PER_INST = 4  # one wave64 VALU instruction occupies its SIMD for 4 cycles (tools/ubench_valu.hip; packed f32 alike)
+PROFILE_ROUND = "r02"     # profiles/<round>_pmc_*.json hold the counter passes of the kernels of THIS build (tools/pmc_profile.py)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=30)   # the first ~25 launches after start-up run ~7 % slow (clock ramp)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--ramp-ms", type=float, default=400.0,
+                    help="untimed clock-ramp phase BEFORE the --warmup steps: the same steps for this many milliseconds.  After "
+                         "start-up the part needs ~25 launches (~15 ms) to reach its sustained clock, and the first steps run ~15 %% slow")
     ap.add_argument("--rows", type=int, default=100_000, help="total samples N (sharded over ranks)")
     ap.add_argument("--snps", type=int, default=500_000)
     ap.add_argument("--k", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=800, help="rows per step PER GPU")
+    ap.add_argument("--min-k", type=int, default=None, help="with --max-k: one decoder head per K in [min_k, max_k] (configs[2])")
+    ap.add_argument("--max-k", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=800, help="rows per step PER GPU (weak scaling, the default mode)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="reference semantics: rows per step over ALL GPUs, batch_size // num_gpus per GPU (neural_admixture.py:287)")
     ap.add_argument("--hidden", type=int, default=1024)
     ap.add_argument("--no-loss", action="store_true", help="skip the loss value (gradients unchanged); default computes it every step like the reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -45,7 +63,7 @@ def parse():
     ap.add_argument("--force-ddp", action="store_true", help="single GPU: run the data-parallel step (sub-range launches + RCCL all-reduce on a 1-rank group)")
     ap.add_argument("--time-kernels", choices=("dominant", "all"), default="dominant",
                     help="HIP events inside the timed region around the dominant kernel only (default: two event records per step) "
-                         "or around every kernel of the step (kernel_ms table; the records cost ~10 %% of the step)")
+                         "or around every kernel of the step (kernel_ms table; the records cost ~4 %% of the step)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="functional check of the N>1 flow on a ONE-GPU box: all ranks use cuda:0 and gloo carries the tensors "
                          "(RCCL refuses two ranks per device); not a measurement")
@@ -53,10 +71,51 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one process per GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(cmd[0], cmd, env)
+
+
+def source_hash():
+    """Identity of the kernels a profile was taken from: sha256 over the HIP sources of libnadm.so."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "neural-admixture_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def load_profile(name, workload_key):
+    """profiles/<round>_<name>.json if it was taken from THESE kernel sources on THIS workload; else None, loudly."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_{name}.json")
+    try:
+        with open(path) as f:
+            pm = json.load(f)
+    except (OSError, ValueError):
+        print(f"[bench] no {path}: run tools/pmc_profile.py on the GPU box and commit the summary", file=sys.stderr)
+        return None
+    if pm.get("src_hash") != source_hash():
+        print(f"[bench] {path} was taken from other kernel sources ({pm.get('src_hash')} != {source_hash()}): counters not reported; "
+              "re-run tools/pmc_profile.py", file=sys.stderr)
+        return None
+    if pm.get("workload_key") != workload_key:
+        return None                                                     # another shape than the profiled one: nothing to say
+    return pm
+
+
 def make_dataset(eng, rows_local, row0, K, dev, seed=1234):
     """Admixture-model synthetic genotypes generated on the device straight into packed bytes."""
     from neural_admixture_amd._lib import lib, check, ptr
-    g = torch.Generator(device="cpu").manual_seed(seed)
     beta = torch.distributions.Beta(torch.tensor(0.5), torch.tensor(0.5))
     torch.manual_seed(seed)
     Fq = (0.5 * beta.sample((K, eng.M))).clamp(0.005, 0.5).float().to(dev)           # same on every rank
@@ -69,7 +128,6 @@ def make_dataset(eng, rows_local, row0, K, dev, seed=1234):
         Qt = dirich.sample((n,)).float().to(dev)
         check(lib.nadm_synth_packed(ptr(xp[s:]), n, row0 + s, eng.M, eng.ld, ptr(Qt), ptr(Fq), K, 0.01, seed, None), "synth")
     torch.cuda.synchronize()
-    del g
     return xp
 
 
@@ -111,10 +169,14 @@ def cpu_baseline(eng, args, dev):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                                               # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or args.force_ddp or args.parallelism == "snp":
+    use_dist = world > 1 or args.force_ddp or args.parallelism == "snp"
+    rccl_ranks = 0
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -132,9 +194,12 @@ def main():
                 dist.init_process_group("gloo", rank=rank, world_size=world)
             else:
                 dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), rank=rank, world_size=world)
-            t_ = torch.zeros(1, device=f"cuda:{local_rank}")
-            dist.all_reduce(t_)
+            t_ = torch.ones(1, device=f"cuda:{local_rank}")
+            dist.all_reduce(t_)                                         # every rank contributes 1: the sum counts the ranks RCCL connected
             torch.cuda.synchronize()
+            rccl_ranks = 0 if args.share_gpu else int(round(float(t_.item())))
+            if int(round(float(t_.item()))) != world:
+                raise RuntimeError(f"all-reduce over {world} ranks summed to {float(t_.item())}")
         finally:
             ctypes.CDLL(None).fflush(None)
             os.dup2(saved_fd, 1)
@@ -144,41 +209,65 @@ def main():
     import neural_admixture_amd as na
     from neural_admixture_amd.model import init_encoder_weights
 
-    M, K, b = args.snps, args.k, args.batch
+    M = args.snps
+    ks = [args.k] if args.min_k is None else list(range(args.min_k, args.max_k + 1))
+    S, K = sum(ks), max(ks)
+    if args.global_batch is not None:
+        b = args.global_batch // world                                  # neural_admixture.py:287
+        if b < 1:
+            raise SystemExit("--global-batch smaller than the number of GPUs")
+    else:
+        b = args.batch
     snp = args.parallelism == "snp"
     rng = np.random.default_rng(42)                                     # identical parameters on every rank
     V0 = (0.01 * rng.standard_normal((M, 8))).astype(np.float32)
-    P0 = rng.uniform(5e-6, 1 - 5e-6, size=(K, M)).astype(np.float32)
+    P0 = rng.uniform(5e-6, 1 - 5e-6, size=(S, M)).astype(np.float32)
     if snp:
         # every rank: ALL rows of its SNP slice (same bytes in HBM per rank as the sample-sharded layout), global batch b*world
         from neural_admixture_amd.snp_parallel import SnpShardedEngine
         rows_local, gb = args.rows, b * world
-        eng = SnpShardedEngine(M, 8, args.hidden, [K], dev, gb, rank, world)
+        eng = SnpShardedEngine(M, 8, args.hidden, ks, dev, gb, rank, world)
         eng.set_packed(make_dataset(eng, rows_local, 0, K, dev, seed=1234 + 7 * rank))
         gperm = torch.Generator(device="cpu").manual_seed(1000)         # the same global batches on every rank
     else:
         rows_local, gb = args.rows // world, b
-        eng = na.Engine(M, 8, args.hidden, [K], dev, b)
+        eng = na.Engine(M, 8, args.hidden, ks, dev, b)
         eng.set_packed(make_dataset(eng, rows_local, rank * rows_local, K, dev))
         gperm = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    eng.load_params(V0, P0, init_encoder_weights(42, 8, args.hidden, [K]))
+    eng.load_params(V0, P0, init_encoder_weights(42, 8, args.hidden, ks))
     del V0, P0
     perm = torch.randperm(rows_local, generator=gperm).to(torch.int32).to(dev)
-    nb = rows_local // gb
+    nb = max(1, rows_local // gb)
     with_loss = not args.no_loss
     lr = 2e-3
+    ddp = not snp and (world > 1 or args.force_ddp)
 
     def step(s):
         o = (s % nb) * gb
         if snp:
             eng.train_step(perm[o:o + gb], gb, lr, with_loss)
-        elif world > 1 or args.force_ddp:
+        elif ddp:
             eng.train_step_ddp(perm[o:o + b], b, lr, world, with_loss, defer_tail=True)
         else:
             eng.train_step(perm[o:o + b], b, lr, with_loss)
 
+    # untimed clock-ramp phase: the same steps until --ramp-ms of wall-clock have passed (the sustained clock is reached
+    # after ~25 launches; `--warmup 5 --steps 20` straight after start-up would time the ramp, not the step)
+    n_ramp = 0
+    torch.cuda.synchronize()
+    t_r = time.perf_counter()
+    while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:
+        for _ in range(10):
+            step(n_ramp)
+            n_ramp += 1
+        torch.cuda.synchronize()
+        if world > 1:                                                   # every rank leaves the phase after the same number of steps
+            t = torch.tensor([1.0 if (time.perf_counter() - t_r) * 1e3 < args.ramp_ms else 0.0], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if float(t.item()) == 0.0:
+                break
     for s in range(args.warmup):
-        step(s)
+        step(n_ramp + s)
     eng.timers = {}
     eng.timed_names = None if args.time_kernels == "all" else {"decode_bce"}
     if world > 1:
@@ -186,13 +275,14 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        step(args.warmup + s)
-    if not snp and (world > 1 or args.force_ddp):
+        step(n_ramp + args.warmup + s)
+    if ddp:
         eng.finish_ddp()                                   # the last step's deferred P piece belongs to the timed work
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dt_rank = dt
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -207,67 +297,89 @@ def main():
         # every kernel (those records cost ~4 % of the step, which is why the timed region carries only the dominant kernel's)
         eng.timers, eng.timed_names = {}, None
         for s in range(min(args.steps, 20)):
-            step(args.warmup + args.steps + s)
-        if not snp and (world > 1 or args.force_ddp):
+            step(n_ramp + args.warmup + args.steps + s)
+        if ddp:
             eng.finish_ddp()
         torch.cuda.synchronize()
         extra, eng.timers = eng.timers, None
         for name, evs in extra.items():
             if name != "decode_bce":
                 kms[name] = float(np.mean([a.elapsed_time(c) for a, c in evs]))
-    # dominant kernel = decode_bce.  Algorithmic bytes per launch: one 2-bit pass over the
-    # batch (b*M/4) + read P and write dP once (2 * 4*M*K).
+    # ---- roofline of the dominant kernel = pass 2 (decode_bce: all heads of the step) ----
+    # Algorithmic bytes in the accounting of SURVEY.md 8d (whole step = 0.75 B/genotype of packed X + 36 B per parameter of
+    # parameter/optimizer traffic): one 2-bit pass over the batch + the pass's share of the per-parameter traffic.
+    #   alg_8d : SURVEY 8d's full 36 B per P parameter when Adam on P runs in the kernel's epilogue (single-GPU and SNP-sharded
+    #            steps) -- that rule prices the dP write + re-read and a second P read, which the fused epilogue does NOT perform;
+    #            8 B (read P, write dP) when Adam is a launch of its own behind the all-reduce (data-parallel step)
+    #   alg_min: the bytes the launch must really move: fused = read P, m, v + write P, m, v = 24 B per parameter; unfused = 8 B
     dom = "decode_bce"
-    # Algorithmic bytes of one pass-2 launch, in the accounting of SURVEY.md 8d (whole step = 0.75 B/genotype of packed X +
-    # 36 B per parameter of parameter/optimizer traffic): one 2-bit pass over the batch + the pass's share of the
-    # per-parameter traffic.  Single-GPU and SNP-sharded steps run Adam on the P rows in the kernel's epilogue, so the launch
-    # carries ALL 36 B of a P parameter (read p; write/read g; read/write p, m, v); in the data-parallel step Adam is a
-    # launch of its own behind the all-reduce and pass 2 keeps only read p + write g = 8 B.
-    fused = (snp or not (world > 1 or args.force_ddp)) and getattr(eng, "fused_adam", False)
+    fused = (snp or not ddp) and getattr(eng, "fused_adam", False)
     rows_b, m_loc = (gb, eng.M) if snp else (b, M)                       # snp: global batch x own SNP slice
-    alg_bytes = rows_b * m_loc / 4 + (36 if fused else 8) * m_loc * K
-    traffic = None                                                      # HBM bytes/launch from the committed PMC passes (same workload)
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
-            pm = json.load(f)
-        if abs(pm["algorithmic_bytes_per_launch"] - alg_bytes) < 1:
-            traffic = pm["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    achieved = alg_bytes / (kms[dom] * 1e-3) / 1e9
-    step_bytes = b * M * (0.75 + 36.0 * (8 + K) / b)                     # SURVEY.md 8d whole-step figure
-    cfg_name = {(100_000, 500_000, 8): "configs[3]", (500_000, 1_000_000, 16): "configs[4]"}.get((args.rows, M, K), "configs[3] shape, resized")
+    x_passes = 1 if getattr(eng, "one_pass_heads", len(ks) == 1) else len(ks)   # heads served by ONE walk over X, or one walk each
+    alg_8d = x_passes * rows_b * m_loc / 4 + (36 if fused else 8) * m_loc * S
+    alg_min = rows_b * m_loc / 4 + (24 if fused else 8) * m_loc * S
+    t_dom = kms[dom] * 1e-3
+    wk = f"{rows_b}x{m_loc}x{'-'.join(map(str, ks))}:{'fused' if fused else 'unfused'}:{'loss' if with_loss else 'noloss'}"
+    hbm = load_profile("pmc_hbm", wk) if rank == 0 else None
+    sq = load_profile("pmc_sq", wk) if rank == 0 else None
+    genotypes_launch = rows_b * m_loc * len(ks)                          # per-genotype BCE algebra runs once per head
+    issue = None
+    if sq is not None:
+        # SQ_INSTS_VALU / SQ_INSTS_MFMA are summed over the shader engines by rocprofv3's per-dispatch record
+        valu, mfma = sq["valu_insts_per_launch"], sq["mfma_insts_per_launch"]
+        clk = sq.get("sclk_ghz", 2.4)
+        issue_peak = N_SIMD * clk * 1e9 / VALU_CYCLES_PER_INST           # wave-instructions per second, whole chip
+        issue = {"valu_insts_per_genotype": valu * 64.0 / genotypes_launch, "mfma_insts_per_64_genotypes": mfma * 64.0 / genotypes_launch,
+                 "valu_wave_insts_per_launch": valu, "issue_peak_wave_insts_per_s": issue_peak, "sclk_ghz": clk,
+                 "achieved_frac_of_valu_issue_peak": valu / t_dom / issue_peak,
+                 "note": "VALU wave-instructions of one launch / its duration vs 1024 SIMDs x clk / 4 cycles; MFMA issue comes on top (not hidden, DESIGN.md section 4)"}
+    achieved = alg_8d / t_dom / 1e9
+    step_bytes = 0.75 * b * M + 36.0 * (8 + S) * M                        # SURVEY.md 8d whole-step figure: 0.75 + 36 (C+S)/b per genotype
+    per_step_units = (gb if snp else b * world) * M
+    cfg_name = {(100_000, 500_000, (8,)): "configs[3]", (500_000, 1_000_000, (16,)): "configs[4]", (2504, 600_000, (7,)): "configs[1]",
+                (2504, 600_000, tuple(range(2, 11))): "configs[2]"}.get((args.rows, M, tuple(ks)), "configs[3] shape, resized")
+    mode = "snp" if snp else ("dp-global-batch" if args.global_batch is not None else "dp")
     out = {
-        "metric": "genotypes/sec (samples x SNPs / epoch-sec) at K=%d" % K,
-        "value": world * b * M * args.steps / dt, "unit": "genotypes/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{cfg_name}: synthetic {args.rows} samples x {M} SNPs, K={K}, 2-bit packed resident in HBM, "
+        "metric": "genotypes/sec (samples x SNPs / epoch-sec) at K=%s" % (K if len(ks) == 1 else f"{ks[0]}..{ks[-1]}"),
+        "value": per_step_units * args.steps / dt, "unit": "genotypes/s",
+        "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong" if args.global_batch is not None else "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{cfg_name}: synthetic {args.rows} samples x {M} SNPs, K={'/'.join(map(str, ks))}, 2-bit packed resident in HBM, "
                                f"{'SNP' if snp else 'sample'}-sharded over {world} GPU(s), batch {b}/GPU, hidden {args.hidden}, n_components 8, "
                                f"loss value {'every step' if with_loss else 'skipped'}",
-                   "global_batch": b * world, "parallelism": f"{args.parallelism}{world}"},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel_ms": kms, "alg_bytes_per_launch": alg_bytes,
-                     "alg_bytes_note": "2-bit pass over the batch + %d B per P parameter (%s)" % (
-                         36 if fused else 8, "Adam on P fused into the launch" if fused else "read P, write dP; Adam is a separate launch"),
+                   "global_batch": gb if snp else b * world, "parallelism": f"{args.parallelism}{world}", "mode": mode,
+                   "clock_ramp_steps_untimed": n_ramp},
+        "roofline": {"bound": "hbm", "limiter": "valu_issue", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "frac_8d": achieved / HBM_PEAK_GBS, "frac_min": alg_min / t_dom / 1e9 / HBM_PEAK_GBS,
+                     "traffic": hbm["traffic_bytes_per_launch"] if hbm else None,
+                     "traffic_source": (f"profiles/{PROFILE_ROUND}_pmc_hbm.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, src_hash {hbm['src_hash']})"
+                                        if hbm else None),
+                     "kernel_ms": kms, "alg_bytes_per_launch": alg_8d, "alg_bytes_min_per_launch": alg_min,
+                     "alg_bytes_note": "frac/frac_8d: 2-bit pass over the batch + %d B per P parameter (SURVEY 8d rule; %s); frac_min: the same pass "
+                                       "+ %d B per P parameter, the bytes the launch has to move" % (
+                                           36 if fused else 8, "Adam on P fused into the launch, no dP round trip" if fused else "read P, write dP; Adam is a separate launch",
+                                           24 if fused else 8),
+                     "issue": issue, "workload_key": wk,
                      "whole_step": {"alg_bytes": step_bytes, "achieved": step_bytes / (dt / args.steps) / 1e9,
                                     "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
-                     # algorithmic flops per genotype = 4C + 6K (X.V, Q.P^T, dP, dQ, dV); the pass-2 kernel
-                     # is bound by vector-ALU issue (BCE algebra per genotype), not by either roof -- DESIGN.md section 4
-                     "mfma": {"alg_flops_per_genotype": 4 * 8 + 6 * K,
-                              "achieved_tflops": world * b * M * args.steps / dt * (4 * 8 + 6 * K) / 1e12 / world,
+                     # algorithmic flops per genotype = 4C + 6S (X.V, Q.P^T, dP, dQ, dV)
+                     "mfma": {"alg_flops_per_genotype": 4 * 8 + 6 * S,
+                              "achieved_tflops": b * M * args.steps / dt * (4 * 8 + 6 * S) / 1e12,
                               "peak_tflops": MFMA_BF16_PEAK_TFLOPS,
-                              "frac": b * M * args.steps / dt * (4 * 8 + 6 * K) / 1e12 / MFMA_BF16_PEAK_TFLOPS}},
+                              "frac": b * M * args.steps / dt * (4 * 8 + 6 * S) / 1e12 / MFMA_BF16_PEAK_TFLOPS}},
         "loss_last_step": loss_last,
     }
+    if world > 1:
+        out["ms_per_step_this_rank"] = dt_rank / args.steps * 1e3          # rank 0's own clock; ms_per_step is the max over ranks
     if args.share_gpu:
         out["config"]["share_gpu"] = "all ranks on cuda:0 over gloo: functional check, not a measurement"
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and len(ks) == 1:
             out["cpu_baseline"] = cpu_baseline(eng, args, dev)
         print(json.dumps(out))
-    if world > 1 or args.force_ddp or args.parallelism == "snp":
+        sys.stdout.flush()
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,6 +1,7 @@
 """Drop-in for ``neural_admixture.model.train.train`` (train.py:19-149): same positional signature,
-same returns ``(Ps, Qs, model)``.  PCA-space GMM decoder init stays Python/sklearn (as the
-north star asks); packing, the step loop and the final-Q pass run on the MI355X engine."""
+same returns ``(Ps, Qs, model)``.  The PCA-space GMM decoder init is the reference's scikit-learn call for
+1000-Genomes-sized inputs and its float64 restatement in device ops (_gmm_em.py, same means to 1e-13) for N > 20000;
+packing, the step loop and the final-Q pass run on the MI355X engine."""
 from __future__ import annotations
 
 import logging
@@ -84,6 +85,7 @@ def _gmm_means_parallel(X_pca: np.ndarray, ks, seed: int):
     import subprocess
     import tempfile
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gmm_fit.py")
+    procs = []
     try:
         with tempfile.TemporaryDirectory() as td:
             xp = os.path.join(td, "x.npy")
@@ -91,11 +93,19 @@ def _gmm_means_parallel(X_pca: np.ndarray, ks, seed: int):
             env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
             procs = [subprocess.Popen([sys.executable, script, xp, str(k), str(seed), os.path.join(td, f"m{k}.npy")], env=env,
                                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for k in ks]
-            if any(p.wait(timeout=600) != 0 for p in procs):
+            codes = [p.wait(timeout=600) for p in procs]
+            if any(codes):
+                log.info(f"    concurrent GMM fits failed (exit codes {codes}); fitting in-process instead")
                 return None
             return [np.load(os.path.join(td, f"m{k}.npy")) for k in ks]
-    except Exception:
+    except (OSError, subprocess.SubprocessError, ValueError) as e:
+        log.info(f"    concurrent GMM fits failed ({type(e).__name__}: {e}); fitting in-process instead")
         return None
+    finally:
+        for p in procs:                         # no orphans: a timed-out / failed batch must not keep running beside the fallback
+            if p.poll() is None:
+                p.kill()
+                p.wait()
 
 
 def supervised_init(data_np, pops, K: int):
