@@ -1,7 +1,9 @@
 """Thin command line with the reference's flags (entry.py:20-67): ``python -m neural_admixture_amd train|infer ...``.
 Reads BED input straight into the packed layout, runs the RSVD + GMM initialisation, trains on the MI355X engine and
 writes ``{name}.{K}.Q/.P``, ``{name}.pt`` and ``{name}_config.json`` exactly where the reference does
-(src/main.py:38-44, src/inference.py:91-92).  VCF/PGEN readers are not part of this build."""
+(src/main.py:38-44, src/inference.py:91-92).  BED and VCF inputs are read natively (io.read_bed_packed, io.read_vcf_packed);
+PGEN needs pgenlib through the reference's own reader.  ``--num_gpus N`` spawns one process per GPU like the reference
+(entry.py:186-190); ``--threads`` is accepted for command-line compatibility and caps the host thread pools."""
 from __future__ import annotations
 
 import argparse
@@ -38,6 +40,9 @@ def parse_train_args(argv):
     p.add_argument("--threads", type=int, default=1)
     p.add_argument("--parallelism", choices=("dp", "snp"), default="dp",
                    help="multi-GPU sharding: dp = samples (the reference's DDP), snp = SNPs (two tiny all-reduces per step)")
+    p.add_argument("--share_gpu", action="store_true",
+                   help="functional check of a --num_gpus N run on a ONE-GPU box: every rank uses cuda:0 and gloo carries the "
+                        "tensors (RCCL refuses two ranks per device)")
     return p.parse_args(argv)
 
 
@@ -77,10 +82,13 @@ def _train_worker(rank, args, num_gpus, data, V, pops, t0):
     if num_gpus > 1:                                        # src/utils.py:69-95
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(rank)
-        torch.distributed.init_process_group("nccl", init_method="env://", rank=rank, world_size=num_gpus)
+        dev_id = 0 if args.share_gpu else rank
+        torch.cuda.set_device(dev_id)
+        torch.distributed.init_process_group("gloo" if args.share_gpu else "nccl", init_method="env://", rank=rank, world_size=num_gpus)
+    else:
+        dev_id = rank
     master = rank == 0
-    device = torch.device(f"cuda:{rank}")
+    device = torch.device(f"cuda:{dev_id}")
     K = args.k
     Ps, Qs, model = train(args.epochs, args.batch_size, args.learning_rate, K, args.seed, data, device, num_gpus, args.hidden_size,
                           master, V, pops, args.min_k, args.max_k, args.n_components, parallelism=args.parallelism)
@@ -116,7 +124,9 @@ def main(argv=None):
             log.info(f"    Running from K={args.min_k} to K={args.max_k}.")
         else:
             raise ValueError("Please provide either --k or both --min_k and --max_k.")
-        num_gpus = max(1, min(args.num_gpus, torch.cuda.device_count()))
+        num_gpus = max(1, args.num_gpus if args.share_gpu else min(args.num_gpus, torch.cuda.device_count()))   # entry.py:168-173
+        for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS", "NUMEXPR_NUM_THREADS"):       # entry.py:138-146
+            os.environ[var] = str(args.threads)
         from .svd import RSVD
         data = _read(args.data_path, torch.device("cuda:0"), keep_on_device=(num_gpus == 1))   # 2-bit transpose on the GPU
         log.info("")

@@ -140,7 +140,8 @@ def train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int,
     ``parallelism`` (keyword, not in the reference): "dp" = samples sharded over the GPUs with a gradient all-reduce, as the
     reference does; "snp" = SNPs sharded (snp_parallel.py): same trajectory up to summation order, two tiny all-reduces
     per step instead of the 4*M*(C+S)-byte one."""
-    if device.type != "cuda":
+    eng_cls = NeuralAdmixture.engine_snp_cls if parallelism == "snp" else NeuralAdmixture.engine_cls
+    if device.type != "cuda" and not eng_cls._CPU_TEST_DOUBLE:      # tests/ run this function over gloo with an oracle-backed double
         raise RuntimeError("neural_admixture_amd.train requires a ROCm GPU device; the CPU path is the reference's own")
     N, M = data.shape
     if n_components is None:

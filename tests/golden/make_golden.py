@@ -342,16 +342,23 @@ def case_supervised():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    case_pack()
-    case_bce_elementwise()
-    one_step_case("one_step_k3", 64, 509, [3], 64, 8, seed=3)
-    one_step_case("one_step_multihead", 64, 509, [2, 3, 4], 64, 8, seed=4)
-    one_step_case("one_step_k8_h1024", 48, 777, [8], 1024, 8, seed=5)
-    one_step_case("one_step_edge", 64, 509, [3], 64, 8, seed=6, edge=True)
-    case_multibatch()
-    case_multihead_run()
-    case_ddp(2)
-    case_demo()
-    case_supervised()
-    one_step_case("one_step_supervised", 64, 509, [5], 64, 8, seed=8, sup=True)
+    cases = {
+        "pack": case_pack,
+        "bce": case_bce_elementwise,
+        "one_step_k3": lambda: one_step_case("one_step_k3", 64, 509, [3], 64, 8, seed=3),
+        "one_step_multihead": lambda: one_step_case("one_step_multihead", 64, 509, [2, 3, 4], 64, 8, seed=4),
+        "one_step_k8_h1024": lambda: one_step_case("one_step_k8_h1024", 48, 777, [8], 1024, 8, seed=5),
+        "one_step_edge": lambda: one_step_case("one_step_edge", 64, 509, [3], 64, 8, seed=6, edge=True),
+        "multibatch": case_multibatch,
+        "multihead_run": case_multihead_run,
+        "ddp": lambda: case_ddp(2),
+        "demo": case_demo,
+        "supervised": case_supervised,
+        "one_step_supervised": lambda: one_step_case("one_step_supervised", 64, 509, [5], 64, 8, seed=8, sup=True),
+        # BASELINE configs[1] / configs[2] model shapes (single head K=7; heads K=2..10) at fixture size
+        "one_step_k7_h1024": lambda: one_step_case("one_step_k7_h1024", 56, 1021, [7], 1024, 8, seed=9),
+        "one_step_heads2to10": lambda: one_step_case("one_step_heads2to10", 40, 613, list(range(2, 11)), 256, 8, seed=10),
+    }
+    for name in (sys.argv[1:] or list(cases)):            # no arguments: every fixture; else only the named cases
+        cases[name]()
     print("done ->", OUT)

@@ -465,3 +465,17 @@ def test_python_dash_m_reaches_the_cli():
         assert r.returncode != 0 and "none" in (r.stdout + r.stderr)          # reaches the reader, no such file
     else:
         assert r.returncode != 0 and "needs a ROCm GPU" in (r.stdout + r.stderr)
+
+
+def test_hudsons_fst_of_the_product_matches_the_reference_table():
+    """model.hudsons_fst (neural_admixture.py:532-553) on the reference's own final P of the demo run against the Fst values
+    the reference computed from it (tests/golden/demo_k3.npz: hi_e5_fst), and the printed table of display_divergences."""
+    from neural_admixture_amd.model import hudsons_fst
+    d = np.load(f"{G}/demo_k3.npz")
+    P = torch.from_numpy(d["hi_e5_P"])
+    fst = d["hi_e5_fst"]
+    for a in range(3):
+        for b in range(a):                      # the fixture holds the lower triangle, like the printed table
+            assert abs(hudsons_fst(P[:, b], P[:, a]) - float(fst[a, b])) < 1e-6
+            assert abs(hudsons_fst(P[:, a], P[:, b]) - float(fst[a, b])) < 1e-6     # symmetric in its arguments
+    assert hudsons_fst(P[:, 0], P[:, 0]) == 0.0

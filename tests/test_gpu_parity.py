@@ -101,7 +101,7 @@ def test_pack_unpack_bit_exact():
 
 
 @pytest.mark.parametrize("name", ["one_step_k3", "one_step_multihead", "one_step_k8_h1024", "one_step_edge",
-                                  "one_step_supervised"])
+                                  "one_step_supervised", "one_step_k7_h1024", "one_step_heads2to10"])
 def test_one_step_against_reference_fixture(name):
     """Loss, every gradient and 3 Adam steps against tensors captured from the reference's autograd."""
     d = np.load(f"{G}/{name}.npz")
@@ -432,14 +432,17 @@ def test_trajectory_demo_c1_vs_reference(ep):
         assert abs(ll - float(d["hi_e5_loglik"])) / abs(float(d["hi_e5_loglik"])) < 1e-4
 
 
-def test_full_width_against_torch_fp32_on_device():
-    """BASELINE-scale width (b=800, M=500k, K=8): the three passes against a plain torch fp32
-    computation on the same GPU from the unpacked matrix (independent code path), plus linearity."""
+@pytest.mark.parametrize("b,M,K", [(800, 500_000, 8),      # configs[3] / the bench workload
+                                   (800, 600_000, 7),      # configs[1]: 1000-Genomes scale, single head K=7
+                                   (104, 600_000, 7)])     # ... and its partial last batch (2504 = 3 * 800 + 104)
+def test_full_width_against_torch_fp32_on_device(b, M, K):
+    """BASELINE-scale width: the three passes against a plain torch fp32 / fp64 computation on the same GPU from the
+    unpacked matrix (independent code path), plus linearity."""
     dev = _dev()
     import neural_admixture_amd as na
     from neural_admixture_amd._lib import lib, check, ptr
     import ctypes as C
-    b, M, K, Cc, Hd = 800, 500_000, 8, 8, 1024
+    Cc, Hd = 8, 1024
     e = na.Engine(M, Cc, Hd, [K], dev, b)
     g = torch.Generator(device="cpu").manual_seed(0)
     Qt = torch.distributions.Dirichlet(torch.full((K,), 0.2)).sample((b,)).float().to(dev)
@@ -814,6 +817,84 @@ def test_world2_real_engine_on_one_gpu_matches_reference_ddp(tmp_path, paralleli
         assert np.allclose(r["losses"], d["losses_rank0"].reshape(int(d["epochs"]), -1).sum(1), rtol=1e-5)
 
 
+def _w2_train_worker(rank, world, port, out_path):
+    """Both ranks call the drop-in boundary train(...): master-only GMM init, barrier, dist.broadcast(P_init / V)
+    (model/train.py:86-113), sharded training on the HIP engine, master-only outputs."""
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import neural_admixture_amd as na_
+    from oracle import nadm_oracle as O_
+    d = np.load(os.path.join(GOLD, "ddp_w2.npz"))
+    Gm = O_.unpack2bit(d["G_packed"], int(d["M"]))
+    V_CM = np.ascontiguousarray(d["V0"].T)
+    if rank != 0:
+        V_CM = np.zeros_like(V_CM)                          # only the broadcast can give rank 1 the master's V
+    dev = torch.device("cuda:0")
+    Ps, Qs, model = na_.train(int(d["epochs"]), int(d["batch"]), float(d["lr"]), int(d["K"]), int(d["seed"]), torch.from_numpy(Gm), dev,
+                              world, int(d["Hd"]), rank == 0, V_CM, None, None, None, 8)
+    assert type(model.engine).__module__.startswith("neural_admixture_amd")
+    if rank == 0:
+        np.savez(out_path, Q=Qs[0], P=Ps[0], V=model.state_dict()["V"].cpu().numpy())
+    else:
+        assert Ps == [] and Qs == []
+    ref = model.engine.small.clone()
+    dist.broadcast(ref, src=0)
+    assert torch.equal(ref, model.engine.small)             # same parameters on both ranks at the end
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_train_boundary_runs_the_init_broadcasts_on_the_hip_engine(tmp_path):
+    import torch.multiprocessing as mp
+    from neural_admixture_amd.train import gmm_p_init
+    _dev()
+    port = 35500 + (os.getpid() % 2000)
+    out = str(tmp_path / "w2_train.npz")
+    mp.spawn(_w2_train_worker, args=(2, port, out), nprocs=2, join=True)
+    r = np.load(out)
+    d = np.load(os.path.join(GOLD, "ddp_w2.npz"))
+    Gm = O.unpack2bit(d["G_packed"], int(d["M"]))
+    P_init = gmm_p_init(Gm, np.ascontiguousarray(d["V0"].T), int(d["K"]), None, None, 8, int(d["seed"]), None)   # host projection + sklearn
+    p = O.make_params(int(d["seed"]), d["V0"].copy(), P_init.astype(np.float32), int(d["Hd"]), [int(d["K"])])
+    p, Qs, _ = O.train_run(Gm, p, int(d["epochs"]), int(d["batch"]), float(d["lr"]), int(d["seed"]), world=2)
+    assert np.abs(r["Q"] - Qs[0]).max() < 2e-4 and np.abs(r["P"] - p.P[0]).max() < 2e-4 and np.abs(r["V"] - p.V).max() < 2e-4
+
+
+def test_cli_train_num_gpus_2_through_its_spawn_worker(tmp_path):
+    """`train --num_gpus 2`: the parent reads the BED and runs the RSVD, then mp.spawn's one worker per rank (entry.py:186-190)
+    with the packed matrix in shared memory; the workers set up the process group, call train() and the master writes the
+    outputs.  On the one-GPU test box the ranks share cuda:0 over gloo (--share_gpu); the result must equal the world-2
+    boundary call made directly."""
+    from neural_admixture_amd import cli
+    _dev()
+    d = np.load(f"{G}/demo_k3.npz")
+    d["bed_bytes"].tofile(tmp_path / "demo.bed")
+    (tmp_path / "demo.fam").write_text("\n".join(["s"] * int(d["N"])) + "\n")
+    out = tmp_path / "out"
+    os.environ["MASTER_PORT"] = str(37500 + os.getpid() % 2000)
+    try:
+        assert cli.main(["train", "--epochs", "5", "--k", "3", "--name", "run2", "--data_path", str(tmp_path / "demo.bed"), "--save_dir", str(out),
+                         "--seed", "42", "--num_gpus", "2", "--share_gpu", "--batch_size", "64", "--threads", "1"]) == 0
+        Q2 = np.loadtxt(out / "run2.3.Q")
+        P2 = np.loadtxt(out / "run2.3.P")
+        assert Q2.shape == (int(d["N"]), 3) and P2.shape == (int(d["M"]), 3)
+        assert (out / "run2.pt").exists() and (out / "run2_config.json").exists()
+        assert np.abs(Q2.sum(axis=1) - 1).max() < 1e-5 and P2.min() >= 0 and P2.max() <= 1
+        # the same run on one rank with the same GLOBAL batch sees the same samples per step only if the shards line up; what
+        # must hold whatever the order: the two-rank run is a valid training run that ends close to the single-rank one
+        os.environ["MASTER_PORT"] = str(37600 + os.getpid() % 2000)
+        assert cli.main(["train", "--epochs", "5", "--k", "3", "--name", "run1", "--data_path", str(tmp_path / "demo.bed"), "--save_dir", str(out),
+                         "--seed", "42", "--num_gpus", "1", "--batch_size", "64", "--threads", "1"]) == 0
+        Q1 = np.loadtxt(out / "run1.3.Q")
+        assert np.abs(Q1 - Q2).mean() < 0.05
+    finally:
+        os.environ.pop("MASTER_PORT", None)
+
+
 def test_rows_at_offsets_beyond_4_gib_in_a_resident_matrix_of_configs4_size():
     """BASELINE configs[4]: 500k samples x 1M SNPs stay packed in HBM -- 125 GB, which ONE MI355X holds.  Rows of such a
     matrix start at byte offsets far beyond 2^32; a step that gathers rows scattered over the whole allocation (first
@@ -975,8 +1056,10 @@ def test_adam_in_the_epilogues_of_passes_2_and_3_equals_the_separate_launches(ks
     assert float(e1.P(0).min()) >= 0.0 and float(e1.P(0).max()) <= 1.0
 
 
-def test_full_size_properties_of_the_step():
-    """BASELINE configs[3] width (M = 500k, b = 800, K = 8), properties that do not need an oracle of that size:
+@pytest.mark.parametrize("M,K", [(500_000, 8), (600_000, 7)])
+def test_full_size_properties_of_the_step(M, K):
+    """BASELINE configs[3] width (M = 500k, b = 800, K = 8) and configs[1] width (M = 600k, K = 7), properties that do not need
+    an oracle of that size:
     (1) equivariance: permuting the batch permutes Z / Q rows bit for bit (a row's sums do not depend on its tile position)
         and leaves the loss and dP / dV unchanged up to the summation order over samples;
     (2) additivity: loss, dP and dV of the batch = the sums over its two halves (BCE(sum) is a sum over samples);
@@ -984,7 +1067,7 @@ def test_full_size_properties_of_the_step():
     import neural_admixture_amd as na
     from neural_admixture_amd._lib import lib, check, ptr
     dev = _dev()
-    b, M, K = 800, 500_000, 8
+    b = 800
     e = na.Engine(M, 8, 1024, [K], dev, b)
     e.fused_adam = False                                  # gradients are inspected: keep them in gbig
     g = torch.Generator(device="cpu").manual_seed(3)

@@ -44,7 +44,7 @@ def test_bce_elementwise_semantics():
 
 
 @pytest.mark.parametrize("name", ["one_step_k3", "one_step_multihead", "one_step_k8_h1024", "one_step_edge",
-                                  "one_step_supervised"])
+                                  "one_step_supervised", "one_step_k7_h1024", "one_step_heads2to10"])
 def test_one_step(name):
     d = np.load(f"{G}/{name}.npz")
     ks = [int(k) for k in d["ks"]]
