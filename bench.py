@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true",
                     help="functional check of the N>1 flow on a ONE-GPU box: all ranks use cuda:0 and gloo carries the tensors "
                          "(RCCL refuses two ranks per device); not a measurement")
+    ap.add_argument("--head-streams", type=int, default=None, help="multi-head models: concurrent pass-2 launches (Engine.head_streams)")
     ap.add_argument("--cpu-rows", type=int, default=2400, help="rows of the same workload used for the bounded CPU baseline")
     return ap.parse_args()
 
@@ -234,6 +235,8 @@ def main():
         eng = na.Engine(M, 8, args.hidden, ks, dev, b)
         eng.set_packed(make_dataset(eng, rows_local, rank * rows_local, K, dev))
         gperm = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    if args.head_streams is not None:
+        eng.head_streams = args.head_streams
     eng.load_params(V0, P0, init_encoder_weights(42, 8, args.hidden, ks))
     del V0, P0
     perm = torch.randperm(rows_local, generator=gperm).to(torch.int32).to(dev)

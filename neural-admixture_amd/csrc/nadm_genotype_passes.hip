@@ -823,32 +823,45 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, uint32_t& H, uin
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
 
-// Two genotypes at a time with packed f32 math.  On gfx950 every VALU instruction costs ~4.5 cycles per wave
-// (tools/ubench_ops.hip), v_pk_{add,mul,fma}_f32 included, so packing halves the price of every add/mul/fma;
-// max, rcp, compare/select and the conversions have no packed form.
-// Returns dR (gradient w.r.t. the pre-clamp reconstruction) and accumulates the BCE loss terms.
-// x = genotype/2 with missing already mapped to 0 (fp4_pair below).
+// Two genotypes at a time with packed f32 math.  Issue cost on gfx950 with a saturated SIMD (tools/ubench_valu_asm.hip, cycles per
+// wave64 instruction): v_add / v_sub / v_mul / v_fma / v_and ~2.9; v_max / v_min / v_med3 / v_max3 / shifts / v_perm / conversions
+// ~4.4; v_pk_{add,mul,fma}_f32 ~4.8 (two results); v_rcp / v_log ~8.3; a 16x16x32 bf16 MFMA ~17 and NOT hidden behind other
+// waves' VALU work (tools/ubench_issue.hip).  max, rcp, log and the conversions have no packed form.
+// Returns dR (gradient w.r.t. the pre-clamp reconstruction) and accumulates the BCE loss terms; x = genotype/2 with missing
+// already mapped to 0 (fp4_pair below).
+//   gradient   den = (1 - d) * d from the UNCLAMPED d: inside [0, 1] that is r(1 - r) bit for bit (r == d there), outside it
+//              is negative.  t = den * (-inf) is +inf exactly where d is out of range, -inf where den > 0 and NaN where
+//              den == 0; max3(den, 1e-12, t) ignores the NaN (IEEE maxNum), keeps the 1e-12 floor in range and becomes +inf
+//              out of range, so the reciprocal -- and with it the gradient -- is exactly 0 there (the reference's clamp_
+//              backward masks on the PRE-clamp value, bounds inclusive).  The numerator can then use d itself: no clamp
+//              instruction on the gradient path at all.
+//   loss       x*max(log r, -100) + (1-x)*max(log(1-r), -100) needs its two clamps only for r == 0 / r == 1 (log = -inf;
+//              an fp32 r is never in (0, e^-100)).  log2(v * 2^20 + 2^(20 - 100/ln2)) - 20 equals log2 v for every
+//              normal v (the addend is below half an ulp of v * 2^20) and -100/ln2 for v == 0: one packed fma per pair
+//              replaces two max, and since the weights x and 1-x add up to 1 the "- 20" is a constant per genotype that
+//              the caller subtracts once per tile pair.  r for the logs: d is never negative (P >= 0, Q >= 0 and the dropped
+//              split terms are 2^-24 relative); 1 - r needs the clamp from above only, and 2*max(v, 0) = v + |v| is one add
+//              of the fast class (the factor 2 goes into the scale) instead of a v_max.
+constexpr float LOSS_LOG_SHIFT = 20.f;                    // log2 of the scale
 template <bool LOSS>
 __device__ __forceinline__ f32x2_t bce_elem2(const float d0, const float d1, const f32x2_t x, f32x2_t& lossacc) {
-    const f32x2_t r = {__builtin_amdgcn_fmed3f(d0, 0.f, 1.f), __builtin_amdgcn_fmed3f(d1, 0.f, 1.f)};
-    const f32x2_t omr = (f32x2_t){1.f, 1.f} - r;
-    const f32x2_t den = omr * r;
-    // The gradient is masked where the unclamped value lies outside [0, 1] (the reference's clamp_ backward, inclusive
-    // bounds).  The mask rides on the denominator: t = (d - r) * inf is NaN where d was in range (0 * inf) and +-inf where
-    // it was not; max(den, 1e-12, |t|) ignores the NaN (IEEE maxNum) and becomes inf otherwise, so 1/denominator -- and with
-    // it the gradient -- is exactly 0 there.  One packed subtract, one packed multiply and a three-input max instead of
-    // max + compare + select per genotype.
-    const f32x2_t t = ((f32x2_t){d0, d1} - r) * (f32x2_t){__builtin_inff(), __builtin_inff()};
-    const f32x2_t inv = {__builtin_amdgcn_rcpf(__builtin_fmaxf(__builtin_fmaxf(den.x, 1e-12f), __builtin_fabsf(t.x))),
-                         __builtin_amdgcn_rcpf(__builtin_fmaxf(__builtin_fmaxf(den.y, 1e-12f), __builtin_fabsf(t.y)))};
-    const f32x2_t g = (r - x) * inv;
+    const f32x2_t d = {d0, d1};
+    const f32x2_t omd = (f32x2_t){1.f, 1.f} - d;
+    const f32x2_t den = omd * d;
+    const f32x2_t t = den * (f32x2_t){-__builtin_inff(), -__builtin_inff()};
+    const f32x2_t inv = {__builtin_amdgcn_rcpf(__builtin_fmaxf(__builtin_fmaxf(den.x, 1e-12f), t.x)),
+                         __builtin_amdgcn_rcpf(__builtin_fmaxf(__builtin_fmaxf(den.y, 1e-12f), t.y))};
+    const f32x2_t g = (d - x) * inv;
     if constexpr (LOSS) {
-        // lossacc accumulates x*max(log2 r, c) + (1-x)*max(log2(1-r), c), c = -100/ln2 (the caller applies -ln2).
-        // Two logs and packed fmas, no compares/selects on the code: the select-based single-log form costs as many
-        // issue slots and its conditions keep ~60 more registers alive.
-        constexpr float kC = -100.f / 0.69314718055994530942f;
-        const f32x2_t l1 = {fmaxf(__builtin_amdgcn_logf(r.x), kC), fmaxf(__builtin_amdgcn_logf(r.y), kC)};
-        const f32x2_t l0 = {fmaxf(__builtin_amdgcn_logf(omr.x), kC), fmaxf(__builtin_amdgcn_logf(omr.y), kC)};
+        constexpr float kScale = 1048576.f;                                    // 2^20
+        constexpr float kFloor = 3.900782386632024e-38f;                       // 2^20 * e^-100 (a normal number): log2 = 20 - 100/ln2
+        f32x2_t omr2;                                                          // 2 * max(1 - d, 0), exact.  As asm: the compiler would
+        asm("v_add_f32_e64 %0, %1, |%1|" : "=v"(omr2.x) : "v"(omd.x));        // pair the two adds into a v_pk_add_f32, which has no
+        asm("v_add_f32_e64 %0, %1, |%1|" : "=v"(omr2.y) : "v"(omd.y));        // |abs| modifier, behind two extra v_and
+        const f32x2_t a1 = __builtin_elementwise_fma(d, (f32x2_t){kScale, kScale}, (f32x2_t){kFloor, kFloor});
+        const f32x2_t a0 = __builtin_elementwise_fma(omr2, (f32x2_t){0.5f * kScale, 0.5f * kScale}, (f32x2_t){kFloor, kFloor});
+        const f32x2_t l1 = {__builtin_amdgcn_logf(a1.x), __builtin_amdgcn_logf(a1.y)};
+        const f32x2_t l0 = {__builtin_amdgcn_logf(a0.x), __builtin_amdgcn_logf(a0.y)};
         lossacc = __builtin_elementwise_fma(x, l1, lossacc);
         lossacc = __builtin_elementwise_fma((f32x2_t){1.f, 1.f} - x, l0, lossacc);
         asm volatile("" : "+v"(lossacc));     // pin the accumulation here: otherwise LLVM sinks all the logs of a tile pair
@@ -1129,6 +1142,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                         }
                     }
                 }
+                if constexpr (LOSS)        // the "- 20" of the shifted logs: 2 * NTW * 4 genotypes per lane and tile pair, half of them per packed half
+                    lossacc -= (f32x2_t){LOSS_LOG_SHIFT * NTW * 4, LOSS_LOG_SHIFT * NTW * 4};
                 // K <= 8: dQ^T rows k (hi part) and k+8 (mid part) sit 32 lanes apart: fold, lanes a<2 store.
                 // W: rows 4a + r ARE k, every lane group with 4a < KP stores its four.
 #pragma unroll

@@ -79,6 +79,8 @@ class Engine:
         self.overlap = False
         self._side, self._ev = None, None
         self._n_cu: Optional[int] = None
+        self.head_streams = 2                                 # decode_all: concurrent pass-2 launches of a multi-head model
+        self._head_streams, self._head_events = None, None
         self._pending_ddp: list = []
 
     def _xg_buf(self) -> torch.Tensor:
@@ -234,8 +236,25 @@ class Engine:
         loss_offs = L.loss_offsets()
         fsz = 4
         ev = self._timed("decode_bce")
+        # Several heads, no per-piece hand-off to a collective: the heads' launches are independent (own P rows, own dQ slab, own
+        # loss slots; they share only Q and X), so they go round-robin onto a few HIP streams.  Each launch ends in a partly
+        # filled round of resident blocks (M = 600k: 2344 blocks on 768 slots = 3.05 rounds); with two or three kernels in
+        # flight the next head's blocks fill the slots the previous head's tail leaves empty.
+        fan = self.head_streams if (len(L.ks) > 1 and on_grad_ready is None and self.device.type == "cuda") else 1
+        if fan > 1:
+            main = torch.cuda.current_stream()
+            if self._head_streams is None or len(self._head_streams) < fan - 1:
+                self._head_streams = [torch.cuda.Stream(device=self.device) for _ in range(fan - 1)]
+                self._head_events = [torch.cuda.Event() for _ in range(fan)]
+            self._head_events[0].record(main)
+            for sd in self._head_streams[: fan - 1]:
+                sd.wait_event(self._head_events[0])
         for h in range(len(L.ks)):
             kp = L.kp[h]
+            if fan > 1 and h % fan:
+                st = C.c_void_p(self._head_streams[h % fan - 1].cuda_stream)
+            elif fan > 1:
+                st = C.c_void_p(main.cuda_stream)
             csnps = int(lib.nadm_decode_chunk_snps(kp))
             align = csnps * 1024 // math.gcd(csnps, 1024)
             for m0, m1 in (self._round_ranges(csnps, align, 3 if kp <= 8 else 2) if p_parts == "rounds" else self._snp_ranges(p_parts, align)):
@@ -255,6 +274,11 @@ class Engine:
                     check(lib.nadm_decode_bce(*args, st), "decode_bce")
                 if on_grad_ready is not None:
                     on_grad_ready(self._ns_pad + L.p_off[h] + m0 * kp, self._ns_pad + L.p_off[h] + m1 * kp)
+        if fan > 1:                                          # join: everything after pass 2 waits for every head
+            for j, sd in enumerate(self._head_streams[: fan - 1]):
+                self._head_events[j + 1].record(sd)
+                main.wait_event(self._head_events[j + 1])
+            st = _stream()
         if ev: ev[1].record()
         self._xg_key = (idx.data_ptr(), b) if self.gather_batch else None   # pass 3 of THIS step, same batch: may read the copy
         n_loss = L.n_loss

@@ -52,5 +52,6 @@ class ModelLayout:
 
     @staticmethod
     def row_stride(M: int) -> int:
-        """Packed row stride in bytes: ceil(M/4) rounded up to 16 (aligned 16 B loads)."""
+        """Packed row stride in bytes: ceil(M/4) rounded up to 16 (aligned 16 B loads; 64 / 128 / 256-byte row alignment was
+        measured and changes nothing: the genotype passes are issue-bound, not request-bound)."""
         return ((int(M) + 3) // 4 + 15) // 16 * 16

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Build a variant of libnadm.so into tools/abl/<name>.so:  tools/build_variant.sh <name> [-DFLAG=..]...
+# (A/B runs: NADM_LIB=tools/abl/<name>.so python bench.py ...; tools/abl_run.sh runs bench.py against every variant.)
+set -e
+name=$1; shift
+R=$(cd "$(dirname "$0")/.." && pwd)
+src=$R/neural-admixture_amd/csrc
+out=$R/tools/abl
+mkdir -p $out /tmp/abl_$name
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
+hipcc $FLAGS -c $src/nadm_genotype_passes.hip -o /tmp/abl_$name/a.o "$@" &
+hipcc $FLAGS -c $src/nadm_small_kernels.hip -o /tmp/abl_$name/b.o "$@" &
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so /tmp/abl_$name/a.o /tmp/abl_$name/b.o -lpthread
+echo "built $out/$name.so"
