@@ -129,7 +129,10 @@ int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const float* zpart,
 /* ---- a9-a11: decoder Q.P^T -> clamp -> BCE(sum) forward + backward, one head -------------
  * (neural_admixture.py:94-97, :288/:431, autograd of both).  P,dP [M,kp]; Q = Qbase + qoff
  * with row stride SP; dqpart = this head's slab [nadm_decode_chunks(M,kp), b, kp]; losspart
- * [chunks] (written only if with_loss != 0).  Missing genotypes are x = 0 in input and target. */
+ * [chunks] (written only if with_loss != 0).  Missing genotypes are x = 0 in input and target.
+ * with_loss is a bit set: 1 = compute the loss value; 2 = P may hold values outside [0, 1] (before the first restrict_P: the
+ * reference's supervised run starts from per-class means of the raw codes, train.py:82) -- the matrix-core kernels then
+ * clamp the reconstruction before the logarithm, which they otherwise skip because clamp(r) == r up to rounding. */
 int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                     const float* P, int32_t kp, const float* Q, int32_t SP,
                     float* dP, float* dqpart, float* losspart, int32_t with_loss, void* stream);

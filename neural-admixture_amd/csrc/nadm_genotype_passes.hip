@@ -841,9 +841,12 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast
 //              replaces two max, and since the weights x and 1-x add up to 1 the "- 20" is a constant per genotype that
 //              the caller subtracts once per tile pair.  r for the logs: d is never negative (P >= 0, Q >= 0 and the dropped
 //              split terms are 2^-24 relative); 1 - r needs the clamp from above only, and 2*max(v, 0) = v + |v| is one add
-//              of the fast class (the factor 2 goes into the scale) instead of a v_max.
+//              of the fast class (the factor 2 goes into the scale) instead of a v_max.  log r itself may use d as long as
+//              P lies in [0, 1] (d <= 1 + a rounding error, log2 of that is < 2e-7): true from the first restrict_P on.
+//              UNIT_P = false clamps d from above for the step(s) before that -- the reference's supervised run starts
+//              from per-class means of the raw codes, which reach 2 (train.py:82).
 constexpr float LOSS_LOG_SHIFT = 20.f;                    // log2 of the scale
-template <bool LOSS>
+template <bool LOSS, bool UNIT_P>
 __device__ __forceinline__ f32x2_t bce_elem2(const float d0, const float d1, const f32x2_t x, f32x2_t& lossacc) {
     const f32x2_t d = {d0, d1};
     const f32x2_t omd = (f32x2_t){1.f, 1.f} - d;
@@ -858,7 +861,9 @@ __device__ __forceinline__ f32x2_t bce_elem2(const float d0, const float d1, con
         f32x2_t omr2;                                                          // 2 * max(1 - d, 0), exact.  As asm: the compiler would
         asm("v_add_f32_e64 %0, %1, |%1|" : "=v"(omr2.x) : "v"(omd.x));        // pair the two adds into a v_pk_add_f32, which has no
         asm("v_add_f32_e64 %0, %1, |%1|" : "=v"(omr2.y) : "v"(omd.y));        // |abs| modifier, behind two extra v_and
-        const f32x2_t a1 = __builtin_elementwise_fma(d, (f32x2_t){kScale, kScale}, (f32x2_t){kFloor, kFloor});
+        f32x2_t dl = d;
+        if constexpr (!UNIT_P) dl = (f32x2_t){__builtin_fminf(d.x, 1.f), __builtin_fminf(d.y, 1.f)};
+        const f32x2_t a1 = __builtin_elementwise_fma(dl, (f32x2_t){kScale, kScale}, (f32x2_t){kFloor, kFloor});
         const f32x2_t a0 = __builtin_elementwise_fma(omr2, (f32x2_t){0.5f * kScale, 0.5f * kScale}, (f32x2_t){kFloor, kFloor});
         const f32x2_t l1 = {__builtin_amdgcn_logf(a1.x), __builtin_amdgcn_logf(a1.y)};
         const f32x2_t l0 = {__builtin_amdgcn_logf(a0.x), __builtin_amdgcn_logf(a0.y)};
@@ -885,7 +890,7 @@ constexpr int BF_WAVES = NADM_BF_WAVES;
 constexpr int BF_NTW = NADM_BF_NTW;     // 16-SNP tiles per wave
 constexpr int BF_TS = NADM_BF_TS;       // samples per LDS tile
 
-template <int KP, bool LOSS>
+template <int KP, bool LOSS, bool UNIT_P = true>
 __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(NADM_BF_WPE, NADM_BF_WPE))) void decode_bce_bf16_kernel(
     const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
     float* P, const float* __restrict__ Q, int SP,
@@ -1100,7 +1105,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                             }
 #pragma unroll
                             for (int h2 = 0; h2 < 2; ++h2) {
-                                const f32x2_t dR = bce_elem2<LOSS>(D[2 * h2], D[2 * h2 + 1], fp4_pair(h2 ? odd[s2] : even[s2], t), lossacc);
+                                const f32x2_t dR = bce_elem2<LOSS, UNIT_P>(D[2 * h2], D[2 * h2 + 1], fp4_pair(h2 ? odd[s2] : even[s2], t), lossacc);
                                 const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector(dR, bf16x2_t));
                                 hi[t2][h2] = hp;
                                 const f32x2_t rem = dR - (f32x2_t){__uint_as_float(hp << 16), __uint_as_float(hp & 0xFFFF0000u)};
@@ -1490,7 +1495,9 @@ static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx,
             static_assert(mf_chunk_snps(KP) == BF_WAVES * 16 * BF_NTW, "same chunking as the f32 MFMA kernel");
             const int64_t chunks = (M + mf_chunk_snps(KP) - 1) / mf_chunk_snps(KP);
             dim3 grid((unsigned)chunks), block(64 * BF_WAVES);
-            if (with_loss)
+            if (with_loss & 2)          // loss value with P possibly outside [0, 1] (before the first restrict_P)
+                hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, true, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad);
+            else if (with_loss)
                 hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad);
             else
                 hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad);
@@ -1629,6 +1636,8 @@ static int decode_bce_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
                            float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
                            float* losspart, int32_t with_loss, void* stream, uint8_t* xg, AdamFused ad) {
     if (!xp || !idx || !P || !Q || !dP || !dqpart) return fail("nadm_decode_bce: null pointer");
+    if (with_loss < 0 || with_loss > 3) return fail("nadm_decode_bce: with_loss is a bit set (1: loss value, 2: P may lie outside [0,1])");
+    if (!(with_loss & 1)) with_loss = 0;
     if (with_loss && !losspart) return fail("nadm_decode_bce: with_loss needs losspart");
     if (b <= 0 || M <= 0) return fail("nadm_decode_bce: empty batch or M");
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_decode_bce: ld must be a multiple of 16 and >= ceil(M/4)");

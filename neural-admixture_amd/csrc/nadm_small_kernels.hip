@@ -14,8 +14,14 @@
 
 namespace nadm {
 
-constexpr int MLP_SB = 4;       // samples per block in mlp_fwd / mlp_bwd_a
-struct DqChunks { int64_t n[NADM_MAX_HEADS]; };   // per-head chunk counts of the dQ partial slabs
+#ifndef NADM_MLP_SB
+#define NADM_MLP_SB 4
+#endif
+constexpr int MLP_SB = NADM_MLP_SB;       // samples per block in mlp_fwd / mlp_bwd_a
+struct DqChunks {                       // per head: rows of the dQ partial slab to add up (n) and rows the slab occupies (full)
+    int64_t n[NADM_MAX_HEADS];
+    int64_t full[NADM_MAX_HEADS];
+};
 
 // -------------------------------------------------------------------------------------------------
 // block-wide sum of `n` (<= 64) per-thread values each; result valid for all threads afterwards.
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_kernel(nadm_heads_t hd, const f
                 s_dl[(tid / kp) * SP + hd.qoff[hh] + (tid % kp)] = t;      // raw dQ
             }
             __syncthreads();
-            base += nch * b * kp;
+            base += dq_chunks.full[hh] * b * kp;
         }
     }
     // ---- softmax backward per (sample, head) ----
@@ -327,10 +333,17 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
     const int ns = min(SB, b - i0);
     const int row = SB * CP;
 
+    // ---- head biases into LDS now (one parallel fetch; read per head pass by a few threads below) ----
+    float* const s_bk = s_logit + SB * SP;                           // [SP], behind s_logit in the dynamic allocation
+    for (int hh = 0; hh < hd.n_heads; ++hh)
+        for (int k = tid; k < hd.k[hh]; k += 256) s_bk[hd.qoff[hh] + k] = small[hd.bk_off[hh] + k];
     // ---- weights of this thread's hidden units: issued first, consumed after the Z reduction ----
     const float* W1 = small + hd.w1_off;
     const float* b1 = small + hd.b1_off;
     float w1[JH][8], bb[JH];
+    float gw[8];                                          // RMSNorm weight: loaded here with everything else, not one dependent load
+#pragma unroll                                            // per component inside the single-thread normalisation below
+    for (int c = 0; c < 8; ++c) gw[c] = (c < C) ? small[hd.g_off + c] : 0.f;
 #pragma unroll
     for (int j = 0; j < JH; ++j) {
         const int h = tid + 256 * j;
@@ -369,12 +382,15 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
         const float ri = 1.0f / sqrtf(ms / (float)C + 1e-8f);
         const int64_t i = i0 + tid;
         rinv[i] = ri;
-        for (int c = 0; c < CP; ++c) {
-            const float zz = z[c];
-            Z[i * CP + c] = zz;
-            const float zn = (c < C) ? zz * ri * small[hd.g_off + c] : 0.f;
-            Zn[i * CP + c] = zn;
-            z[c] = zn;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {                     // this kernel: C <= CP <= 8
+            if (c < CP) {
+                const float zz = z[c];
+                Z[i * CP + c] = zz;
+                const float zn = (c < C) ? zz * ri * gw[c] : 0.f;
+                Zn[i * CP + c] = zn;
+                z[c] = zn;
+            }
         }
     }
     __syncthreads();
@@ -396,7 +412,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
     // ---- head logits, MLP_KT columns per pass ----
     for (int hh = 0; hh < hd.n_heads; ++hh) {
         const float* Wk = small + hd.wk_off[hh];
-        const float* bk = small + hd.bk_off[hh];
+        const float* bk = s_bk + hd.qoff[hh];
         const int K = hd.k[hh];
         for (int k0 = 0; k0 < K; k0 += MLP_KT) {
             float wk[JH][MLP_KT];
@@ -462,9 +478,41 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
     extern __shared__ __attribute__((aligned(16))) float s_dl[];         // [SB][SP]
     const int C = hd.C, CP = hd.CP, Hd = hd.Hd, SP = hd.SP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- loss: one EXTRA block (the launch has one more block than sample groups when n_loss > 0).  Inside a working block
+    // the sum -- an HBM round trip, a float64 wave reduction -- was a tail every other block had already left behind.
+    if (n_loss > 0 && blockIdx.x == gridDim.x - 1) {
+        double a = 0.0;
+        for (int64_t e0 = 0; e0 < n_loss; e0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int64_t e = e0 + tid + 256 * u; v[u] = e < n_loss ? losspart[e] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += (double)v[u];
+        }
+        a = wave_sum_all_f64(a);
+        __shared__ double s_l[4];
+        if ((tid & 63) == 0) s_l[tid >> 6] = a;
+        __syncthreads();
+        if (tid == 0) {
+            const double tot = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]);
+            loss_acc[0] += tot;
+            loss_acc[1] = tot;
+        }
+        return;
+    }
     const int i0 = blockIdx.x * SB;
     const int ns = min(SB, b - i0);
 
+    // ---- everything the short single-thread sections below read from global memory is fetched HERE, by many threads at once,
+    // and parked in LDS: Q of the block's samples (softmax backward), Z, rinv and the RMSNorm weight (RMSNorm backward).
+    // Read where they are used -- a handful of threads looping over k or c -- every element is a dependent L2 round trip of
+    // its own while the whole block waits at the next barrier (8 + 8 + 8 round trips = most of the kernel's 33 us).
+    __shared__ float s_z[SB * 8], s_g[8], s_ri[SB];
+    float* const s_q = s_dl + SB * SP;                               // [SB][SP], behind s_dl in the dynamic allocation
+    for (int e = tid; e < SB * SP; e += 256) s_q[e] = (e / SP < ns) ? Q[(int64_t)(i0 + e / SP) * SP + e % SP] : 0.f;
+    if (tid < SB * 8) s_z[tid] = (tid / 8 < ns && (tid & 7) < CP) ? Z[(int64_t)(i0 + tid / 8) * CP + (tid & 7)] : 0.f;
+    if (tid >= 64 && tid < 72) s_g[tid - 64] = (tid - 64 < C) ? small[hd.g_off + tid - 64] : 0.f;
+    if (tid >= 128 && tid < 128 + SB) s_ri[tid - 128] = (tid - 128 < ns) ? rinv[i0 + tid - 128] : 0.f;
     // ---- this thread's hidden units: forward activations (relu mask) and W1 rows, issued first ----
     const float* W1 = small + hd.w1_off;
     float hact[JH][SB], w1[JH][8];
@@ -503,7 +551,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
                 s_dl[(tid / kp) * SP + hd.qoff[hh] + (tid % kp)] = t;
             }
             __syncthreads();
-            base += nch * b * kp;
+            base += dq_chunks.full[hh] * b * kp;
         }
     }
     // ---- softmax backward per (sample, head) ----
@@ -512,7 +560,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
         const int k = hd.k[hh], kp = hd.kp[hh], o = hd.qoff[hh];
         float* dl = s_dl + s * SP + o;
         if (s < ns) {
-            const float* q = Q + (int64_t)(i0 + s) * SP + o;
+            const float* q = s_q + s * SP + o;
             float dot = 0.f;
             for (int j = 0; j < k; ++j) dot = fmaf(dl[j], q[j], dot);
             for (int j = 0; j < kp; ++j) {
@@ -583,37 +631,23 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
     __syncthreads();
     if (tid < ns) {
         const int64_t i = i0 + tid;
-        const float ri = rinv[i];
-        const float* g = small + hd.g_off;
+        const float ri = s_ri[tid];
+        const float* g = s_g;
+        const float* zr = s_z + tid * 8;
         const float* dzn = s_dzn + tid * 8;
         float dot = 0.f;
-        for (int c = 0; c < C; ++c) dot = fmaf(dzn[c] * g[c], Z[i * CP + c], dot);
+        for (int c = 0; c < C; ++c) dot = fmaf(dzn[c] * g[c], zr[c], dot);
         const float mean_tz = dot / (float)C;
         const float ri3 = ri * ri * ri;
         for (int c = 0; c < CP; ++c) {
             float dz = 0.f, dgv = 0.f;
             if (c < C) {
-                const float z = Z[i * CP + c];
+                const float z = zr[c];
                 dz = ri * (dzn[c] * g[c]) - z * ri3 * mean_tz;
                 dgv = dzn[c] * z * ri;
             }
             dZ[i * CP + c] = dz;
             dgp[i * CP + c] = dgv;
-        }
-    }
-    // ---- loss (block 0 only) ----
-    if (blockIdx.x == 0 && n_loss > 0) {
-        double a = 0.0;
-        for (int64_t e = tid; e < n_loss; e += 256) a += (double)losspart[e];
-        a = wave_sum_all_f64(a);
-        __shared__ double s_l[4];
-        __syncthreads();
-        if ((tid & 63) == 0) s_l[tid >> 6] = a;
-        __syncthreads();
-        if (tid == 0) {
-            const double tot = (s_l[0] + s_l[1]) + (s_l[2] + s_l[3]);
-            loss_acc[0] += tot;
-            loss_acc[1] = tot;
         }
     }
 }
@@ -1140,7 +1174,7 @@ extern "C" int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const fl
     if (b <= 0) return fail("nadm_mlp_fwd: empty batch");
     if (hd->Hd <= 256 * MLP_JMAX && hd->C <= 8 && !getenv("NADM_MLP_GENERIC")) {
         const dim3 grid((b + MLP_SB - 1) / MLP_SB);
-        const size_t lds = (size_t)MLP_SB * hd->SP * 4;
+        const size_t lds = (size_t)(MLP_SB + 1) * hd->SP * 4;                    // s_logit + the head biases
         if (hd->Hd <= 1024)
             hipLaunchKernelGGL((mlp_fwd_fast_kernel<MLP_SB, 4>), grid, dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q);
         else
@@ -1158,6 +1192,32 @@ extern "C" int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const fl
 extern "C" int nadm_mlp_bwd_weights(const nadm_heads_t* hd, int32_t b, const float* Zn, const float* H, const float* dL,
                                     const float* dHpre, const float* dgp, float* small_part, float* grad_small, void* stream);
 
+// First level of the dQ reduction.  Pass 2 leaves one slab row [b, kp] per SNP chunk (1954 rows = 50 MB at M = 500k, K = 8);
+// the MLP backward runs one block per 4 samples, and each of its blocks would walk all those rows 128 bytes at a time (33 us,
+// latency-bound, 1.5 TB/s).  Here every thread owns one float4 column of the slab and adds the rows y, y + DQ_R, y + 2 DQ_R, ...
+// into row y -- whole rows are read with full lines by ~450 blocks -- so the MLP backward is left with DQ_R rows per head.
+// In place: row y (< DQ_R) is read only by the threads that also write it.  Fixed order, no atomics.
+constexpr int DQ_R = 64;
+__global__ __launch_bounds__(256) void dq_prereduce_kernel(float* __restrict__ dq, DqChunks n, nadm_heads_t hd, int b) {
+    const int hh = blockIdx.z;
+    const int64_t nch = n.n[hh];
+    if (nch <= DQ_R) return;
+    int64_t base = 0;
+    for (int h = 0; h < hh; ++h) base += n.full[h] * b * hd.kp[h];
+    const int64_t row4 = (int64_t)b * hd.kp[hh] / 4;
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= row4) return;
+    float4* slab = reinterpret_cast<float4*>(dq + base) + col;
+    const int y = blockIdx.y;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int64_t ch = y; ch < nch; ch += DQ_R) {
+        const float4 v = slab[ch * row4];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    slab[(int64_t)y * row4] = a;
+}
+
 extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const float* dqpart, int64_t M, int32_t b,
                             const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
                             float* dL, float* dHpre, float* dgp, float* small_part, float* dZ, float* grad_small,
@@ -1168,10 +1228,24 @@ extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const fl
     if (b <= 0) return fail("nadm_mlp_bwd: empty batch");
     hipStream_t st = (hipStream_t)stream;
     DqChunks dqc;
-    for (int h = 0; h < NADM_MAX_HEADS; ++h) dqc.n[h] = h < hd->n_heads ? nadm_decode_chunks(M, hd->kp[h]) : 0;
+    for (int h = 0; h < NADM_MAX_HEADS; ++h) dqc.n[h] = dqc.full[h] = h < hd->n_heads ? nadm_decode_chunks(M, hd->kp[h]) : 0;
+    {   // slabs of more than 4 * DQ_R rows are folded to DQ_R rows first (dqpart is scratch of the step: reduced in place)
+        int64_t max_rows = 0, max_row4 = 0;
+        for (int h = 0; h < hd->n_heads; ++h) {
+            if (dqc.n[h] > max_rows) max_rows = dqc.n[h];
+            if ((int64_t)b * hd->kp[h] / 4 > max_row4) max_row4 = (int64_t)b * hd->kp[h] / 4;
+        }
+        if (max_rows > 4 * DQ_R && !getenv("NADM_NO_PREREDUCE")) {
+            hipLaunchKernelGGL(dq_prereduce_kernel, dim3((unsigned)((max_row4 + 255) / 256), DQ_R, hd->n_heads), dim3(256), 0, st,
+                               const_cast<float*>(dqpart), dqc, *hd, b);
+            if (check_launch("dq_prereduce")) return 1;
+            for (int h = 0; h < hd->n_heads; ++h)                       // the kernel's rule: heads with more than DQ_R rows were folded
+                if (dqc.n[h] > DQ_R) dqc.n[h] = DQ_R;
+        }
+    }
     if (hd->Hd <= 256 * MLP_JMAX && hd->C <= 8 && !getenv("NADM_MLP_GENERIC")) {
-        const dim3 grid((b + MLP_SB - 1) / MLP_SB);
-        const size_t lds = (size_t)MLP_SB * hd->SP * 4;
+        const dim3 grid((b + MLP_SB - 1) / MLP_SB + (n_loss > 0 ? 1 : 0));          // + the loss block
+        const size_t lds = (size_t)2 * MLP_SB * hd->SP * 4;                      // s_dl + the block's Q rows
         if (hd->Hd <= 1024)
             hipLaunchKernelGGL((mlp_bwd_a_fast_kernel<MLP_SB, 4>), grid, dim3(256), lds, st, *hd, small, dqpart, dqc, b, Z, rinv, H, Q, dL, dHpre, dgp, dZ,
                                losspart, n_loss, loss_acc);

@@ -61,6 +61,7 @@ class Engine:
         self.loss_acc = torch.zeros(2, dtype=torch.float64, device=device)
         self.xp: Optional[torch.Tensor] = None          # packed genotypes [rows, ld]
         self.step_count = 0
+        self.p_unit = True                              # every P entry in [0, 1] (see load_params)
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event) on the launch stream
         # pass 2 writes the batch's gathered rows back to back into xg and pass 3 reads them from there (include/nadm.h,
         # nadm_decode_bce_gather): same bytes, same results, no scattered reads over the resident matrix in pass 3
@@ -154,6 +155,9 @@ class Engine:
             big[L.p_off[h]: L.p_off[h] + L.M * L.kp[h]].reshape(L.M, L.kp[h])[:, :k] = P_SM[ini:ini + k].T
             ini += k
         self.big.copy_(torch.from_numpy(big))
+        # the loss value of pass 2 may skip the clamp of the reconstruction while every P entry lies in [0, 1]; true after the
+        # first restrict_P, and for the GMM initialisation (clipped to [5e-6, 1 - 5e-6]) -- not for the supervised one
+        self.p_unit = bool(np.min(P_SM) >= 0.0 and np.max(P_SM) <= 1.0) if np.size(P_SM) else True
         self.small.copy_(torch.from_numpy(np.ascontiguousarray(small, dtype=np.float32)))
         for t in (self.mbig, self.vbig, self.msmall, self.vsmall, self.gbig, self.gsmall):
             t.zero_()
@@ -264,7 +268,7 @@ class Engine:
                         C.c_void_p(self.Q.data_ptr() + L.qoff[h] * fsz), L.SP,
                         C.c_void_p(self.gbig.data_ptr() + (L.p_off[h] + m0 * kp) * fsz),
                         C.c_void_p(self.dqpart.data_ptr() + (dq_offs[h] + c0 * b * kp) * fsz),
-                        C.c_void_p(self.losspart.data_ptr() + (loss_offs[h] + c0) * fsz), 1 if with_loss else 0)
+                        C.c_void_p(self.losspart.data_ptr() + (loss_offs[h] + c0) * fsz), (1 if self.p_unit else 3) if with_loss else 0)
                 xg = C.c_void_p(self._xg_buf().data_ptr() + m0 // 4) if (h == 0 and self.gather_batch) else None
                 if fused_adam is not None:                    # single-GPU step: Adam + clamp on these P rows in the kernel's epilogue
                     check(lib.nadm_decode_bce_step(*args, xg, C.byref(self._adam_args(L.p_off[h] + m0 * kp, fused_adam)), st), "decode_bce_step")
@@ -387,6 +391,7 @@ class Engine:
         check(lib.nadm_adam(ptr(self.big), ptr(self.gbig), ptr(self.mbig), ptr(self.vbig), L.n_big, L.clamp_from,
                             lr, self.step_count, grad_scale, st), "adam(big)")
         self.adam_part("small", lr, grad_scale)
+        self.p_unit = True                                    # the launch clamps P to [0, 1] (restrict_P)
         if ev: ev[1].record()
 
     def train_step(self, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True) -> None:
@@ -402,6 +407,7 @@ class Engine:
             self.forward(idx, b)
             self.step_count += 1
             self.backward(idx, b, with_loss, fused_adam=(lr, 1.0), side_weights=True)    # small parameters: nadm_small_grads
+            self.p_unit = True                                # restrict_P ran in pass 2's epilogue
             return
         if not self.overlap or self.device.type != "cuda":
             self.forward(idx, b)
@@ -436,6 +442,7 @@ class Engine:
         self.adam_part("V", lr, 1.0)
         if ev: ev[1].record()
         main.wait_event(ev_side)                              # the next step reads P and the small parameters
+        self.p_unit = True
 
     def train_step_ddp(self, idx: torch.Tensor, b: int, lr: float, world: int, with_loss: bool = True,
                        defer_tail: bool = False) -> None:
@@ -504,6 +511,8 @@ class Engine:
         self.adam_part("small", lr, scale)
         if ev: ev[1].record()
         self._pending_ddp = pending
+        self.p_unit = True                                    # every P piece is clamped by its Adam launch (a deferred one in finish_ddp,
+                                                              # which runs before the next pass 2)
 
     def finish_ddp(self) -> None:
         """Apply the Adam update of a P piece whose all-reduce was deferred by train_step_ddp(defer_tail=True)."""

@@ -105,6 +105,7 @@ class SnpShardedEngine(Engine):
         if self.fused_adam:          # dP and dV of the slice are final and local: Adam in the epilogues of passes 2 and 3
             self.step_count += 1
             self.backward(idx, b, with_loss, fused_adam=(lr, 1.0 / self.world))    # small parameters: nadm_small_grads
+            self.p_unit = True                                # restrict_P ran in pass 2's epilogue
             return
         self.backward(idx, b, with_loss)
         self.adam(lr, 1.0 / self.world)
