@@ -40,7 +40,7 @@ extern "C" {
 
 #define NADM_MAX_HEADS 32
 #define NADM_MAX_K 64
-#define NADM_ABI_VERSION 4   /* 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
+#define NADM_ABI_VERSION 5   /* 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
@@ -161,6 +161,11 @@ typedef struct {
     float   lr;
     int32_t step;         /* 1-based step count                       */
     float   grad_scale;   /* gradients are multiplied by this first   */
+    int32_t when;         /* 0: in the kernel's epilogue, from the gradient the launch has just completed (single-GPU step).
+                           * 1 (nadm_decode_bce_step only): in its PROLOGUE, from the gradient that already lies in dP -- the
+                           * data-parallel step: dP of the previous step was all-reduced in between (neural_admixture.py:315-319),
+                           * `step` is that step's count, and the launch then overwrites dP with this step's gradient.  Every P row
+                           * belongs to one block of the launch, so the update needs neither a launch of its own nor a second read of P */
 } nadm_adam_t;
 int nadm_decode_bce_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                          float* P, int32_t kp, const float* Q, int32_t SP,
@@ -218,6 +223,13 @@ int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b
  * >= clamp_from are clamped to [0,1] after the update (pass n for "no clamp"). */
 int nadm_adam(float* param, const float* grad, float* m, float* v, int64_t n, int64_t clamp_from,
               float lr, int32_t step, float grad_scale, void* stream);
+
+/* Two parameter segments in ONE launch (the data-parallel step: V and the small parameters become final together, behind the
+ * [small | dV] all-reduce; as two launches the second one is pure launch latency).  Same element update as nadm_adam; segment
+ * 0 is clamped to [0,1] from element clamp_from0 on, segment 1 never. */
+int nadm_adam2(float* param0, const float* grad0, float* m0, float* v0, int64_t n0, int64_t clamp_from0,
+               float* param1, const float* grad1, float* m1, float* v1, int64_t n1,
+               float lr, int32_t step, float grad_scale, void* stream);
 
 /* ---- 8(f)-3: log-likelihood report from the packed matrix (src/utils_c/utils.pyx:15-40, called train.py:134-146) -----
  * partial[b] (b < nadm_loglik_blocks(M), double, device) = sum over the block's 1024 SNPs and all `rows` rows of

@@ -26,7 +26,8 @@ class Heads(C.Structure):
 
 class AdamArgs(C.Structure):
     """nadm_adam_t (include/nadm.h)."""
-    _fields_ = [("m", C.c_void_p), ("v", C.c_void_p), ("lr", C.c_float), ("step", C.c_int32), ("grad_scale", C.c_float)]
+    _fields_ = [("m", C.c_void_p), ("v", C.c_void_p), ("lr", C.c_float), ("step", C.c_int32), ("grad_scale", C.c_float),
+                ("when", C.c_int32)]
 
 
 class MlpWeights(C.Structure):
@@ -75,13 +76,14 @@ def _load():
         "nadm_encode_bwd": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp]),
         "nadm_vcf_parse_gt": (C.c_int, [C.c_char_p, i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]),
         "nadm_adam": (C.c_int, [vp, vp, vp, vp, i64, i64, f32, i32, f32, vp]),
+        "nadm_adam2": (C.c_int, [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, i64, f32, i32, f32, vp]),
         "nadm_synth_packed": (C.c_int, [vp, i64, i64, i64, i64, vp, vp, i32, f32, u64, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.nadm_abi_version() != 4:
+    if lib.nadm_abi_version() != 5:
         raise RuntimeError("neural_admixture_amd: libnadm.so ABI version mismatch")
     return lib, tuple(sig)
 

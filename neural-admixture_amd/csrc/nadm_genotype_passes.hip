@@ -930,6 +930,21 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     for (int e = tid; e < (MF_TS / 16) * 2 * 64; e += NTHR) (&s_qr[0][0][0])[e] = make_uint4(0, 0, 0, 0);
     for (int e = tid; e < (MF_TS / 32) * (W ? 2 : 1) * 64; e += NTHR) (&s_qd[0][0][0])[e] = make_uint4(0, 0, 0, 0);
 
+    // ---- data-parallel step: the previous step's Adam + clamp on this block's P rows, from the all-reduced gradient in dP ----
+    // (a P row belongs to exactly one block of the launch, which overwrites the same dP rows at its end; doing the update here
+    // instead of in a launch of its own between the all-reduce and this pass saves that launch and one read of P)
+    if (ad.m != nullptr && ad.pre) {
+        constexpr int ROW4P = KP / 4;
+        const int64_t blk0 = chunk * (MF_WAVES * 16 * NTW);
+        for (int e = tid; e < MF_WAVES * 16 * NTW * ROW4P; e += NTHR) {
+            const int64_t m = blk0 + e / ROW4P;
+            if (m < M) {
+                const int64_t o = m * KP + 4 * (e % ROW4P);
+                adam_float4(P + o, *reinterpret_cast<const float4*>(dP + o), ad.m + o, ad.v + o, ad.step_size, ad.bc2_sqrt, ad.grad_scale, true);
+            }
+        }
+        __syncthreads();                                    // the rows are final before any thread of the block loads them below
+    }
     // ---- resident A operands built from P ----
     uint4 pa_r1[NTW], pa_r2[NTW], pa_r3[W ? NTW : 1];     // R^T: lane (row = SNP n, slot a)
 #pragma unroll
@@ -1208,7 +1223,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                 const int64_t o = m * KP + 4 * (e % ROW4);
                 // single-GPU step: the gradient of these rows is final here and nothing else in the step reads P again, so
                 // Adam + clamp is applied on the spot (no dP round trip through HBM, no separate launch for the P matrices)
-                if (ad.m != nullptr) adam_float4(P + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.bc2_sqrt, ad.grad_scale, true);
+                if (ad.m != nullptr && !ad.pre) adam_float4(P + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.bc2_sqrt, ad.grad_scale, true);
                 else *reinterpret_cast<float4*>(dP + o) = g4;
             }
         }
@@ -1504,6 +1519,7 @@ static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx,
             return check_launch("decode_bce_bf16");
         }
     }
+    if (ad.m && ad.pre && launch_adam_range(P, dP, ad, M * KP, st)) return 1;      // no prologue in this kernel: update first
     const int64_t chunks = (M + mf_chunk_snps(KP) - 1) / mf_chunk_snps(KP);
     dim3 grid((unsigned)chunks), block(64 * mf_waves(KP));
     if (with_loss)
@@ -1512,7 +1528,7 @@ static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx,
         hipLaunchKernelGGL((decode_bce_mfma_kernel<KP, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
     if (check_launch("decode_bce_mfma")) return 1;
     if (xg && launch_gather_rows(xp, ld, idx, b, M, xg, st)) return 1;
-    return ad.m ? launch_adam_range(P, dP, ad, M * KP, st) : 0;
+    return (ad.m && !ad.pre) ? launch_adam_range(P, dP, ad, M * KP, st) : 0;
 }
 
 template <int KP>
@@ -1520,6 +1536,7 @@ static int launch_decode(const uint8_t* xp, int64_t ld, const int32_t* idx, int 
                          const float* Q, int SP, float* dP, float* dqpart, float* losspart, int with_loss,
                          hipStream_t st, uint8_t* xg, AdamFused ad) {
     constexpr int SPL = dec_spl(KP);
+    if (ad.m && ad.pre && launch_adam_range(P, dP, ad, M * KP, st)) return 1;      // no prologue in this kernel: update first
     const int64_t chunks = (M + 256 * SPL - 1) / (256 * SPL);
     dim3 grid((unsigned)chunks), block(256);
     if (with_loss)
@@ -1528,7 +1545,7 @@ static int launch_decode(const uint8_t* xp, int64_t ld, const int32_t* idx, int 
         hipLaunchKernelGGL((decode_bce_kernel<KP, SPL, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
     if (check_launch("decode_bce")) return 1;
     if (xg && launch_gather_rows(xp, ld, idx, b, M, xg, st)) return 1;
-    return ad.m ? launch_adam_range(P, dP, ad, M * KP, st) : 0;
+    return (ad.m && !ad.pre) ? launch_adam_range(P, dP, ad, M * KP, st) : 0;
 }
 
 }  // namespace nadm
@@ -1667,23 +1684,25 @@ static int decode_bce_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
 extern "C" int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                                const float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
                                float* losspart, int32_t with_loss, void* stream) {
-    return decode_bce_impl(xp, ld, idx, b, M, const_cast<float*>(P), kp, Q, SP, dP, dqpart, losspart, with_loss, stream, nullptr, AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f});
+    return decode_bce_impl(xp, ld, idx, b, M, const_cast<float*>(P), kp, Q, SP, dP, dqpart, losspart, with_loss, stream, nullptr, AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0});
 }
 
 extern "C" int nadm_decode_bce_gather(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                                       const float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
                                       float* losspart, int32_t with_loss, uint8_t* xg, void* stream) {
     if (!xg) return fail("nadm_decode_bce_gather: null pointer");
-    return decode_bce_impl(xp, ld, idx, b, M, const_cast<float*>(P), kp, Q, SP, dP, dqpart, losspart, with_loss, stream, xg, AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f});
+    return decode_bce_impl(xp, ld, idx, b, M, const_cast<float*>(P), kp, Q, SP, dP, dqpart, losspart, with_loss, stream, xg, AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0});
 }
 
 static int adam_fused_args(const nadm_adam_t* adam, const char* who, AdamFused* out) {
-    *out = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f};
+    *out = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0};
     if (!adam) return 0;
     if (!adam->m || !adam->v) return fail(who);
     if (adam->step < 1) return fail("nadm_*_step: Adam step is 1-based");
     if (((uintptr_t)adam->m | (uintptr_t)adam->v) & 15) return fail("nadm_*_step: Adam state must be 16-byte aligned");
     out->m = adam->m; out->v = adam->v; out->grad_scale = adam->grad_scale;
+    out->pre = adam->when == 1 ? 1 : 0;
+    if (adam->when != 0 && adam->when != 1) return fail("nadm_*_step: nadm_adam_t.when is 0 (epilogue) or 1 (prologue, pass 2 only)");
     adam_scalars(adam->lr, adam->step, &out->step_size, &out->bc2_sqrt);
     return 0;
 }
@@ -1699,7 +1718,7 @@ extern "C" int nadm_decode_bce_step(const uint8_t* xp, int64_t ld, const int32_t
 
 static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                            const float* dZ, int32_t CP, float* dV, void* stream, uint32_t missing_bf16,
-                           float* Vrw = nullptr, AdamFused ad = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f},
+                           float* Vrw = nullptr, AdamFused ad = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0},
                            const nadm_mlp_weights_t* mw = nullptr) {
     if (!xp || !idx || !dZ || !dV) return fail("nadm_encode_bwd: null pointer");
     if (b <= 0 || M <= 0) return fail("nadm_encode_bwd: empty batch or M");

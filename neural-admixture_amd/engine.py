@@ -82,7 +82,7 @@ class Engine:
         self._n_cu: Optional[int] = None
         self.head_streams = 2                                 # decode_all: concurrent pass-2 launches of a multi-head model
         self._head_streams, self._head_events = None, None
-        self._pending_ddp: list = []
+        self._pending_ddp = None                              # (works, lr, grad_scale, step) of a deferred P update
 
     def _xg_buf(self) -> torch.Tensor:
         if self._xg is None:
@@ -227,9 +227,13 @@ class Engine:
         return [(0, m_cut), (m_cut, M)]
 
     def _adam_args(self, off_floats: int, fused) -> "AdamArgs":
-        """nadm_adam_t for the rows of the big buffer that start at float offset ``off_floats``; fused = (lr, grad_scale)."""
+        """nadm_adam_t for the rows of the big buffer that start at float offset ``off_floats``; fused = (lr, grad_scale) for an
+        update in the kernel's epilogue with the current step count, or (lr, grad_scale, step) for the PREVIOUS step's update in
+        the prologue of pass 2 (data-parallel step, nadm_adam_t.when = 1)."""
+        if len(fused) == 3:
+            return AdamArgs(self.mbig.data_ptr() + off_floats * 4, self.vbig.data_ptr() + off_floats * 4, fused[0], fused[2], fused[1], 1)
         lr, scale = fused
-        return AdamArgs(self.mbig.data_ptr() + off_floats * 4, self.vbig.data_ptr() + off_floats * 4, lr, self.step_count, scale)
+        return AdamArgs(self.mbig.data_ptr() + off_floats * 4, self.vbig.data_ptr() + off_floats * 4, lr, self.step_count, scale, 0)
 
     def decode_all(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_grad_ready=None, p_parts=1,
                    supervised: bool = True, fused_adam=None) -> int:
@@ -344,15 +348,16 @@ class Engine:
         if ev: ev[1].record()
 
     def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_decoder_done=None, on_mlp_bwd_done=None,
-                 on_grad_ready=None, p_parts=1, v_parts: int = 1, fused_adam=None, side_weights: bool = False) -> None:
+                 on_grad_ready=None, p_parts=1, v_parts: int = 1, fused_adam=None, side_weights: bool = False, pre_adam=None) -> None:
         """Decoder + BCE fwd/bwd per head, MLP backward, dV.  Gradients land in gbig / gsmall (views of gflat).
         ``on_decoder_done`` (optional callable) is invoked after all the dP kernels are enqueued.  With
         ``on_mlp_bwd_done`` the MLP weight gradients are left to that callback (nadm_mlp_bwd_weights on another stream).
         ``on_grad_ready(lo, hi)`` is invoked each time a contiguous piece gflat[lo:hi] of the big gradients is final and
         enqueued; passes 2 and 3 are launched on ``p_parts`` / ``v_parts`` SNP sub-ranges so that the data-parallel step can
         all-reduce one piece while the next is being computed (each head's P, or the two parts of a single head's P; the
-        small gradients travel with the first piece of dV)."""
-        n_loss = self.decode_all(idx, b, with_loss, on_grad_ready, p_parts, fused_adam=fused_adam)
+        small gradients travel with the first piece of dV).  ``pre_adam`` = (lr, grad_scale, step): pass 2 first applies that
+        (previous) step's Adam + clamp to its P rows from the gradient lying in gbig, then overwrites it (data-parallel step)."""
+        n_loss = self.decode_all(idx, b, with_loss, on_grad_ready, p_parts, fused_adam=fused_adam if pre_adam is None else pre_adam)
         if on_decoder_done is not None:
             on_decoder_done()
         self.mlp_backward(b, n_loss if with_loss else 0, weights=on_mlp_bwd_done is None and not side_weights)
@@ -375,6 +380,14 @@ class Engine:
         else:
             check(lib.nadm_adam(ptr(self.small), ptr(self.gsmall), ptr(self.msmall), ptr(self.vsmall), L.n_small, L.n_small,
                                 lr, self.step_count, grad_scale, st), "adam(small)")
+
+    def adam_v_small(self, lr: float, grad_scale: float) -> None:
+        """Adam on V and on the small parameters in ONE launch (nadm_adam2) for the CURRENT step_count: in the data-parallel step
+        both become final together, behind the [small | dV] all-reduce."""
+        L = self.lay
+        check(lib.nadm_adam2(ptr(self.big), ptr(self.gbig), ptr(self.mbig), ptr(self.vbig), L.clamp_from, L.clamp_from,
+                             ptr(self.small), ptr(self.gsmall), ptr(self.msmall), ptr(self.vsmall), L.n_small,
+                             lr, self.step_count, grad_scale, _stream()), "adam2(V, small)")
 
     def adam_p_range(self, lo: int, hi: int, lr: float, grad_scale: float, step: int, stream=None) -> None:
         """Adam + clamp on elements [lo, hi) of the big buffer (a range inside the P matrices) for step count ``step``."""
@@ -454,9 +467,9 @@ class Engine:
         one message after pass 3.
 
         ``defer_tail``: the next step needs V and the small parameters at once (pass 1, MLP) but P only when its pass 2
-        starts.  The LAST P piece is therefore sent AFTER the small + dV message and its Adam update is applied at the
-        beginning of the next call (or by finish_ddp()), which takes that message off the critical path when the links are
-        the bottleneck.  Same arithmetic, same results; the caller must call finish_ddp() before reading P."""
+        starts.  The LAST P piece is therefore sent AFTER the small + dV message, and the Adam update of ALL P pieces is left to
+        the prologue of the next step's pass 2 (every block updates its own rows from the all-reduced gradient before it uses
+        them) -- or to finish_ddp().  Same arithmetic, same results; the caller must call finish_ddp() before reading P."""
         import torch.distributed as dist
         L = self.lay
         works, pieces = [], []
@@ -488,39 +501,49 @@ class Engine:
                 deferred.append(held[-1])
                 send(*held.pop())
         self.forward(idx, b)
-        self.finish_ddp()                                     # the previous step's deferred P piece: needed from pass 2 on
+        # The previous step's P update (defer_tail): its all-reduced gradient lies in gbig; this step's pass 2 applies Adam + clamp
+        # to every block's own P rows in its prologue (nadm_adam_t.when = 1), so the update costs no launch and no extra read of P.
+        pre = None
+        if self._pending_ddp:
+            pworks, plr, pscale, pstep = self._pending_ddp
+            for w in pworks:
+                if w is not None:
+                    w.wait()                                  # the compute stream waits for the messages, the host does not
+            pre = (plr, pscale, pstep)
+            self._pending_ddp = None
         # message plan: one per head (a head's all-reduce runs under the next head's pass 2); a single head is cut where
         # its last round of blocks starts (_round_ranges); then the small gradients + dV as one message
-        self.backward(idx, b, with_loss, on_grad_ready=reduce_piece, p_parts="rounds" if len(L.ks) == 1 else 1, v_parts=1,
+        self.backward(idx, b, with_loss, on_grad_ready=reduce_piece, p_parts="rounds" if len(L.ks) == 1 else 1, v_parts=1, pre_adam=pre,
                       **({"side_weights": True} if self.side_weights else {}))
         scale = 1.0 / world
         self.step_count += 1
         off = self._ns_pad
         ev = self._timed("adam")
-        deferred_set = set(deferred)
-        pending = []
+        p_works = []
         for w, (lo, hi) in zip(works, pieces):                # messages complete in the order they were enqueued
-            if (lo, hi) in deferred_set:
-                pending.append((w, lo - off, hi - off, lr, scale, self.step_count))
+            if lo >= p_start and defer_tail:                  # a P piece: applied by the next step's pass 2 (or finish_ddp)
+                p_works.append(w)
                 continue
             if w is not None:
                 w.wait()
             if lo >= p_start:                                 # a P piece: Adam on it while later messages are still in flight
                 self.adam_p_range(lo - off, hi - off, lr, scale, self.step_count)
-        self.adam_part("V", lr, scale)                        # every [small | dV] piece is in
-        self.adam_part("small", lr, scale)
+        self.adam_v_small(lr, scale)                          # every [small | dV] piece is in: V and the small parameters, one launch
         if ev: ev[1].record()
-        self._pending_ddp = pending
-        self.p_unit = True                                    # every P piece is clamped by its Adam launch (a deferred one in finish_ddp,
-                                                              # which runs before the next pass 2)
+        self._pending_ddp = (p_works, lr, scale, self.step_count) if defer_tail else None
+        self.p_unit = True                                    # P is clamped by its Adam launch / by the prologue of the pass that reads it next
 
     def finish_ddp(self) -> None:
-        """Apply the Adam update of a P piece whose all-reduce was deferred by train_step_ddp(defer_tail=True)."""
-        for w, lo, hi, lr, scale, step in self._pending_ddp:
+        """Apply the P update train_step_ddp(defer_tail=True) left to the next step's pass 2 (call before reading P)."""
+        if not self._pending_ddp:
+            return
+        works, lr, scale, step = self._pending_ddp
+        for w in works:
             if w is not None:
                 w.wait()
-            self.adam_p_range(lo, hi, lr, scale, step)
-        self._pending_ddp = []
+        L = self.lay
+        self.adam_p_range(L.clamp_from, L.n_big, lr, scale, step)
+        self._pending_ddp = None
 
     def infer_q(self, idx: torch.Tensor, b: int) -> List[torch.Tensor]:
         """Encoder-only pass (final Q, neural_admixture.py:369-383; src/inference.py:71-77)."""

@@ -40,8 +40,11 @@ class OracleEngine(Engine):
             Q[:, L.qoff[i]: L.qoff[i] + k] = Qs[i]
         self.Q[: b * L.SP] = torch.from_numpy(Q.reshape(-1))
 
-    def backward(self, idx, b, with_loss=True, on_decoder_done=None, on_mlp_bwd_done=None, on_grad_ready=None, p_parts=1, v_parts=1):
+    def backward(self, idx, b, with_loss=True, on_decoder_done=None, on_mlp_bwd_done=None, on_grad_ready=None, p_parts=1, v_parts=1,
+                 pre_adam=None):
         L, h = self.lay, self.lay.heads
+        if pre_adam is not None:                        # the product's pass 2 applies the previous step's P update in its prologue
+            self.adam_p_range(L.clamp_from, L.n_big, pre_adam[0], pre_adam[1], pre_adam[2])
         lab = None if self.labels is None else self.labels.numpy().astype(np.int64)[self._idx]
         loss, g, _ = O.step_grads(self._params(), self.G[self._idx], lab)
         big = np.zeros(L.n_big, dtype=np.float32)
@@ -75,6 +78,10 @@ class OracleEngine(Engine):
         self.step_count += 1
         for part in ("P", "V", "small"):
             self.adam_part(part, lr, grad_scale)
+
+    def adam_v_small(self, lr, grad_scale):
+        self.adam_part("V", lr, grad_scale)
+        self.adam_part("small", lr, grad_scale)
 
     def adam_p_range(self, lo, hi, lr, grad_scale, step, stream=None):
         self._adam_on(self.big[lo:hi], self.gbig[lo:hi], self.mbig[lo:hi], self.vbig[lo:hi], True, lr, grad_scale, step)

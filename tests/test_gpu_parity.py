@@ -748,19 +748,20 @@ def test_ddp_step_on_rccl_world1_equals_plain_step():
         assert e1.read_loss() == e2.read_loss()
         # wide enough for the round-boundary cut of pass 2 (two P messages), multi-head (one message per head), and the
         # deferred last P piece (sent after [small | dV], applied at the start of the next step / by finish_ddp)
-        for M2, ks2 in ((300_000, [5]), (40_000, [2, 3, 4])):
+        # ... and the K > 8 (two k slots) and K > 16 (generic kernel: the update is a launch in front of it) variants of pass 2
+        for M2, ks2 in ((300_000, [5]), (40_000, [2, 3, 4]), (6_000, [13]), (3_000, [20])):
             Gw = O.synth_genotypes(12, M2, 3, seed=5)
             pw = O.make_params(2, (rng.standard_normal((M2, 8)) / 500).astype(np.float32),
                                rng.uniform(0.1, 0.9, (sum(ks2), M2)).astype(np.float32), 64, ks2)
             ea, eb, ec = make_engine(Gw, pw, 12), make_engine(Gw, pw, 12), make_engine(Gw, pw, 12)
-            if len(ks2) == 1:
+            if M2 >= 300_000:
                 assert len(eb._round_ranges(256, 1024, 3)) == 2
             ix = torch.arange(12, dtype=torch.int32, device=dev)
             for _ in range(3):
                 ea.train_step(ix, 12, 2e-3, True)
                 eb.train_step_ddp(ix, 12, 2e-3, 1, True)
                 ec.train_step_ddp(ix, 12, 2e-3, 1, True, defer_tail=True)
-                assert len(ec._pending_ddp) == 1
+                assert ec._pending_ddp is not None and len(ec._pending_ddp[0]) >= 1     # P pieces left to the next pass 2 / finish_ddp
             ec.finish_ddp()
             torch.cuda.synchronize()
             assert torch.equal(ea.big, eb.big) and torch.equal(ea.big, ec.big) and torch.equal(ea.small, ec.small)
