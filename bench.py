@@ -332,10 +332,17 @@ def main():
         valu, mfma = sq["valu_insts_per_launch"], sq["mfma_insts_per_launch"]
         clk = sq.get("sclk_ghz", 2.4)
         issue_peak = N_SIMD * clk * 1e9 / VALU_CYCLES_PER_INST           # wave-instructions per second, whole chip
+        simd_cycles = sq.get("busy_cycles_sum_over_se", 0.0) * 32.0        # SQ_BUSY_CYCLES is per shader engine (32 SIMDs each)
         issue = {"valu_insts_per_genotype": valu * 64.0 / genotypes_launch, "mfma_insts_per_64_genotypes": mfma * 64.0 / genotypes_launch,
                  "valu_wave_insts_per_launch": valu, "issue_peak_wave_insts_per_s": issue_peak, "sclk_ghz": clk,
                  "achieved_frac_of_valu_issue_peak": valu / t_dom / issue_peak,
-                 "note": "VALU wave-instructions of one launch / its duration vs 1024 SIMDs x clk / 4 cycles; MFMA issue comes on top (not hidden, DESIGN.md section 4)"}
+                 # counters of the same launch: cycles a SIMD spent issuing VALU work / matrix work over all SIMD-cycles of the launch.
+                 # The two do not overlap on a SIMD (tools/ubench_issue.hip), so their sum is the issue utilisation; the rest is the
+                 # partly filled last round of blocks, barriers and dependency stalls
+                 "simd_valu_busy_frac": sq["active_inst_valu_quad_cycles"] * 4.0 / simd_cycles if simd_cycles else None,
+                 "simd_mfma_busy_frac": sq["valu_mfma_busy_cycles"] / simd_cycles if simd_cycles else None,
+                 "note": "VALU wave-instructions of one launch / its duration vs 1024 SIMDs x clk / 4 cycles (instructions cost 2.9-8.3 cycles, "
+                         "tools/ubench_valu_asm.hip); MFMA issue comes on top (not hidden, DESIGN.md section 4)"}
     achieved = alg_8d / t_dom / 1e9
     step_bytes = 0.75 * b * M + 36.0 * (8 + S) * M                        # SURVEY.md 8d whole-step figure: 0.75 + 36 (C+S)/b per genotype
     per_step_units = (gb if snp else b * world) * M

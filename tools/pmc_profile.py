@@ -115,7 +115,7 @@ def main():
         out = {"round": RND, "src_hash": src, "workload_key": workload_key(line), "kernels": [k[:80] for k in dec],
                "valu_insts_per_launch": tot("SQ_INSTS_VALU"), "mfma_insts_per_launch": tot("SQ_INSTS_MFMA"),
                "lds_insts_per_launch": tot("SQ_INSTS_LDS"), "salu_insts_per_launch": tot("SQ_INSTS_SALU"),
-               "wave_quad_cycles": tot("SQ_WAVE_CYCLES"), "active_inst_valu_quad_cycles": tot("SQ_ACTIVE_INST_VALU"),
+               "busy_cycles_sum_over_se": tot("SQ_BUSY_CYCLES"), "wave_quad_cycles": tot("SQ_WAVE_CYCLES"), "active_inst_valu_quad_cycles": tot("SQ_ACTIVE_INST_VALU"),
                "valu_mfma_busy_cycles": tot("SQ_VALU_MFMA_BUSY_CYCLES"), "wait_inst_any_quad_cycles": tot("SQ_WAIT_INST_ANY"),
                "wait_any_quad_cycles": tot("SQ_WAIT_ANY"), "lds_bank_conflict_cycles": tot("SQ_LDS_BANK_CONFLICT"),
                "active_inst_lds_quad_cycles": tot("SQ_ACTIVE_INST_LDS"), "sclk_ghz": 2.4,
