@@ -19,7 +19,7 @@ samples the library's per-component numpy loops take 22-45 s while the whole tra
 
 The K tiny Cholesky factorisations run on the host with the same LAPACK calls the library uses; everything that touches
 the N samples is a device op.  ``tests/test_abi_and_host.py`` checks the means against the library's on the CPU and
-``tests/test_gpu_parity.py`` on the GPU; ``NADM_GMM=sklearn`` selects the library fit (_gmm_fit.py) instead."""
+``tests/test_gpu_parity.py`` on the GPU; ``gmm_p_init(..., fit="sklearn")`` selects the library fit (_gmm_fit.py) instead."""
 from __future__ import annotations
 
 import math

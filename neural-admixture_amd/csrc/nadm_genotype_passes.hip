@@ -514,41 +514,7 @@ __global__ __launch_bounds__(256) void encode_bwd_kernel(
 }
 
 
-// =================================================================================================
-// pass 2, matrix-core version (KP <= 16): fp32 MFMA 16x16x4 for R^T = P.Q^T and dQ^T = P^T.dR^T,
-// VALU for the per-genotype BCE algebra and for dP = dR^T.Q.
-//
-//   tile = 16 SNPs x 16 samples, D layout of v_mfma_f32_16x16x4_f32: lane l holds rows 4(l>>4)+r,
-//   column l&15.  With rows = SNPs and columns = samples:
-//     * a lane's 4 D registers are 4 CONSECUTIVE SNPs of ONE sample = exactly one packed byte,
-//     * the dR registers are directly the B operand (B[k = SNP (l>>4, r)][col = sample l&15]) of
-//       dQ^T += P^T.dR^T, which the matrix core reduces over SNPs (no cross-lane traffic),
-//     * dP reduces over samples = over the low lane bits, which MFMA cannot do from this layout; it
-//       runs on the VALU into lane-local accumulators [tile][4 SNPs][KP] that persist for the whole
-//       sample loop and are reduced over the 16 sample-lanes ONCE per block (DPP).
-//   f32-input MFMA is bit-for-bit an fmaf chain, so numerics equal the VALU kernel up to summation
-//   order (cdna_hip_programming.md section 3).
-//
-//   block = 16 waves (1024 threads) = one block per CU at 4 waves/SIMD (<=128 VGPRs);
-//   wave w owns NTW tiles: SNPs  snp_wave0 + 8a*(NTW/2).. : for NTW=2 tile t, row (a,r) <-> SNP
-//   8a + 4t + r, so the lane reads ONE ushort per sample (tile 0 = low byte, tile 1 = high byte).
-//   X / Q tiles of 32 samples are double-buffered in LDS and prefetched one tile ahead; dQ partials
-//   of the 16 waves are combined through LDS per 32-sample tile and written as one [b,KP] slab
-//   per chunk (deterministic fixed-order sums everywhere).
-// =================================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int CTRL>
-__device__ __forceinline__ float row_xchg_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float row16_sum(float v) {     // sum over the 16 lanes of a DPP row, in all lanes
-    v = row_xchg_add<0xB1>(v);
-    v = row_xchg_add<0x4E>(v);
-    v = row_xchg_add<0x141>(v);
-    v = row_xchg_add<0x140>(v);
-    return v;
-}
 
 // Shape of the bf16 matrix-core pass-2 kernel (KP <= 8), tuned on MI355X with bench.py (b=800, M=500k, K=8; decode time
 // with / without the loss):  8 waves x 4 tiles, occupancy 2: 435 / 373 us;  8 x 2, occ. 4: 401 / 331;  4 x 2, occ. 4:
@@ -565,223 +531,10 @@ __device__ __forceinline__ float row16_sum(float v) {     // sum over the 16 lan
 #ifndef NADM_BF_WPE
 #define NADM_BF_WPE 3        // waves per SIMD the register allocator must leave room for
 #endif
-constexpr int mf_ts(int kp) { return kp <= 8 ? 64 : 32; }   // samples per LDS tile in the matrix-core kernel (LDS <= 64 KB)
-constexpr int mf_waves(int kp) { return kp <= 8 ? NADM_BF_WAVES : 8; }   // waves per block (kp <= 8: shared with the bf16 kernel so both write the same dQ slabs)
+constexpr int mf_waves(int kp) { return NADM_BF_WAVES; }   // waves per block
 constexpr int MF_RS_PAD = 16;       // LDS row stride of the X tile = row bytes + 16 (16 B aligned, de-phased banks)
-constexpr int mf_ntw(int kp) { return kp <= 8 ? NADM_BF_NTW : 2; }            // 16-SNP tiles per wave (dP accumulators: NTW*4*KP regs <= 128)
+constexpr int mf_ntw(int kp) { return NADM_BF_NTW; }            // 16-SNP tiles per wave
 constexpr int mf_chunk_snps(int kp) { return mf_waves(kp) * 16 * mf_ntw(kp); }
-
-// gradient w.r.t. the pre-clamp reconstruction and (optionally) the BCE loss term of one genotype.
-// x = genotype/2 with missing already mapped to 0 (fp4_pair below).
-// loss uses one log: x=0 -> log(1-r), x=1 -> log r, x=.5 -> .5*log(r(1-r)); the -100 clamps of the two
-// separate terms can only bind when r is exactly 0 or 1, where the merged form gives the same value.
-template <bool LOSS>
-__device__ __forceinline__ float bce_elem(float r_raw, float cf, float& lossacc) {
-    const float r = __builtin_amdgcn_fmed3f(r_raw, 0.f, 1.f);
-    const float omr = 1.f - r;
-    const float den_raw = omr * r;
-    const float g = fmaf(-0.5f, cf, r) * __builtin_amdgcn_rcpf(fmaxf(den_raw, 1e-12f));
-    if constexpr (LOSS) {
-        const bool is1 = (cf == 1.f);
-        const float t = (cf == 2.f) ? r : (is1 ? den_raw : omr);
-        const float w = is1 ? 0.5f * 0.69314718055994530942f : 0.69314718055994530942f;
-        lossacc -= fmaxf(__builtin_amdgcn_logf(t) * w, is1 ? -50.f : -100.f);
-    }
-    return (r == r_raw) ? g : 0.f;
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// acc.xy += s.x * q.xy   (packed FMA, src0 low half broadcast to both lanes of the pair)
-__device__ __forceinline__ void pk_fma_bcast(f32x2& acc, const f32x2 s, const f32x2 q) {
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(s), "v"(q));
-}
-
-template <int KP, bool LOSS>
-__global__ __launch_bounds__(64 * mf_waves(KP)) void decode_bce_mfma_kernel(
-    const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
-    const float* __restrict__ P, const float* __restrict__ Q, int SP,
-    float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart) {
-    constexpr int KQ = KP / 4;
-    constexpr int NTW = mf_ntw(KP);
-    constexpr int MF_WAVES = mf_waves(KP);
-    constexpr int MF_TS = mf_ts(KP);
-    constexpr int RB = MF_WAVES * 4 * NTW;              // packed bytes per row per block (96 or 64)
-    constexpr int RS = RB + MF_RS_PAD;
-    constexpr int PPR = RB / 16;                         // 16 B pieces per row
-    __shared__ __attribute__((aligned(16))) uint8_t s_x[2][MF_TS * RS];
-    __shared__ __attribute__((aligned(16))) float s_q[2][MF_TS * KP];
-    __shared__ __attribute__((aligned(16))) float s_dq[MF_WAVES][MF_TS * KP];
-    __shared__ float s_loss[MF_WAVES];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int a = lane >> 4, n = lane & 15;
-    const int64_t chunk = blockIdx.x;
-    const int64_t byte0 = chunk * RB;
-    const int64_t snp_wave0 = chunk * mf_chunk_snps(KP) + wave * (16 * NTW);
-    // SNP of (tile t, row-block a', r'):  snp_wave0 + 4*NTW*a' + 4*t + r'
-    auto snp_of = [&](int t, int ab, int r) -> int64_t { return snp_wave0 + 4 * NTW * ab + 4 * t + r; };
-    auto ldP = [&](int64_t m, int k) -> float { return (m < M && k < KP) ? P[m * KP + k] : 0.f; };
-
-    // ---- resident MFMA operands built from P (one-off, straight from global) ----
-    float pa_r[NTW][KQ];        // R^T = P.Q^T   : A[row = SNP n][k = a + 4j]
-    float pa_q[NTW][4];         // dQ^T += P^T.dR: A[row = k = n][kk = SNP (a, r)]
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-#pragma unroll
-        for (int j = 0; j < KQ; ++j) pa_r[t][j] = ldP(snp_of(t, n >> 2, n & 3), a + 4 * j);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pa_q[t][r] = ldP(snp_of(t, a, r), n);
-    }
-    f32x2 dp[NTW][4][KP / 2];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int k = 0; k < KP / 2; ++k) dp[t][r][k] = (f32x2){0.f, 0.f};
-    float lossacc = 0.f;
-
-    // ---- X / Q tile staging.  Every thread issues the (unconditional, address-clamped) loads so that the
-    //      waits on them are unconditional too: a wait hidden inside a divergent branch makes the compiler
-    //      drain the prefetch at the first MFMA of the next tile.  The row index for the NEXT tile is
-    //      fetched one tile early, so the index->row dependency never stalls. ----
-    constexpr int NTHR = 64 * MF_WAVES;
-    constexpr int NPIECE = MF_TS * PPR;                      // 16 B pieces per X tile (<= NTHR)
-    static_assert(NPIECE <= NTHR, "one piece per thread");
-    const int pc = tid < NPIECE ? tid : tid - NPIECE * (tid / NPIECE);   // duplicate pieces beyond NPIECE (never committed)
-    const int pr = pc / PPR, pc16 = pc % PPR;
-    const int64_t poff = byte0 + pc16 * 16;
-    const bool pcol_ok = poff * 4 < M;             // not `< ld`: on an SNP sub-range launch the bytes past M belong to the next range
-    const int64_t poff_c = pcol_ok ? poff : 0;
-    auto row_index = [&](int i0) -> int32_t { const int smp = i0 + pr; return idx[smp < b ? smp : b - 1]; };
-    int32_t row_pref = row_index(0);                         // kept as the raw 32-bit value: widened only when used
-    uint4 stage;
-    auto issue = [&](int i0) {
-        stage = *reinterpret_cast<const uint4*>(xp + (int64_t)row_pref * ld + poff_c);
-        row_pref = row_index(i0 + MF_TS);                    // index of the tile after this one
-    };
-    auto commit = [&](int buf, int i0) {
-        const bool ok = pcol_ok && (i0 + pr < b);
-        const uint4 v = ok ? stage : make_uint4(0, 0, 0, 0);
-        if (tid < NPIECE) *reinterpret_cast<uint4*>(&s_x[buf][pr * RS + pc16 * 16]) = v;
-    };
-    constexpr int QPT = (MF_TS * KP + NTHR - 1) / NTHR;      // Q elements per thread per tile
-    float qstage[QPT];
-    auto issue_q = [&](int i0) {                             // global -> registers (consumed one tile later)
-#pragma unroll
-        for (int u = 0; u < QPT; ++u) {
-            const int e = tid + u * NTHR;
-            const int ec = e < MF_TS * KP ? e : 0;
-            const int r = ec / KP, k = ec % KP;
-            const int smp = i0 + r < b ? i0 + r : b - 1;
-            qstage[u] = Q[(int64_t)smp * SP + k];
-        }
-    };
-    auto commit_q = [&](int buf, int i0) {
-#pragma unroll
-        for (int u = 0; u < QPT; ++u) {
-            const int e = tid + u * NTHR;
-            const int r = e / KP;
-            if (e < MF_TS * KP) s_q[buf][e] = (i0 + r < b) ? qstage[u] : 0.f;
-        }
-    };
-
-    issue(0);
-    issue_q(0);
-    commit(0, 0);
-    commit_q(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): every prologue load (P operands, tile 0) has landed
-    __syncthreads();
-
-    const int ntiles = (b + MF_TS - 1) / MF_TS;
-    for (int tl = 0; tl < ntiles; ++tl) {
-        const int cur = tl & 1;
-        const int i0 = tl * MF_TS;
-        const int nt = min(MF_TS, b - i0);
-        if (tl + 1 < ntiles) { issue_q(i0 + MF_TS); issue(i0 + MF_TS); }   // block-uniform
-
-#pragma unroll 1
-        for (int stl = 0; stl < MF_TS / 16; ++stl) {
-            if (i0 + 16 * stl < b) {                                  // block-uniform
-                const int srow = 16 * stl + n;                          // this lane's sample row in the tile
-                float qb[KQ];                                           // B of R^T: Q[sample n][k = a + 4j]
-#pragma unroll
-                for (int j = 0; j < KQ; ++j) qb[j] = s_q[cur][srow * KP + a + 4 * j];
-                f32x2 q8[KP / 2];                                       // this lane's sample: all KP columns
-#pragma unroll
-                for (int j = 0; j < KQ; ++j) {
-                    const float4 v = *reinterpret_cast<const float4*>(&s_q[cur][srow * KP + 4 * j]);
-                    q8[2 * j] = (f32x2){v.x, v.y}; q8[2 * j + 1] = (f32x2){v.z, v.w};
-                }
-                uint32_t bits;                                          // NTW bytes: 4 SNPs x NTW tiles of this sample
-                if constexpr (NTW == 4) bits = *reinterpret_cast<const uint32_t*>(&s_x[cur][srow * RS + wave * 16 + 4 * a]);
-                else if constexpr (NTW == 2) bits = *reinterpret_cast<const uint16_t*>(&s_x[cur][srow * RS + wave * 8 + 2 * a]);
-                else bits = s_x[cur][srow * RS + wave * 4 + a];
-                bits &= ~((bits & (bits >> 1) & 0x55555555u) * 3u);         // missing (3) -> 0: x = 0 in input and target
-
-                f32x4 dq = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) {
-                    f32x4 D = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int j = 0; j < KQ; ++j) D = __builtin_amdgcn_mfma_f32_16x16x4f32(pa_r[t][j], qb[j], D, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float cf = (float)((bits >> (8 * t + 2 * r)) & 3u);
-                        f32x2 dR2;
-                        dR2.x = bce_elem<LOSS>(D[r], cf, lossacc);
-#pragma unroll
-                        for (int k = 0; k < KP / 2; ++k) pk_fma_bcast(dp[t][r][k], dR2, q8[k]);
-                        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(pa_q[t][r], dR2.x, dq, 0, 0, 0);
-                    }
-                }
-                // dQ^T tile: lane (a, n) holds k = 4a + r', sample n  ->  s_dq[wave][sample][k]
-                if (4 * a < KP)
-                    *reinterpret_cast<float4*>(&s_dq[wave][srow * KP + 4 * a]) = make_float4(dq[0], dq[1], dq[2], dq[3]);
-            }
-        }
-        __syncthreads();
-        for (int e = tid; e < nt * KP; e += NTHR) {
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < MF_WAVES; ++w) s += s_dq[w][e];
-            dqpart[(chunk * b + i0) * KP + e] = s;
-        }
-        if (tl + 1 < ntiles) {
-            commit(cur ^ 1, i0 + MF_TS);
-            commit_q(cur ^ 1, i0 + MF_TS);
-        }
-        __syncthreads();
-    }
-
-    // ---- dP: reduce the lane-local accumulators over the 16 sample lanes, lane n==0 stores ----
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float o[KP];
-#pragma unroll
-            for (int k = 0; k < KP / 2; ++k) { o[2 * k] = row16_sum(dp[t][r][k].x); o[2 * k + 1] = row16_sum(dp[t][r][k].y); }
-            const int64_t m = snp_of(t, a, r);
-            if (n == 0 && m < M) {
-#pragma unroll
-                for (int k = 0; k < KP; k += 4)
-                    *reinterpret_cast<float4*>(dP + m * KP + k) = make_float4(o[k], o[k + 1], o[k + 2], o[k + 3]);
-            }
-        }
-    }
-    if constexpr (LOSS) {
-        const float s = wave_sum_lane63(lossacc);
-        if (lane == 63) s_loss[wave] = s;
-        __syncthreads();
-        if (tid == 0) {
-            float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < MF_WAVES; ++w) tot += s_loss[w];
-            losspart[chunk] = tot;
-        }
-    }
-}
 
 // =================================================================================================
 // pass 2, bf16 matrix-core version (KP <= 8).  f32-input MFMA runs on the vector ALUs and does not overlap
@@ -1453,22 +1206,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // ---- SNPs per lane in pass 2 as a function of the padded head width (register budget ~128) ----
 constexpr int dec_spl(int kp) { return kp <= 8 ? 8 : (kp <= 16 ? 4 : (kp <= 32 ? 2 : 1)); }
 
-static bool use_mfma_decode() {
-    static const bool v = [] {
-        const char* e = getenv("NADM_DECODE_IMPL");
-        return !(e && strcmp(e, "valu") == 0);
-    }();
-    return v;
-}
-
-static bool use_bf16_decode() {
-    static const bool v = [] {
-        const char* e = getenv("NADM_DECODE_IMPL");
-        return !(e && strcmp(e, "mfma_f32") == 0);
-    }();
-    return v;
-}
-
 // Adam on n floats for the variants of passes 2 and 3 that have no fused epilogue (same element function)
 __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ p, const float* __restrict__ g, AdamFused ad, int64_t n, int clamp01) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
@@ -1505,30 +1242,16 @@ template <int KP>
 static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, float* P,
                               const float* Q, int SP, float* dP, float* dqpart, float* losspart, int with_loss,
                               hipStream_t st, uint8_t* xg, AdamFused ad) {
-    if constexpr (KP <= 16) {
-        if (use_bf16_decode()) {
-            static_assert(mf_chunk_snps(KP) == BF_WAVES * 16 * BF_NTW, "same chunking as the f32 MFMA kernel");
-            const int64_t chunks = (M + mf_chunk_snps(KP) - 1) / mf_chunk_snps(KP);
-            dim3 grid((unsigned)chunks), block(64 * BF_WAVES);
-            if (with_loss & 2)          // loss value with P possibly outside [0, 1] (before the first restrict_P)
-                hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, true, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad);
-            else if (with_loss)
-                hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad);
-            else
-                hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad);
-            return check_launch("decode_bce_bf16");
-        }
-    }
-    if (ad.m && ad.pre && launch_adam_range(P, dP, ad, M * KP, st)) return 1;      // no prologue in this kernel: update first
+    static_assert(KP <= 16 && mf_chunk_snps(KP) == BF_WAVES * 16 * BF_NTW, "chunking published by nadm_decode_chunk_snps");
     const int64_t chunks = (M + mf_chunk_snps(KP) - 1) / mf_chunk_snps(KP);
-    dim3 grid((unsigned)chunks), block(64 * mf_waves(KP));
-    if (with_loss)
-        hipLaunchKernelGGL((decode_bce_mfma_kernel<KP, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
+    dim3 grid((unsigned)chunks), block(64 * BF_WAVES);
+    if (with_loss & 2)          // loss value with P possibly outside [0, 1] (before the first restrict_P)
+        hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, true, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad);
+    else if (with_loss)
+        hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad);
     else
-        hipLaunchKernelGGL((decode_bce_mfma_kernel<KP, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
-    if (check_launch("decode_bce_mfma")) return 1;
-    if (xg && launch_gather_rows(xp, ld, idx, b, M, xg, st)) return 1;
-    return (ad.m && !ad.pre) ? launch_adam_range(P, dP, ad, M * KP, st) : 0;
+        hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad);
+    return check_launch("decode_bce_bf16");
 }
 
 template <int KP>
@@ -1552,13 +1275,8 @@ static int launch_decode(const uint8_t* xp, int64_t ld, const int32_t* idx, int 
 
 using namespace nadm;
 
-static bool use_mfma_encode() {
-    static const bool v = [] {
-        const char* e = getenv("NADM_ENCODE_IMPL");
-        return !(e && strcmp(e, "valu") == 0);
-    }();
-    return v;
-}
+// the matrix-core kernels of passes 1 and 3 cover CP <= 8; wider encoders (n_components > 8) run the VALU kernels
+static bool use_mfma_encode() { return true; }
 
 // NOTE: the chunk count must not depend on CP (callers size zpart before they pass CP); the MFMA kernel
 // covers CP <= 8 and the VALU kernel writes the same 2048-SNP chunks when it is the fallback.
@@ -1568,7 +1286,7 @@ extern "C" int64_t nadm_encode_chunks(int64_t M) {
 }
 
 extern "C" int32_t nadm_decode_chunk_snps(int kp) {
-    if (kp <= 16 && use_mfma_decode()) return mf_chunk_snps(kp);
+    if (kp <= 16) return mf_chunk_snps(kp);
     return 256 * dec_spl(kp);
 }
 
@@ -1659,7 +1377,7 @@ static int decode_bce_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
     if (b <= 0 || M <= 0) return fail("nadm_decode_bce: empty batch or M");
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_decode_bce: ld must be a multiple of 16 and >= ceil(M/4)");
     hipStream_t st = (hipStream_t)stream;
-    if (kp <= 16 && use_mfma_decode()) {
+    if (kp <= 16) {
         switch (kp) {
             case 4: return launch_decode_mfma<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
             case 8: return launch_decode_mfma<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);

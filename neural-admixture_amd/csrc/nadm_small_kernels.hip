@@ -14,10 +14,7 @@
 
 namespace nadm {
 
-#ifndef NADM_MLP_SB
-#define NADM_MLP_SB 4
-#endif
-constexpr int MLP_SB = NADM_MLP_SB;       // samples per block in mlp_fwd / mlp_bwd_a
+constexpr int MLP_SB = 4;       // samples per block in mlp_fwd / mlp_bwd_a (2 and 1 were measured: slower)
 struct DqChunks {                       // per head: rows of the dQ partial slab to add up (n) and rows the slab occupies (full)
     int64_t n[NADM_MAX_HEADS];
     int64_t full[NADM_MAX_HEADS];
@@ -1251,7 +1248,7 @@ extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const fl
             if (dqc.n[h] > max_rows) max_rows = dqc.n[h];
             if ((int64_t)b * hd->kp[h] / 4 > max_row4) max_row4 = (int64_t)b * hd->kp[h] / 4;
         }
-        if (max_rows > 4 * DQ_R && !getenv("NADM_NO_PREREDUCE")) {
+        if (max_rows > 4 * DQ_R) {
             hipLaunchKernelGGL(dq_prereduce_kernel, dim3((unsigned)((max_row4 + 255) / 256), DQ_R, hd->n_heads), dim3(256), 0, st,
                                const_cast<float*>(dqpart), dqc, *hd, b);
             if (check_launch("dq_prereduce")) return 1;

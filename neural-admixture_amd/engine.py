@@ -70,8 +70,8 @@ class Engine:
         self._iota: Optional[torch.Tensor] = None
         self._xg_key = None
         self.side_weights = device.type == "cuda"            # MLP weight-gradient partials as extra blocks of pass 3's launch
-        self.fused_adam = device.type == "cuda" and os.environ.get("NADM_FUSED_ADAM", "1") != "0"   # see train_step
-        self.sync_tail_message = os.environ.get("NADM_DDP_SYNC_TAIL", "1") != "0"   # see train_step_ddp.send
+        self.fused_adam = device.type == "cuda"               # Adam in the epilogues of passes 2 and 3, see train_step
+        self.sync_tail_message = True                         # see train_step_ddp.send
         self.timers: Optional[dict] = None                    # {name: [(start, end) HIP events]} when a dict (bench.py)
         self.timed_names = None                               # restrict the timers to these kernel names (None = all)
         # train_step(): optional second stream for the work that does not depend on pass 3.  Measured on MI355X (b=800,

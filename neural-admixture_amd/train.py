@@ -43,12 +43,13 @@ def pca_project_gpu(data, V_CM: np.ndarray, device: torch.device, chunk_rows: in
 
 
 def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_components: int, seed: int,
-               device: Optional[torch.device] = None) -> np.ndarray:
+               device: Optional[torch.device] = None, fit: str = "auto") -> np.ndarray:
     """P_init [sum(ks), M] = clip(GMM means @ V, 5e-6, 1-5e-6) in the PCA subspace (train.py:49-68).
     Note the projection keeps missing (3) as 1.5, exactly like the reference (train.py:52).
     ``data_np``: uint8 [N,M] array or an io.PackedGenotypes.  With a GPU ``device`` and n_components <= 8 the
     projection runs on the GPU (pca_project_gpu); otherwise on the host, 1024 rows at a time like the reference.
-    The mixture fit is scikit-learn's on a CPU device and its restatement in device ops (_gmm_em.py) on a GPU."""
+    The mixture fit (``fit``): "sklearn" = the reference's scikit-learn call, "em" = its float64 restatement in device ops
+    (_gmm_em.py, same means to 1e-13), "auto" = the device for N > 20000 on a GPU, the library otherwise."""
     N = data_np.shape[0]
     if device is not None and device.type == "cuda" and n_components <= 8:
         X_pca = pca_project_gpu(data_np, V_CM, device)
@@ -59,8 +60,7 @@ def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_comp
             X_pca[i:i + 1024] = (rows(i, min(N, i + 1024)).astype(np.float32) / 2) @ V_CM.T
     X_pca = X_pca.astype("float64")
     ks = [K] if K is not None else list(range(min_k, max_k + 1))
-    import os
-    how = os.environ.get("NADM_GMM", "auto")                    # "em" | "sklearn" force one; both give the same means (1e-13)
+    how = fit
     on_gpu = device is not None and device.type == "cuda"
     # device EM: ~0.6 ms per iteration whatever N (launch-bound) + ~0.8 s of one-off start-up (first float64 batched GEMMs);
     # library fit: proportional to N (1 s at N = 2504, 22-45 s at N = 100k), and several K can run as concurrent child

@@ -947,7 +947,7 @@ def test_rows_at_offsets_beyond_4_gib_in_a_resident_matrix_of_configs4_size():
 
 
 def test_mixture_means_on_the_gpu_equal_the_library_fit():
-    """train.gmm_p_init on a GPU device fits the mixture with _gmm_em (float64 device ops); NADM_GMM=sklearn selects the
+    """train.gmm_p_init on a GPU device fits the mixture with _gmm_em (float64 device ops) for large N; fit="sklearn" selects the
     library fit the reference calls (train.py:61).  Same means -> same P init."""
     from neural_admixture_amd._gmm_em import fit_means as em
     from neural_admixture_amd._gmm_fit import fit_means as sk
@@ -962,11 +962,7 @@ def test_mixture_means_on_the_gpu_equal_the_library_fit():
     V = np.linalg.svd(Gm.astype(np.float32), full_matrices=False)[2][:8].astype(np.float32)
     res = {}
     for how in ("em", "sklearn"):
-        os.environ["NADM_GMM"] = how
-        try:
-            res[how] = gmm_p_init(Gm, V, None, 2, 4, 8, 42, dev)
-        finally:
-            del os.environ["NADM_GMM"]
+        res[how] = gmm_p_init(Gm, V, None, 2, 4, 8, 42, dev, fit=how)
     a, b = res["em"], res["sklearn"]
     assert a.shape == b.shape == (9, 4000) and np.abs(a - b).max() < 1e-6
 
