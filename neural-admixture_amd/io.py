@@ -112,15 +112,21 @@ def read_bed_packed(path: str, device: Optional[torch.device] = None, keep_on_de
         check(lib.nadm_bed_to_packed(C.c_void_p(B.ctypes.data), N, M, ptr(out), ld, c4, 1, C.byref(fl)), "bed_to_packed")
         counts, flipped = [int(c4[i]) for i in range(4)], bool(fl.value)
     assert sum(counts) == N * M
-    if counts[1] == 0 and counts[2] == 0 and counts[3] == 0:
-        raise AssertionError("Only biallelic SNPs are supported.")
+    # the reference's check on the decoded matrix, from the code counts before the flip (src/snp_reader.py:109):
+    # int(G.min()) == 0 and int(G.max()) in (2, 3)
+    if counts[0] == 0 or (counts[2] == 0 and counts[3] == 0):
+        raise AssertionError("Only biallelic SNPs are supported. Please make sure multiallelic sites have been removed.")
     return PackedGenotypes(out, N, M, flipped)
 
 
 def orient_minor_allele(G: np.ndarray) -> np.ndarray:
     """The reference's orientation rule (src/snp_reader.py:109-110): ``G if G.mean() < 1 else 2 - G``.  There the
-    subtraction is done in uint8, which turns a missing call 3 into 255; every consumer masks the code with 3 again
-    (pack2bit.cu:29), i.e. missing stays missing -- written out here."""
+    subtraction is done in uint8, which turns a missing call 3 into 255.  Its GPU training path masks the code with 3 again
+    when it packs (pack2bit.cu:29), i.e. missing stays missing -- that is what is written out here.  DELIBERATE DIVERGENCE on
+    flipped inputs that contain missing calls: the reference's RSVD, its GMM projection and its log-likelihood consume the
+    255 unmasked (and its CPU training path fails in BCE on it); here a missing call stays code 3
+    everywhere (1.5 in the projections, skipped by the log-likelihood), so V, P_init and the reported log-likelihood of such
+    an input differ from the reference's.  Inputs that are not flipped (mean code < 1, the usual minor-allele coding) agree."""
     assert int(G.min()) == 0 and int(G.max()) in (2, 3), \
         "Only biallelic SNPs are supported. Please make sure multiallelic sites have been removed."
     if G.mean() < 1:

@@ -479,3 +479,28 @@ def test_hudsons_fst_of_the_product_matches_the_reference_table():
             assert abs(hudsons_fst(P[:, b], P[:, a]) - float(fst[a, b])) < 1e-6
             assert abs(hudsons_fst(P[:, a], P[:, b]) - float(fst[a, b])) < 1e-6     # symmetric in its arguments
     assert hudsons_fst(P[:, 0], P[:, 0]) == 0.0
+
+
+def test_bed_reader_applies_the_reference_biallelic_check(tmp_path):
+    """src/snp_reader.py:109: ``int(G.min()) == 0 and int(G.max()) in (2, 3)`` -- a matrix without a single 0, or with
+    nothing above 1, is refused with the reference's message (computed from the code counts, no uint8 matrix)."""
+    from neural_admixture_amd.io import read_bed_packed
+    inv = np.array([3, 2, 0, 1], dtype=np.uint8)                           # genotype code -> PLINK 2-bit code
+
+    def write(Gm, name):
+        N, M = Gm.shape
+        codes = inv[Gm.T]
+        pad = np.zeros((M, (N + 3) // 4 * 4), dtype=np.uint8)
+        pad[:, :N] = codes
+        bed = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+        (tmp_path / f"{name}.bed").write_bytes(bytes([0x6C, 0x1B, 0x01]) + bed.tobytes())
+        (tmp_path / f"{name}.fam").write_text("\n".join(["s"] * N) + "\n")
+        return str(tmp_path / f"{name}.bed")
+    rng = np.random.default_rng(0)
+    ok = rng.choice(np.array([0, 0, 0, 1, 2], dtype=np.uint8), size=(9, 21))
+    assert read_bed_packed(write(ok, "ok")).shape == (9, 21)
+    for bad, name in ((np.ones((9, 21), dtype=np.uint8), "only1"),                        # max == 1
+                      (rng.choice(np.array([1, 2], dtype=np.uint8), size=(9, 21)), "no0"),  # min == 1
+                      (rng.choice(np.array([0, 1], dtype=np.uint8), size=(9, 21)), "no2")): # max == 1
+        with pytest.raises(AssertionError, match="biallelic"):
+            read_bed_packed(write(bad, name))
