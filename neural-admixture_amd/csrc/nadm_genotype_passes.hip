@@ -666,7 +666,12 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     __shared__ __attribute__((aligned(16))) uint4 s_qr[MF_TS / 16][2][64];   // B operands of R^T per 16-sample tile
     __shared__ __attribute__((aligned(16))) uint4 s_qd[MF_TS / 32][W ? 2 : 1][64];   // B operands of dP per 32-sample pair
     __shared__ __attribute__((aligned(16))) float s_dq[MF_WAVES][MF_TS * KP];
-    __shared__ __attribute__((aligned(16))) uint16_t s_t[MF_WAVES][2][2][32 * 16];  // per wave: [SNP tile of the pair][hi / lo][32 samples][16 SNPs]
+    // row stride / plane size of the transposition buffer in bf16 units: 16 SNPs + 4 pad.  With dense 32-byte rows the 8-byte
+    // writes of a half-wave fall on 4 banks groups (4-way conflicts, 56 % of the LDS-busy cycles in r01's counters); 40-byte
+    // rows spread them.  -4 % on the kernel without the loss value (230 -> 221 us), nothing with it (VALU-bound); K > 8 keeps
+    // the dense rows, its 50 KB of LDS would not fit three blocks per CU with the pad
+    constexpr int TWS = W ? 16 : 20, TWP = 32 * TWS;
+    __shared__ __attribute__((aligned(16))) uint16_t s_t[MF_WAVES][2][2][TWP];  // per wave: [SNP tile of the pair][hi / lo][32 samples][16 SNPs (+ pad)]
     __shared__ float s_loss[MF_WAVES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -880,8 +885,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                                 lo[t2][h2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rem, bf16x2_t));
                             }
                             // transposition buffer of this SNP tile: T[t2][hl][sample 16*s2 + n][SNP 4a .. 4a+3]  (row = 16 bf16 = 32 B)
-                            *reinterpret_cast<uint2*>(tw + (2 * t2 + 0) * 512 + (16 * s2 + n) * 16 + 4 * a) = make_uint2(hi[t2][0], hi[t2][1]);
-                            *reinterpret_cast<uint2*>(tw + (2 * t2 + 1) * 512 + (16 * s2 + n) * 16 + 4 * a) = make_uint2(lo[t2][0], lo[t2][1]);
+                            *reinterpret_cast<uint2*>(tw + (2 * t2 + 0) * TWP + (16 * s2 + n) * TWS + 4 * a) = make_uint2(hi[t2][0], hi[t2][1]);
+                            *reinterpret_cast<uint2*>(tw + (2 * t2 + 1) * TWP + (16 * s2 + n) * TWS + 4 * a) = make_uint2(lo[t2][0], lo[t2][1]);
                         }
                         // dQ^T of this sample tile: the lane's 8 dR values (2 tiles x 4 SNPs) are the B operand
                         const bf16x8 bh = as_bf16x8(make_uint4(hi[0][0], hi[0][1], hi[1][0], hi[1][1]));
@@ -899,11 +904,11 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                         // A operand: lane (row = SNP n, slot a = samples 8a..8a+7): two transposing reads of 4 samples each
                         typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_p;
                         const int trow = 8 * a + (n >> 2), tcol = (n & 3) * 4;
-                        const uint16_t* th = tw + (2 * t2 + 0) * 512, *tlw = tw + (2 * t2 + 1) * 512;
-                        const s16x4_t h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(th + trow * 16 + tcol));
-                        const s16x4_t h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(th + (trow + 4) * 16 + tcol));
-                        const s16x4_t l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(tlw + trow * 16 + tcol));
-                        const s16x4_t l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(tlw + (trow + 4) * 16 + tcol));
+                        const uint16_t* th = tw + (2 * t2 + 0) * TWP, *tlw = tw + (2 * t2 + 1) * TWP;
+                        const s16x4_t h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(th + trow * TWS + tcol));
+                        const s16x4_t h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(th + (trow + 4) * TWS + tcol));
+                        const s16x4_t l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(tlw + trow * TWS + tcol));
+                        const s16x4_t l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(tlw + (trow + 4) * TWS + tcol));
                         const bf16x8 ah = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                         const bf16x8 al = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
                         const int t = 2 * tp + t2;
