@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_kernel(nadm_heads_t hd, const f
 constexpr int MLP_JMAX = 8;     // hidden units per thread: JH = 4 (Hd <= 1024) or 8 (Hd <= 2048)
 constexpr int MLP_KT = 8;       // head columns per pass of the hidden-dimension reductions
 
-template <int SB, int JH>
+template <int SB, int JH, bool C8>
 __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, const float* __restrict__ small,
                                                            const float* __restrict__ zpart, int64_t n_chunks, int b,
                                                            float* __restrict__ Z, float* __restrict__ rinv,
@@ -341,12 +341,35 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
     float gw[8];                                          // RMSNorm weight: loaded here with everything else, not one dependent load
 #pragma unroll                                            // per component inside the single-thread normalisation below
     for (int c = 0; c < 8; ++c) gw[c] = (c < C) ? small[hd.g_off + c] : 0.f;
+    // W1 is [Hd, C] row-major: with C == 8 a thread's row is 32 contiguous bytes = two 16-byte loads (8 load instructions per
+    // thread); read element by element it is 32 instructions whose 64 lanes each touch a different 32-byte sector -- those
+    // loads alone kept the texture path busy for ~8 us per block (s_memtime probe, warm caches make no difference)
+    // Every load of a phase is UNCONDITIONAL with a clamped index, in straight-line code, and masked afterwards: a load under a
+    // lane-dependent condition -- or inside a run-time branch -- becomes its own block with a wait behind it, and the 24-56
+    // loads of a phase then pay one L2 round trip EACH instead of one together (s_memtime probe: 5.5 us for the H + W1 loads
+    // of mlp_bwd_a).  C8 (C == 8, 16-byte aligned W1: the default model) is a template parameter for the same reason: W1 is
+    // [Hd, C] row-major, a thread's row is then two 16-byte loads instead of 8 loads whose lanes each touch another sector.
 #pragma unroll
     for (int j = 0; j < JH; ++j) {
-        const int h = tid + 256 * j;
-        bb[j] = h < Hd ? b1[h] : 0.f;
+        const int h = tid + 256 * j, hc = h < Hd ? h : Hd - 1;
+        bb[j] = b1[hc];
+        if constexpr (C8) {
+            const float4 lo4 = reinterpret_cast<const float4*>(W1)[hc * 2];
+            const float4 hi4 = reinterpret_cast<const float4*>(W1)[hc * 2 + 1];
+            w1[j][0] = lo4.x; w1[j][1] = lo4.y; w1[j][2] = lo4.z; w1[j][3] = lo4.w;
+            w1[j][4] = hi4.x; w1[j][5] = hi4.y; w1[j][6] = hi4.z; w1[j][7] = hi4.w;
+        } else {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) w1[j][c] = (h < Hd && c < C) ? W1[h * C + c] : 0.f;
+            for (int c = 0; c < 8; ++c) w1[j][c] = W1[hc * C + (c < C ? c : 0)];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < JH; ++j) {                                   // masks, after every load has been issued
+        const bool in = tid + 256 * j < Hd;
+        bb[j] = in ? bb[j] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) w1[j][c] = (in && c < C) ? w1[j][c] : 0.f;
     }
     // ---- Z = sum over chunks (same scheme as mlp_fwd_kernel) ----
     {
@@ -357,10 +380,15 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
         if (g < G && e4 * 4 < ns * CP) {
             const float4* src = reinterpret_cast<const float4*>(zpart + (int64_t)i0 * CP) + e4;
             const int64_t stride4 = (int64_t)b * CP / 4;
-#pragma unroll 8
-            for (int64_t ch = g; ch < n_chunks; ch += G) {
-                const float4 v = src[ch * stride4];
-                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            // eight rows per trip, loaded unconditionally (clamped row) and added under a mask: with the trip count unknown the
+            // unrolled loop tested and waited per row -- 4 of the kernel's 14 us for 8 loads
+            for (int64_t ch0 = g; ch0 < n_chunks; ch0 += 8 * G) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int64_t ch = ch0 + (int64_t)u * G; v[u] = src[(ch < n_chunks ? ch : n_chunks - 1) * stride4]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (ch0 + (int64_t)u * G < n_chunks) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
             }
         }
         reinterpret_cast<float4*>(s_grp)[tid] = a;
@@ -414,11 +442,16 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
         for (int k0 = 0; k0 < K; k0 += MLP_KT) {
             float wk[JH][MLP_KT];
 #pragma unroll
-            for (int j = 0; j < JH; ++j) {
-                const int h = tid + 256 * j;
+            for (int kk = 0; kk < MLP_KT; ++kk) {                              // unconditional, all in flight together (see the W1 loads)
+                const float* row = Wk + (k0 + kk < K ? k0 + kk : K - 1) * Hd;   // wave-uniform row, clamped
 #pragma unroll
-                for (int kk = 0; kk < MLP_KT; ++kk) wk[j][kk] = (h < Hd && k0 + kk < K) ? Wk[(k0 + kk) * Hd + h] : 0.f;
+                for (int j = 0; j < JH; ++j) { const int h = tid + 256 * j; wk[j][kk] = row[h < Hd ? h : Hd - 1]; }
             }
+            __builtin_amdgcn_sched_barrier(0);                                 // keep the loads above their first use
+#pragma unroll
+            for (int kk = 0; kk < MLP_KT; ++kk)
+#pragma unroll
+                for (int j = 0; j < JH; ++j) wk[j][kk] = (tid + 256 * j < Hd && k0 + kk < K) ? wk[j][kk] : 0.f;
             float acc[SB][MLP_KT];
 #pragma unroll
             for (int s = 0; s < SB; ++s)
@@ -460,7 +493,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
     }
 }
 
-template <int SB, int JH>
+template <int SB, int JH, bool C8>
 __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, const float* __restrict__ small,
                                                              const float* __restrict__ dqpart, DqChunks dq_chunks, int b,
                                                              const float* __restrict__ Z, const float* __restrict__ rinv,
@@ -514,12 +547,28 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
     const float* W1 = small + hd.w1_off;
     float hact[JH][SB], w1[JH][8];
 #pragma unroll
+    for (int j = 0; j < JH; ++j) {                                   // unconditional, straight-line: see mlp_fwd_fast_kernel
+        const int h = tid + 256 * j, hc = h < Hd ? h : Hd - 1;
+#pragma unroll
+        for (int s = 0; s < SB; ++s) hact[j][s] = H[(int64_t)(i0 + (s < ns ? s : ns - 1)) * Hd + hc];
+        if constexpr (C8) {
+            const float4 lo4 = reinterpret_cast<const float4*>(W1)[hc * 2];
+            const float4 hi4 = reinterpret_cast<const float4*>(W1)[hc * 2 + 1];
+            w1[j][0] = lo4.x; w1[j][1] = lo4.y; w1[j][2] = lo4.z; w1[j][3] = lo4.w;
+            w1[j][4] = hi4.x; w1[j][5] = hi4.y; w1[j][6] = hi4.z; w1[j][7] = hi4.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) w1[j][c] = W1[hc * C + (c < C ? c : 0)];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
     for (int j = 0; j < JH; ++j) {
-        const int h = tid + 256 * j;
+        const bool in = tid + 256 * j < Hd;
 #pragma unroll
-        for (int s = 0; s < SB; ++s) hact[j][s] = (h < Hd && s < ns) ? H[(int64_t)(i0 + s) * Hd + h] : 0.f;
+        for (int s = 0; s < SB; ++s) hact[j][s] = (in && s < ns) ? hact[j][s] : 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) w1[j][c] = (h < Hd && c < C) ? W1[h * C + c] : 0.f;
+        for (int c = 0; c < 8; ++c) w1[j][c] = (in && c < C) ? w1[j][c] : 0.f;
     }
     // ---- dQ = sum over chunks, per head ----
     {
@@ -582,11 +631,16 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
         for (int k0 = 0; k0 < K; k0 += MLP_KT) {
             float wk[JH][MLP_KT];
 #pragma unroll
-            for (int j = 0; j < JH; ++j) {
-                const int h = tid + 256 * j;
+            for (int kk = 0; kk < MLP_KT; ++kk) {                              // unconditional, all in flight together (see the W1 loads)
+                const float* row = Wk + (k0 + kk < K ? k0 + kk : K - 1) * Hd;   // wave-uniform row, clamped
 #pragma unroll
-                for (int kk = 0; kk < MLP_KT; ++kk) wk[j][kk] = (h < Hd && k0 + kk < K) ? Wk[(k0 + kk) * Hd + h] : 0.f;
+                for (int j = 0; j < JH; ++j) { const int h = tid + 256 * j; wk[j][kk] = row[h < Hd ? h : Hd - 1]; }
             }
+            __builtin_amdgcn_sched_barrier(0);                                 // keep the loads above their first use
+#pragma unroll
+            for (int kk = 0; kk < MLP_KT; ++kk)
+#pragma unroll
+                for (int j = 0; j < JH; ++j) wk[j][kk] = (tid + 256 * j < Hd && k0 + kk < K) ? wk[j][kk] : 0.f;
 #pragma unroll
             for (int kk = 0; kk < MLP_KT; ++kk) {
                 float dls[SB];
@@ -1188,10 +1242,11 @@ extern "C" int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const fl
     if (hd->Hd <= 256 * MLP_JMAX && hd->C <= 8 && !getenv("NADM_MLP_GENERIC")) {
         const dim3 grid((b + MLP_SB - 1) / MLP_SB);
         const size_t lds = (size_t)(MLP_SB + 1) * hd->SP * 4;                    // s_logit + the head biases
-        if (hd->Hd <= 1024)
-            hipLaunchKernelGGL((mlp_fwd_fast_kernel<MLP_SB, 4>), grid, dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q);
-        else
-            hipLaunchKernelGGL((mlp_fwd_fast_kernel<MLP_SB, 8>), grid, dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q);
+        const bool c8 = hd->C == 8 && ((reinterpret_cast<uintptr_t>(small) + 4 * (size_t)hd->w1_off) & 15) == 0;
+#define NADM_FWD_LAUNCH(JH, C8) hipLaunchKernelGGL((mlp_fwd_fast_kernel<MLP_SB, JH, C8>), grid, dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q)
+        if (hd->Hd <= 1024) { if (c8) NADM_FWD_LAUNCH(4, true); else NADM_FWD_LAUNCH(4, false); }
+        else { if (c8) NADM_FWD_LAUNCH(8, true); else NADM_FWD_LAUNCH(8, false); }
+#undef NADM_FWD_LAUNCH
     } else if (hd->Hd <= 2048) {
         const size_t lds = (size_t)(1024 + MLP_SB * (hd->CP + hd->Hd + hd->SP)) * 4;
         hipLaunchKernelGGL((mlp_fwd_kernel<MLP_SB>), dim3((b + MLP_SB - 1) / MLP_SB), dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q);
@@ -1259,12 +1314,12 @@ extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const fl
     if (hd->Hd <= 256 * MLP_JMAX && hd->C <= 8 && !getenv("NADM_MLP_GENERIC")) {
         const dim3 grid((b + MLP_SB - 1) / MLP_SB + (n_loss > 0 ? 1 : 0));          // + the loss block
         const size_t lds = (size_t)2 * MLP_SB * hd->SP * 4;                      // s_dl + the block's Q rows
-        if (hd->Hd <= 1024)
-            hipLaunchKernelGGL((mlp_bwd_a_fast_kernel<MLP_SB, 4>), grid, dim3(256), lds, st, *hd, small, dqpart, dqc, b, Z, rinv, H, Q, dL, dHpre, dgp, dZ,
-                               losspart, n_loss, loss_acc);
-        else
-            hipLaunchKernelGGL((mlp_bwd_a_fast_kernel<MLP_SB, 8>), grid, dim3(256), lds, st, *hd, small, dqpart, dqc, b, Z, rinv, H, Q, dL, dHpre, dgp, dZ,
-                               losspart, n_loss, loss_acc);
+        const bool c8 = hd->C == 8 && ((reinterpret_cast<uintptr_t>(small) + 4 * (size_t)hd->w1_off) & 15) == 0;
+#define NADM_BWD_LAUNCH(JH, C8) hipLaunchKernelGGL((mlp_bwd_a_fast_kernel<MLP_SB, JH, C8>), grid, dim3(256), lds, st, *hd, small, dqpart, dqc, b, Z, rinv, H, Q, \
+                                                   dL, dHpre, dgp, dZ, losspart, n_loss, loss_acc)
+        if (hd->Hd <= 1024) { if (c8) NADM_BWD_LAUNCH(4, true); else NADM_BWD_LAUNCH(4, false); }
+        else { if (c8) NADM_BWD_LAUNCH(8, true); else NADM_BWD_LAUNCH(8, false); }
+#undef NADM_BWD_LAUNCH
     } else if (hd->Hd <= 2048) {
         const size_t lds = (size_t)(1024 + MLP_SB * (hd->SP + hd->CP + hd->Hd)) * 4;
         hipLaunchKernelGGL((mlp_bwd_a_kernel<MLP_SB>), dim3((b + MLP_SB - 1) / MLP_SB), dim3(256), lds, st, *hd, small, dqpart, dqc, b, Z, rinv, H, Q,

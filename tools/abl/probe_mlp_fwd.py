@@ -12,14 +12,9 @@ rng = np.random.default_rng(0)
 e.load_params((0.01 * rng.standard_normal((M, 8))).astype(np.float32), rng.uniform(0.01, 0.99, (K, M)).astype(np.float32), init_encoder_weights(1, 8, 1024, [K]))
 idx = torch.arange(b, dtype=torch.int32, device=dev)
 e.fused_adam = False
-names = "after Q,Z,g,rinv fetched(0), [W1 ptr calc](1), after H + W1 loads(2), dq loop+reduce(3), softmax-bwd(4), dH incl Wk loads(5), part(6), end(7)"
 for it in range(30):
     e.forward(idx, b); e.backward(idx, b, True)
+e.forward(idx, b)
 torch.cuda.synchronize()
-t = e.dHpre[400 * 1024: 400 * 1024 + 8].cpu().numpy().astype(np.int64)
-print("COLD (inside a full step):", t, names)
-for it in range(5):
-    e.mlp_backward(b, 0)
-torch.cuda.synchronize()
-t = e.dHpre[400 * 1024: 400 * 1024 + 8].cpu().numpy().astype(np.int64)
-print("WARM (5 launches back to back):", t)
+t = e.H[400 * 1024: 400 * 1024 + 8].cpu().numpy().astype(np.int64)
+print("fwd: weights+bias fetched(0), Z reduce(1), rmsnorm(2), hidden(3), logits incl Wk(4), -, -, end(7):", t)
