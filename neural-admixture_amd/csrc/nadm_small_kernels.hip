@@ -583,10 +583,14 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
             if (g < G && e4 * 4 < ns * kp) {
                 const float4* src = reinterpret_cast<const float4*>(dqpart + base + (int64_t)i0 * kp) + e4;
                 const int64_t stride4 = (int64_t)b * kp / 4;
-#pragma unroll 16
-                for (int64_t ch = g; ch < nch; ch += G) {
-                    const float4 v = src[ch * stride4];
-                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                constexpr int DQD = 16;     // rows per trip: loaded unconditionally (clamped row), added under a mask -- see mlp_fwd_fast_kernel
+                for (int64_t ch0 = g; ch0 < nch; ch0 += (int64_t)DQD * G) {
+                    float4 v[DQD];
+#pragma unroll
+                    for (int u = 0; u < DQD; ++u) { const int64_t ch = ch0 + (int64_t)u * G; v[u] = src[(ch < nch ? ch : nch - 1) * stride4]; }
+#pragma unroll
+                    for (int u = 0; u < DQD; ++u)
+                        if (ch0 + (int64_t)u * G < nch) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
                 }
             }
             reinterpret_cast<float4*>(s_grp)[tid] = a;
@@ -900,13 +904,23 @@ __global__ __launch_bounds__(256) void mlp_bwd_b_kernel(nadm_heads_t hd, int b, 
     mlp_bwd_b_block(hd, b, Zn, H, dL, dHpre, dgp, small_part, blockIdx.x, blockIdx.y);
 }
 
+// sum over the sample splits of element e, rows in order (bit-identical whichever kernel calls it); 32 rows per trip are
+// loaded unconditionally (clamped row) so that they are in flight together -- the plain loop over a run-time count waited per
+// unrolled group
+__device__ __forceinline__ float sum_splits(const float* __restrict__ part, int splits, int n, int e) {
+    float a = 0.f;
+    for (int j0 = 0; j0 < splits; j0 += 32) {
+        float v[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) v[u] = part[(int64_t)(j0 + u < splits ? j0 + u : splits - 1) * n + e];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) if (j0 + u < splits) a += v[u];
+    }
+    return a;
+}
 __global__ void small_reduce_kernel(const float* __restrict__ part, int splits, int n, float* __restrict__ out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    float a = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < splits; ++j) a += part[(int64_t)j * n + e];
-    out[e] = a;
+    if (e < n) out[e] = sum_splits(part, splits, n, e);
 }
 
 // =================================================================================================
@@ -1260,11 +1274,14 @@ extern "C" int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const fl
 extern "C" int nadm_mlp_bwd_weights(const nadm_heads_t* hd, int32_t b, const float* Zn, const float* H, const float* dL,
                                     const float* dHpre, const float* dgp, float* small_part, float* grad_small, void* stream);
 
-// First level of the dQ reduction.  Pass 2 leaves one slab row [b, kp] per SNP chunk (1954 rows = 50 MB at M = 500k, K = 8);
-// the MLP backward runs one block per 4 samples, and each of its blocks would walk all those rows 128 bytes at a time (33 us,
-// latency-bound, 1.5 TB/s).  Here every thread owns one float4 column of the slab and adds the rows y, y + DQ_R, y + 2 DQ_R, ...
-// into row y -- whole rows are read with full lines by ~450 blocks -- so the MLP backward is left with DQ_R rows per head.
+// First level of the dQ reduction for TALL slabs.  Pass 2 leaves one slab row [b, kp] per SNP chunk (1954 rows = 50 MB at
+// M = 500k, K = 8); the MLP backward runs one block per 4 samples and each of its blocks walks all those rows 128 bytes at a
+// time, 16 rows in flight per thread: latency-bound, ~1 us per trip -- 8 us at 1954 rows, growing with M.  Here every thread
+// owns one float4 column of the slab and adds the rows y, y + DQ_R, y + 2 DQ_R, ... into row y -- whole rows are read with full
+// lines by ~450 blocks at 4.5 TB/s (11 us per 50 MB) -- so the MLP backward is left with DQ_R rows per head.  Measured at
+// M = 500k: 13.2 + 11.1 us with the fold against 21.3 us without, hence the fold only above DQ_R_MIN_ROWS rows (M > 655k).
 // In place: row y (< DQ_R) is read only by the threads that also write it.  Fixed order, no atomics.
+constexpr int DQ_R_MIN_ROWS = 2560;
 constexpr int DQ_R = 64;
 __global__ __launch_bounds__(256) void dq_prereduce_kernel(float* __restrict__ dq, DqChunks n, nadm_heads_t hd, int b) {
     const int hh = blockIdx.z;
@@ -1297,13 +1314,13 @@ extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const fl
     hipStream_t st = (hipStream_t)stream;
     DqChunks dqc;
     for (int h = 0; h < NADM_MAX_HEADS; ++h) dqc.n[h] = dqc.full[h] = h < hd->n_heads ? nadm_decode_chunks(M, hd->kp[h]) : 0;
-    {   // slabs of more than 4 * DQ_R rows are folded to DQ_R rows first (dqpart is scratch of the step: reduced in place)
+    {   // tall slabs are folded to DQ_R rows first (dqpart is scratch of the step: reduced in place)
         int64_t max_rows = 0, max_row4 = 0;
         for (int h = 0; h < hd->n_heads; ++h) {
             if (dqc.n[h] > max_rows) max_rows = dqc.n[h];
             if ((int64_t)b * hd->kp[h] / 4 > max_row4) max_row4 = (int64_t)b * hd->kp[h] / 4;
         }
-        if (max_rows > 4 * DQ_R) {
+        if (max_rows > DQ_R_MIN_ROWS) {
             hipLaunchKernelGGL(dq_prereduce_kernel, dim3((unsigned)((max_row4 + 255) / 256), DQ_R, hd->n_heads), dim3(256), 0, st,
                                const_cast<float*>(dqpart), dqc, *hd, b);
             if (check_launch("dq_prereduce")) return 1;
@@ -1359,13 +1376,12 @@ __global__ void small_reduce_adam_kernel(const float* __restrict__ part, int spl
                                          float* __restrict__ p, AdamFused ad) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
-    float a = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < splits; ++j) a += part[(int64_t)j * n + e];
+    float mq = 0.f, vq = 0.f, pq = 0.f;
+    if (ad.m != nullptr) { mq = ad.m[e]; vq = ad.v[e]; pq = p[e]; }            // in flight with the partial sums
+    const float a = sum_splits(part, splits, n, e);
     out[e] = a;
     if (ad.m != nullptr) {
-        float mq = ad.m[e], vq = ad.v[e];
-        p[e] = adam_element(p[e], a, mq, vq, ad.step_size, ad.bc2_sqrt, ad.grad_scale, false);
+        p[e] = adam_element(pq, a, mq, vq, ad.step_size, ad.bc2_sqrt, ad.grad_scale, false);
         ad.m[e] = mq; ad.v[e] = vq;
     }
 }
