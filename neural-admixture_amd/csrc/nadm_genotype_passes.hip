@@ -688,21 +688,31 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     for (int e = tid; e < (MF_TS / 16) * 2 * 64; e += NTHR) (&s_qr[0][0][0])[e] = make_uint4(0, 0, 0, 0);
     for (int e = tid; e < (MF_TS / 32) * (W ? 2 : 1) * 64; e += NTHR) (&s_qd[0][0][0])[e] = make_uint4(0, 0, 0, 0);
 
-    // ---- data-parallel step: the previous step's Adam + clamp on this block's P rows, from the all-reduced gradient in dP ----
-    // (a P row belongs to exactly one block of the launch, which overwrites the same dP rows at its end; doing the update here
-    // instead of in a launch of its own between the all-reduce and this pass saves that launch and one read of P)
-    if (ad.m != nullptr && ad.pre) {
+    // ---- the block's P rows [chunk SNPs x KP] -> LDS, once, with full 16 B / lane lines (the transposition buffers are free until
+    // the first tile); the operands below are built from that image.  Read element by element from global memory -- 48 dword
+    // loads per thread whose lanes each touch another sector -- the prologue took 16-27 k cycles of a block's ~215 k (s_memtime
+    // probe), most of it memory latency.  Data-parallel step (ad.pre): the previous step's Adam + clamp is applied on the way,
+    // from the all-reduced gradient lying in dP (a P row belongs to exactly one block of the launch, which overwrites the same
+    // dP rows at its end: the update needs neither a launch of its own nor a second read of P).
+    static_assert(sizeof(s_t) >= (size_t)MF_WAVES * 16 * NTW * KP * sizeof(float), "the P image fits the transposition buffers");
+    float* const s_p = reinterpret_cast<float*>(&s_t[0][0][0][0]);
+    {
         constexpr int ROW4P = KP / 4;
         const int64_t blk0 = chunk * (MF_WAVES * 16 * NTW);
         for (int e = tid; e < MF_WAVES * 16 * NTW * ROW4P; e += NTHR) {
             const int64_t m = blk0 + e / ROW4P;
+            float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < M) {
                 const int64_t o = m * KP + 4 * (e % ROW4P);
-                adam_float4(P + o, *reinterpret_cast<const float4*>(dP + o), ad.m + o, ad.v + o, ad.step_size, ad.bc2_sqrt, ad.grad_scale, true);
+                if (ad.m != nullptr && ad.pre)
+                    adam_float4(P + o, *reinterpret_cast<const float4*>(dP + o), ad.m + o, ad.v + o, ad.step_size, ad.bc2_sqrt, ad.grad_scale, true);
+                p4 = *reinterpret_cast<const float4*>(P + o);
             }
+            reinterpret_cast<float4*>(s_p)[e] = p4;
         }
-        __syncthreads();                                    // the rows are final before any thread of the block loads them below
+        __syncthreads();
     }
+    auto p_at = [&](int64_t m, int k) -> float { return s_p[(int)(m - chunk * (MF_WAVES * 16 * NTW)) * KP + k]; };   // rows past M hold zeros
     // ---- resident A operands built from P ----
     uint4 pa_r1[NTW], pa_r2[NTW], pa_r3[W ? NTW : 1];     // R^T: lane (row = SNP n, slot a)
 #pragma unroll
@@ -712,8 +722,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
         uint32_t h[4], md[4], lo[4];
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
-            const float v0 = (m < M && k0 + k < KP) ? P[m * KP + k0 + k] : 0.f;
-            const float v1 = (m < M && k0 + k + 1 < KP) ? P[m * KP + k0 + k + 1] : 0.f;
+            const float v0 = (k0 + k < KP) ? p_at(m, k0 + k) : 0.f;
+            const float v1 = (k0 + k + 1 < KP) ? p_at(m, k0 + k + 1) : 0.f;
             split3_pair(v0, v1, h[k >> 1], md[k >> 1], lo[k >> 1]);
         }
         const uint4 H = make_uint4(h[0], h[1], h[2], h[3]);
@@ -745,8 +755,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
             const int64_t m0 = snp_of(2 * tp + (e >> 2), a, e & 3), m1 = snp_of(2 * tp + (e >> 2), a, (e & 3) + 1);
-            const float v0 = (m0 < M && kq < KP) ? P[m0 * KP + kq] : 0.f;
-            const float v1 = (m1 < M && kq < KP) ? P[m1 * KP + kq] : 0.f;
+            const float v0 = (kq < KP) ? p_at(m0, kq) : 0.f;
+            const float v1 = (kq < KP) ? p_at(m1, kq) : 0.f;
             uint32_t h, md, lo;
             split3_pair(v0, v1, h, md, lo);
             if constexpr (W) { w1[e >> 1] = h; w2[e >> 1] = md; }

@@ -11,13 +11,14 @@ e.set_packed(xp)
 rng = np.random.default_rng(0)
 e.load_params((0.01 * rng.standard_normal((M, 8))).astype(np.float32), rng.uniform(0.01, 0.99, (K, M)).astype(np.float32), init_encoder_weights(1, 8, 1024, [K]))
 idx = torch.randperm(20000)[:b].to(torch.int32).to(dev)
-for it in range(30):
-    e.forward(idx, b)
-    e.decode_all(idx, b, True, fused_adam=None)
-torch.cuda.synchronize()
-L = e.lay
-for chunk in (300, 1100, 1800):
-    base = chunk * b * L.kp[0]
-    for w in range(4):
-        t = e.dqpart[base + w * 8: base + w * 8 + 7].cpu().numpy().astype(np.int64)
-        print(f"chunk {chunk} wave {w}: issue {t[0]}  p-loop {t[1]}  barrier1-wait {t[2]}  dq-reduce+commit {t[3]}  barrier2-wait {t[4]}  | total in tiles {t[:5].sum()}  block lifetime to end of tiles {t[6]}")
+for fused in (None, (2e-3, 1.0)):
+    for it in range(10):
+        e.forward(idx, b)
+        e.step_count += 1
+        e.decode_all(idx, b, True, fused_adam=fused)
+    torch.cuda.synchronize()
+    L = e.lay
+    for chunk in (300, 1100, 1800):
+        base = chunk * b * L.kp[0]
+        t = e.dqpart[base: base + 3].cpu().numpy().astype(np.int64)
+        print(f"{'adam epilogue' if fused else 'dP write    '} chunk {chunk}: prologue {t[0]}  tile loop {t[1]}  epilogue {t[2]} cycles")
