@@ -1206,6 +1206,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     {
         constexpr int ROW4 = CP / 4;
         const int64_t m0 = chunk * EB_CHUNK_SNPS;
+        // (a loop of load-update-store trips: four HBM round trips per block at the end of a single-round kernel.  Issuing the
+        // loads of all trips first, or one trip ahead, makes the register allocator spill the main loop's accumulators to
+        // scratch at this kernel's 128-VGPR budget; as a non-inlined helper the call made the kernel 15x slower; in pass 2,
+        // whose blocks overlap each other's epilogues, batching the loads changed nothing.  Left as a plain loop.)
         for (int e = tid; e < EB_CHUNK_SNPS * ROW4; e += 256) {
             const int64_t m = m0 + e / ROW4;
             if (m < M) {
