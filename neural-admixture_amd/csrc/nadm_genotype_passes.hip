@@ -665,7 +665,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     __shared__ __attribute__((aligned(16))) uint8_t s_x[MF_TS * RS];
     __shared__ __attribute__((aligned(16))) uint4 s_qr[MF_TS / 16][2][64];   // B operands of R^T per 16-sample tile
     __shared__ __attribute__((aligned(16))) uint4 s_qd[MF_TS / 32][W ? 2 : 1][64];   // B operands of dP per 32-sample pair
-    __shared__ __attribute__((aligned(16))) float s_dq[MF_WAVES][MF_TS * KP];
+    __shared__ __attribute__((aligned(16))) float s_dq[MF_WAVES][W ? 1 : 2][MF_TS * KP];   // K <= 8: [hi part | mid part] of the P operand, added up below
     // row stride / plane size of the transposition buffer in bf16 units: 16 SNPs + 4 pad.  With dense 32-byte rows the 8-byte
     // writes of a half-wave fall on 4 banks groups (4-way conflicts, 56 % of the LDS-busy cycles in r01's counters); 40-byte
     // rows spread them.  -4 % on the kernel without the loss value (230 -> 221 us), nothing with it (VALU-bound); K > 8 keeps
@@ -932,23 +932,15 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                 }
                 if constexpr (LOSS)        // the "- 20" of the shifted logs: 2 * NTW * 4 genotypes per lane and tile pair, half of them per packed half
                     lossacc -= (f32x2_t){LOSS_LOG_SHIFT * NTW * 4, LOSS_LOG_SHIFT * NTW * 4};
-                // K <= 8: dQ^T rows k (hi part) and k+8 (mid part) sit 32 lanes apart: fold, lanes a<2 store.
-                // W: rows 4a + r ARE k, every lane group with 4a < KP stores its four.
+                // K <= 8: dQ^T rows k (from the hi piece of P, lanes a < 2) and k + 8 (from the mid piece, lanes a >= 2) are two
+                // partial sums of the same dQ element: both are parked in LDS and meet in the cross-wave sum below (a register fold
+                // with v_permlane32_swap cost 16 VALU instructions per tile pair).  W: rows 4a + r ARE k.
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    float o[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if constexpr (W) {
-                            o[r] = dq[s2][r];
-                        } else {                                       // v_permlane32_swap: both halves of the wave see lo and hi
-                            const uint32_t u = __float_as_uint(dq[s2][r]);
-                            const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-                            o[r] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-                        }
-                    }
-                    if ((W || a < 2) && 4 * a < KP)
-                        *reinterpret_cast<float4*>(&s_dq[wave][(16 * (2 * p + s2) + n) * KP + 4 * a]) = make_float4(o[0], o[1], o[2], o[3]);
+                    const int ah = W ? a : (a & 1), part = W ? 0 : (a >> 1);
+                    if (4 * ah < KP)
+                        *reinterpret_cast<float4*>(&s_dq[wave][part][(16 * (2 * p + s2) + n) * KP + 4 * ah]) =
+                            make_float4(dq[s2][0], dq[s2][1], dq[s2][2], dq[s2][3]);
                 }
             }
         }
@@ -956,10 +948,12 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
         for (int e4 = tid; e4 < nt * KP / 4; e4 += NTHR) {          // 16 B per lane: the tile's slab rows are contiguous
             float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int w = 0; w < MF_WAVES; ++w) {
-                const float4 v = *reinterpret_cast<const float4*>(&s_dq[w][4 * e4]);
-                sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
-            }
+            for (int w = 0; w < MF_WAVES; ++w)
+#pragma unroll
+                for (int part = 0; part < (W ? 1 : 2); ++part) {
+                    const float4 v = *reinterpret_cast<const float4*>(&s_dq[w][part][4 * e4]);
+                    sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+                }
             *reinterpret_cast<float4*>(dqpart + (chunk * b + i0) * KP + 4 * e4) = sm;
         }
         if (tl + 1 < ntiles) commit(i0 + MF_TS);
