@@ -158,6 +158,10 @@ def test_one_step_against_reference_fixture(name):
     (900, 1300, [4], 64, 8, 8),      # b > 832: two row-blocks in pass 1
     (70, 2600, [2, 3, 4, 5, 6, 7, 8, 9, 10], 64, 8, 9),   # c3-style multi-head, SP = 68
     (150, 5000, [13], 64, 8, 10),    # KP = 16 on the bf16 matrix-pipe kernel: several sample tiles, ragged last one
+    (12, 1200, [64], 32, 8, 11),     # K = 64: the widest head the ABI takes (NADM_MAX_K)
+    (9, 800, [5], 2048, 8, 12),      # Hd = 2048: eight hidden units per thread in the register-resident MLP kernels
+    (9, 800, [5], 2304, 8, 13),      # Hd > 2048: the generic MLP kernels
+    (6, 700_000, [3], 64, 8, 14),    # 2735 dQ slab rows: above the threshold where the slab is folded by dq_prereduce_kernel first
 ])
 def test_step_against_oracle_random_shapes(N, M, ks, Hd, C, seed):
     Gm = O.synth_genotypes(N, M, max(2, min(max(ks), 6)), seed=seed + 100, missing=0.05)
@@ -197,6 +201,28 @@ def test_step_against_oracle_random_shapes(N, M, ks, Hd, C, seed):
     for h, k in enumerate(ks):
         gp = big[L.p_off[h]: L.p_off[h] + L.M * L.kp[h]].reshape(L.M, L.kp[h])
         assert not gp[:, k:].any()
+
+
+def test_step_with_mostly_missing_genotypes_and_an_all_missing_sample():
+    """Missing calls are x = 0 in input AND target (neural_admixture.py:169-170): 60 % missing, one sample without a single
+    call, one SNP column missing everywhere -- loss and gradients against the oracle, nothing non-finite."""
+    N, M, ks, Hd = 37, 1900, [4], 64
+    Gm = O.synth_genotypes(N, M, 4, seed=77, missing=0.6)
+    Gm[5, :] = 3
+    Gm[:, 100:108] = 3
+    rng = np.random.default_rng(5)
+    p = O.make_params(5, (rng.standard_normal((M, 8)) / np.sqrt(M)).astype(np.float32), rng.uniform(0.02, 0.98, size=(4, M)).astype(np.float32), Hd, ks)
+    e = make_engine(Gm, p, N)
+    idx = torch.arange(N, dtype=torch.int32, device=e.device)
+    loss, grads, aux = O.step_grads(p, Gm)
+    e.forward(idx, N)
+    e.backward(idx, N, True)
+    torch.cuda.synchronize()
+    assert abs(e.read_loss()[1] - loss) / loss < 5e-6
+    g = engine_grads(e)
+    for k_, v in grads.items():
+        assert np.isfinite(g[k_]).all() and rel(g[k_], v) < 2e-5, k_
+    assert mx(e.Z.cpu().numpy()[: N * 8].reshape(N, 8)[5], 0 * aux["Z"][5]) == 0          # the all-missing sample projects to exactly 0
 
 
 def test_fast_and_generic_mlp_kernels_agree(monkeypatch):
