@@ -191,7 +191,9 @@ int nadm_small_grads(const float* small_part, int32_t splits, int32_t n_small, f
  * nadm_decode_chunks(M,kp_h)*b*kp_h floats), writes dZ [b,CP], the flat small-parameter gradient
  * grad_small [n_small] (NULL: left to nadm_mlp_bwd_weights), and when n_loss>0 adds the step's loss (sum of losspart[0..n_loss)) to
  * loss_acc[0] (running sum) and stores it in loss_acc[1] (last step); loss_acc is double[2].
- * Scratch: dL [b,SP], dHpre [b,Hd], dgp [b,CP], small_part [nadm_sample_splits(b), n_small]. */
+ * Scratch: dL [b,SP], dHpre [b,Hd], dgp [b,CP], small_part [nadm_sample_splits(b), n_small].  dqpart is scratch of the step as
+ * well: a slab of more than 2560 rows is folded to 64 rows IN PLACE first (its first 64 rows then hold partial sums); shorter
+ * slabs are left untouched. */
 int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const float* dqpart, int64_t M, int32_t b,
                  const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
                  float* dL, float* dHpre, float* dgp, float* small_part,
