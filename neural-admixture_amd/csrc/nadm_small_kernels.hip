@@ -479,17 +479,21 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
         }
     }
     __syncthreads();
-    // ---- softmax per (sample, head) ----
-    if (tid < ns * hd.n_heads) {
-        const int s = tid / hd.n_heads, hh = tid % hd.n_heads;
-        const int k = hd.k[hh], kp = hd.kp[hh], o = hd.qoff[hh];
-        float* lg = s_logit + s * SP + o;
+    // ---- softmax: one thread per (sample, column).  Every thread of a head walks the head's k logits itself -- maximum, then
+    // the exponentials in order -- so all of them arrive at the same sum bit for bit (as one thread per head did, with k
+    // dependent LDS round trips and k + kp stores in a row while 250 threads waited) ----
+    for (int e = tid; e < ns * SP; e += 256) {
+        const int s = e / SP, c = e % SP;
+        int hh = 0;
+        while (hh + 1 < hd.n_heads && c >= hd.qoff[hh + 1]) ++hh;
+        const int k = hd.k[hh], o = hd.qoff[hh], j = c - o;
+        const float* lg = s_logit + s * SP + o;
         float mx = -INFINITY;
-        for (int j = 0; j < k; ++j) mx = fmaxf(mx, lg[j]);
-        float sum = 0.f;
-        for (int j = 0; j < k; ++j) { const float e = expf(lg[j] - mx); lg[j] = e; sum += e; }
+        for (int jj = 0; jj < k; ++jj) mx = fmaxf(mx, lg[jj]);
+        float sum = 0.f, mine = 0.f;
+        for (int jj = 0; jj < k; ++jj) { const float ex = expf(lg[jj] - mx); sum += ex; if (jj == j) mine = ex; }
         const float inv = 1.0f / sum;
-        for (int j = 0; j < kp; ++j) Q[(int64_t)(i0 + s) * SP + o + j] = (j < k) ? lg[j] * inv : 0.f;
+        Q[(int64_t)(i0 + s) * SP + c] = (j < k) ? mine * inv : 0.f;
     }
 }
 
@@ -604,23 +608,24 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
             base += dq_chunks.full[hh] * b * kp;
         }
     }
-    // ---- softmax backward per (sample, head) ----
-    if (tid < SB * hd.n_heads) {
-        const int s = tid / hd.n_heads, hh = tid % hd.n_heads;
-        const int k = hd.k[hh], kp = hd.kp[hh], o = hd.qoff[hh];
-        float* dl = s_dl + s * SP + o;
-        if (s < ns) {
+    // ---- softmax backward: one thread per (sample, column); every thread of a head forms the head's dot product itself, in
+    // order (the same value in all of them) and writes its element to a third LDS image (no in-place update, one barrier) ----
+    float* const s_dlv = s_dl + 2 * SB * SP;                          // [SB][SP]: dL of the block's samples, read by the dH phase
+    for (int e = tid; e < SB * SP; e += 256) {
+        const int s = e / SP, c = e % SP;
+        int hh = 0;
+        while (hh + 1 < hd.n_heads && c >= hd.qoff[hh + 1]) ++hh;
+        const int k = hd.k[hh], o = hd.qoff[hh], j = c - o;
+        float v = 0.f;
+        if (s < ns && j < k) {
+            const float* dl = s_dl + s * SP + o;
             const float* q = s_q + s * SP + o;
             float dot = 0.f;
-            for (int j = 0; j < k; ++j) dot = fmaf(dl[j], q[j], dot);
-            for (int j = 0; j < kp; ++j) {
-                const float v = (j < k) ? q[j] * (dl[j] - dot) : 0.f;
-                dl[j] = v;
-                dL[(int64_t)(i0 + s) * SP + o + j] = v;
-            }
-        } else {
-            for (int j = 0; j < kp; ++j) dl[j] = 0.f;
+            for (int jj = 0; jj < k; ++jj) dot = fmaf(dl[jj], q[jj], dot);
+            v = q[j] * (dl[j] - dot);
         }
+        s_dlv[e] = v;
+        if (s < ns) dL[(int64_t)(i0 + s) * SP + c] = v;
     }
     __syncthreads();
     // ---- dH (relu-masked) in registers: head columns in passes of MLP_KT, accumulation order = head, column ----
@@ -649,7 +654,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
             for (int kk = 0; kk < MLP_KT; ++kk) {
                 float dls[SB];
 #pragma unroll
-                for (int s = 0; s < SB; ++s) dls[s] = (k0 + kk < K) ? s_dl[s * SP + o + k0 + kk] : 0.f;
+                for (int s = 0; s < SB; ++s) dls[s] = (k0 + kk < K) ? s_dlv[s * SP + o + k0 + kk] : 0.f;
 #pragma unroll
                 for (int j = 0; j < JH; ++j)
 #pragma unroll
@@ -1330,7 +1335,7 @@ extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const fl
     }
     if (hd->Hd <= 256 * MLP_JMAX && hd->C <= 8 && !getenv("NADM_MLP_GENERIC")) {
         const dim3 grid((b + MLP_SB - 1) / MLP_SB + (n_loss > 0 ? 1 : 0));          // + the loss block
-        const size_t lds = (size_t)2 * MLP_SB * hd->SP * 4;                      // s_dl + the block's Q rows
+        const size_t lds = (size_t)3 * MLP_SB * hd->SP * 4;                      // s_dl + the block's Q rows + dL
         const bool c8 = hd->C == 8 && ((reinterpret_cast<uintptr_t>(small) + 4 * (size_t)hd->w1_off) & 15) == 0;
 #define NADM_BWD_LAUNCH(JH, C8) hipLaunchKernelGGL((mlp_bwd_a_fast_kernel<MLP_SB, JH, C8>), grid, dim3(256), lds, st, *hd, small, dqpart, dqc, b, Z, rinv, H, Q, \
                                                    dL, dHpre, dgp, dZ, losspart, n_loss, loss_acc)
