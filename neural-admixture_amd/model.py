@@ -127,6 +127,61 @@ def epoch_order(generator: torch.Generator, n: int) -> torch.Tensor:
     return perm.to(torch.int32)
 
 
+class _EpochOrders:
+    """Sample orders of successive epochs on the device, one epoch ahead of the kernels.  Two things cost time at every epoch
+    boundary when the order is made with ``epoch_order(...).to(device)`` (measured at N = 100k, 43 ms of kernels per epoch):
+    the copy from pageable memory makes the host wait for every step queued before it, so the launch queue runs dry while
+    the next order is drawn (two ``randperm`` = 10 ms of host time); and the int64 -> int32 conversion of 100k elements on
+    the host is a parallel region of torch's intra-op pool -- its (here 128) threads spin at the region's barrier for
+    milliseconds and the HIP runtime's own threads stall behind them: +5 ms per epoch even when the result is not used.
+    Here epoch e+1's order is drawn as soon as epoch e's steps are queued (before the epoch's loss is read back), straight
+    into pinned memory (``randperm(out=...)`` is serial), and the copy and the narrowing to int32 are queued on the compute
+    stream behind those steps -- stream order is all the synchronisation the device buffers need (a copy on a side stream
+    with events in both directions measured 3-4 ms per epoch slower: the launch queue then drains in bursts).  The
+    generator is consumed in the same sequence as before, so the orders are the same.  Keep parallel CPU ops out of the
+    epoch loop."""
+    RING = 4                                             # pinned staging buffers; the host runs at most ~2.5 epochs ahead
+
+    def __init__(self, generator: torch.Generator, n: int, device: torch.device):
+        self.gen, self.n, self.dev = generator, n, device
+        self.on_gpu = device.type == "cuda"
+        if self.on_gpu:
+            self.pin = [torch.empty(n, dtype=torch.int64).pin_memory() for _ in range(self.RING)]
+            self.copied = [None] * self.RING             # event: pin[i] has been read by its copy
+            self.second = torch.empty(n, dtype=torch.int64)          # the sampler's second, unused draw
+            self.wide = torch.empty(n, dtype=torch.int64, device=device)
+            self.buf = [torch.empty(n, dtype=torch.int32, device=device) for _ in range(2)]
+        self.ready = None
+        self._after = None
+        self._draw(0)
+
+    def _draw(self, epoch: int) -> None:
+        if not self.on_gpu:
+            self.ready = epoch_order(self.gen, self.n).to(self.dev)
+            return
+        i = epoch % self.RING
+        if self.copied[i] is not None:
+            self.copied[i].synchronize()                 # RING epochs later: long since complete
+        torch.randperm(self.n, generator=self.gen, out=self.pin[i])          # same two draws as epoch_order()
+        torch.randperm(self.n, generator=self.gen, out=self.second)
+        self.wide.copy_(self.pin[i], non_blocking=True)
+        self.copied[i] = torch.cuda.Event()
+        self.copied[i].record()
+        self.buf[epoch & 1].copy_(self.wide)             # int64 -> int32 on the device
+        self.ready = self.buf[epoch & 1]
+
+    def take(self, epoch: int, prefetch: bool) -> torch.Tensor:
+        """Order of ``epoch`` (valid until the epoch after next is drawn)."""
+        self._after = (epoch, prefetch)
+        return self.ready
+
+    def epoch_queued(self) -> None:
+        """Call when every step of the epoch handed out last has been queued: draws the next order behind them."""
+        epoch, prefetch = self._after
+        if prefetch:
+            self._draw(epoch + 1)
+
+
 class NeuralAdmixture:
     """Trainer mirror (constructor signature of neural_admixture.py:248-249)."""
     engine_cls = Engine          # tests swap in an oracle-backed double to run the DDP orchestration on gloo
@@ -192,19 +247,22 @@ class NeuralAdmixture:
             log.info("")
         b = self.batch_size
         seq = torch.arange(n_local, dtype=torch.int32, device=dev)
+        orders = _EpochOrders(generator, N, dev) if world == 1 else None
         for epoch in range(self.epochs):
             logged = (epoch % log_every == 0)
             with_loss = logged or self.loss_mode == "always"
             if world > 1:
                 order = seq                                # rows are stored in shard order
             else:
-                order = epoch_order(generator, N).to(dev)
+                order = orders.take(epoch, prefetch=epoch + 1 < self.epochs)
             for s in range(0, n_local, b):
                 bb = min(b, n_local - s)
                 if world > 1:
                     eng.train_step_ddp(order[s:s + bb], bb, self.lr, world, with_loss, defer_tail=True)
                 else:
                     eng.train_step(order[s:s + bb], bb, self.lr, with_loss)
+            if orders is not None:
+                orders.epoch_queued()                      # next epoch's order: drawn and copied underneath this epoch's steps
             if with_loss:
                 loss_acc, _ = eng.read_loss(reset=True)
                 self.epoch_losses[epoch] = loss_acc

@@ -407,6 +407,21 @@ def test_epoch_order_is_the_random_sampler_sequence():
             assert torch.equal(g1.get_state(), g2.get_state())
 
 
+def test_prefetched_epoch_orders_are_the_same_sequence():
+    """model._EpochOrders (the trainer's one-epoch-ahead order buffer) hands out epoch_order()'s sequence and leaves the
+    generator where epoch_order() leaves it (host path; the device path is checked in test_gpu_parity)."""
+    from neural_admixture_amd.model import epoch_order, _EpochOrders
+    n, epochs = 700, 5
+    g1, g2 = torch.Generator().manual_seed(3), torch.Generator().manual_seed(3)
+    orders = _EpochOrders(g2, n, torch.device("cpu"))
+    for e in range(epochs):
+        want = epoch_order(g1, n)
+        got = orders.take(e, prefetch=e + 1 < epochs)
+        assert got.dtype == torch.int32 and torch.equal(got, want)
+        orders.epoch_queued()
+    assert torch.equal(g1.get_state(), g2.get_state())
+
+
 def test_vcf_reader_follows_the_reference_reader_conventions(tmp_path):
     """io.read_vcf (nadm_vcf_parse_gt) against a plain-Python statement of what the reference's reader computes
     (src/snp_reader.py:73-87,108-110: scikit-allel GT as int8 with -1 fills, summed over two alleles, negatives -> 3, then

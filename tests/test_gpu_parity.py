@@ -1158,3 +1158,29 @@ def test_cli_train_from_vcf_equals_the_boundary_call(tmp_path):
     V = RSVD(data, N, M, 8, 13)
     Ps, Qs, _ = na.train(3, 100, 2e-3, K, 13, data, dev, 1, 128, True, V, None, None, None, 8)
     assert np.array_equal(Q, Qs[0])
+
+
+@pytest.mark.gpu
+def test_prefetched_epoch_orders_on_the_device_are_the_sampler_sequence():
+    """model._EpochOrders on cuda: drawn into pinned memory one epoch ahead, copied on a side stream, narrowed on the device --
+    the orders the kernels read are epoch_order()'s (= RandomSampler's), buffers are not overwritten while an epoch that reads
+    them is still queued, and the generator ends in the same state."""
+    from neural_admixture_amd.model import epoch_order, _EpochOrders
+    dev = torch.device("cuda:0")
+    n, epochs = 100_000, 6
+    g1, g2 = torch.Generator().manual_seed(11), torch.Generator().manual_seed(11)
+    orders = _EpochOrders(g2, n, dev)
+    sums = []
+    busy = torch.zeros(1 << 22, device=dev)
+    for e in range(epochs):
+        got = orders.take(e, prefetch=e + 1 < epochs)
+        for _ in range(20):
+            busy.add_(1.0)                                    # stands in for the epoch's steps: keeps the stream behind the host
+        sums.append((got.to(torch.int64) * torch.arange(n, device=dev)).sum())     # reads the order late on the compute stream
+        orders.epoch_queued()
+    torch.cuda.synchronize()
+    for e in range(epochs):
+        want = epoch_order(g1, n).to(torch.int64)
+        assert int(sums[e].item()) == int((want * torch.arange(n)).sum().item()), e
+    assert torch.equal(g1.get_state(), g2.get_state())
+
