@@ -248,27 +248,31 @@ class NeuralAdmixture:
         b = self.batch_size
         seq = torch.arange(n_local, dtype=torch.int32, device=dev)
         orders = _EpochOrders(generator, N, dev) if world == 1 else None
-        for epoch in range(self.epochs):
-            logged = (epoch % log_every == 0)
-            with_loss = logged or self.loss_mode == "always"
-            if world > 1:
-                order = seq                                # rows are stored in shard order
-            else:
-                order = orders.take(epoch, prefetch=epoch + 1 < self.epochs)
-            for s in range(0, n_local, b):
-                bb = min(b, n_local - s)
+        host_threads = torch.get_num_threads()
+        torch.set_num_threads(1)                           # the loop is launches only: no parallel regions (see _EpochOrders)
+        try:
+            for epoch in range(self.epochs):
+                logged = (epoch % log_every == 0)
+                with_loss = logged or self.loss_mode == "always"
                 if world > 1:
-                    eng.train_step_ddp(order[s:s + bb], bb, self.lr, world, with_loss, defer_tail=True)
+                    order = seq                                # rows are stored in shard order
                 else:
-                    eng.train_step(order[s:s + bb], bb, self.lr, with_loss)
-            if orders is not None:
-                orders.epoch_queued()                      # next epoch's order: drawn and copied underneath this epoch's steps
-            if with_loss:
-                loss_acc, _ = eng.read_loss(reset=True)
-                self.epoch_losses[epoch] = loss_acc
-                if logged and self.master:
-                    log.info(f"            Loss in epoch {epoch:3d} on device {dev} is {loss_acc:,.0f}")
-
+                    order = orders.take(epoch, prefetch=epoch + 1 < self.epochs)
+                for s in range(0, n_local, b):
+                    bb = min(b, n_local - s)
+                    if world > 1:
+                        eng.train_step_ddp(order[s:s + bb], bb, self.lr, world, with_loss, defer_tail=True)
+                    else:
+                        eng.train_step(order[s:s + bb], bb, self.lr, with_loss)
+                if orders is not None:
+                    orders.epoch_queued()                      # next epoch's order: drawn and copied underneath this epoch's steps
+                if with_loss:
+                    loss_acc, _ = eng.read_loss(reset=True)
+                    self.epoch_losses[epoch] = loss_acc
+                    if logged and self.master:
+                        log.info(f"            Loss in epoch {epoch:3d} on device {dev} is {loss_acc:,.0f}")
+        finally:
+            torch.set_num_threads(host_threads)
         if world > 1:
             eng.finish_ddp()                               # the last step's deferred P piece
         # ---- final Q: sequential batches of <=1024, encoder only (:369-383) ----

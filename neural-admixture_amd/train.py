@@ -4,6 +4,7 @@ same returns ``(Ps, Qs, model)``.  The PCA-space GMM decoder init is the referen
 packing, the step loop and the final-Q pass run on the MI355X engine."""
 from __future__ import annotations
 
+import contextlib
 import logging
 import sys
 from typing import Optional
@@ -131,9 +132,48 @@ def supervised_init(data_np, pops, K: int):
     return y, P
 
 
+@contextlib.contextmanager
+def capped_host_threads(limit: int = 4):
+    """Caps torch's intra-op pool and the BLAS / OpenMP pools (threadpoolctl) at ``limit`` threads for the duration of the
+    block, never raising a pool that is smaller already.  The host side of a run is a launch loop plus a few small numpy /
+    scikit-learn calls; with the default pools of a large host (256 threads here, shared with other jobs) their barriers
+    spin long enough to stall the HIP runtime's own threads: a full default run on one MI355X takes 2.5 / 5.1 / 14.3-17 s
+    (2504 x 600k K=7 / K=2..10 / 100k x 500k K=8) with the default pools and 1.9 / 4.8 / 13.1 s with them capped, the
+    mixture fit alone 1.6 -> 1.0 s.  The reference's CLI caps them with --threads (entry.py:138-146); this makes the
+    boundary function behave the same when it is called directly."""
+    prev = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(prev, limit)))
+    limits = None
+    try:
+        from threadpoolctl import ThreadpoolController, threadpool_limits
+        per_api = {}
+        for lib_info in ThreadpoolController().info():
+            api, n = lib_info.get("user_api"), lib_info.get("num_threads")
+            if api and n:
+                per_api[api] = min(per_api.get(api, limit), n, limit)
+        limits = threadpool_limits(limits=per_api) if per_api else None
+    except ImportError:                          # threadpoolctl comes with scikit-learn; without it only torch's pool is capped
+        pass
+    try:
+        yield
+    finally:
+        if limits is not None:
+            limits.restore_original_limits()
+        torch.set_num_threads(prev)
+
+
 def train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int, data: torch.Tensor, device: torch.device,
           num_gpus: int, hidden_size: int, master: bool, V: np.ndarray, pops, min_k: int = None, max_k: int = None,
           n_components: int = None, *, parallelism: str = "dp"):
+    """The reference's boundary function (see the module docstring and _train); host thread pools capped while it runs."""
+    with capped_host_threads():
+        return _train(epochs, batch_size, learning_rate, K, seed, data, device, num_gpus, hidden_size, master, V, pops, min_k, max_k,
+                      n_components, parallelism=parallelism)
+
+
+def _train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int, data: torch.Tensor, device: torch.device,
+           num_gpus: int, hidden_size: int, master: bool, V: np.ndarray, pops, min_k: int = None, max_k: int = None,
+           n_components: int = None, *, parallelism: str = "dp"):
     """See module docstring.  ``data`` uint8 [N,M] CPU tensor (or an ``io.PackedGenotypes``, e.g. from
     ``io.read_bed_packed``); ``V`` numpy [C,M] (RSVD output,
     svd.py:83); returns Ps (list of [M,k] float32), Qs (list of [N,k] float32), model.
