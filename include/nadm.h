@@ -40,7 +40,7 @@ extern "C" {
 
 #define NADM_MAX_HEADS 32
 #define NADM_MAX_K 64
-#define NADM_ABI_VERSION 5   /* 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
+#define NADM_ABI_VERSION 6   /* 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
@@ -125,6 +125,14 @@ int nadm_pca_project_t(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_
 /* ---- a6-a8: RMSNorm + Linear/ReLU + per-head Linear + softmax (neural_admixture.py:173-176) */
 int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const float* zpart, int64_t n_chunks, int32_t b,
                  float* Z, float* rinv, float* Zn, float* H, float* Q, void* stream);
+/* The same, and Q additionally as the bf16 MFMA operand images pass 2 builds from it (heads with padded K <= 16): every block
+ * of nadm_decode_bce* otherwise splits the batch's Q into bf16 pieces itself, tile by tile (1954 blocks at M = 500k doing the
+ * same 800 x K conversion).  qimg: n_heads regions of qimg_head_bytes >= nadm_q_image_bytes(b) bytes, 16-byte aligned and
+ * ZERO-FILLED ONCE by the caller (slots that hold no piece are never written); head h's images start at h * qimg_head_bytes.
+ * Hand a head's region to nadm_decode_bce_images together with the same Q. */
+int64_t nadm_q_image_bytes(int32_t b);
+int nadm_mlp_fwd_images(const nadm_heads_t* hd, const float* small, const float* zpart, int64_t n_chunks, int32_t b,
+                        float* Z, float* rinv, float* Zn, float* H, float* Q, void* qimg, int64_t qimg_head_bytes, void* stream);
 
 /* ---- a9-a11: decoder Q.P^T -> clamp -> BCE(sum) forward + backward, one head -------------
  * (neural_admixture.py:94-97, :288/:431, autograd of both).  P,dP [M,kp]; Q = Qbase + qoff
@@ -171,6 +179,12 @@ int nadm_decode_bce_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int3
                          float* P, int32_t kp, const float* Q, int32_t SP,
                          float* dP, float* dqpart, float* losspart, int32_t with_loss,
                          uint8_t* xg, const nadm_adam_t* adam, void* stream);
+/* nadm_decode_bce_step (xg and adam may be NULL: then nadm_decode_bce / _gather) with this head's Q operand images from
+ * nadm_mlp_fwd_images (kp <= 16): the same bf16 pieces, the same results bit for bit. */
+int nadm_decode_bce_images(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                           float* P, int32_t kp, const float* Q, int32_t SP,
+                           float* dP, float* dqpart, float* losspart, int32_t with_loss,
+                           uint8_t* xg, const nadm_adam_t* adam, const void* qimg, void* stream);
 /* `weights` (may be NULL): the MLP weight-gradient partials -- the first half of nadm_mlp_bwd_weights, which like pass 3
  * depends only on the outputs of nadm_mlp_bwd(grad_small = NULL) -- are computed by extra blocks of the same launch (they
  * fill the under-occupied last round of pass 3) into small_part [nadm_sample_splits(b), n_small]; nadm_small_grads then

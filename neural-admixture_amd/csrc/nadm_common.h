@@ -75,6 +75,75 @@ __device__ __forceinline__ void adam_float4(float* __restrict__ p, const float4 
     *reinterpret_cast<float4*>(v) = make_float4(vv[0], vv[1], vv[2], vv[3]);
 }
 
+// ---- bf16 pieces of an fp32 value (round-to-nearest-even conversions, v_cvt_pk_bf16_f32) ----
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_bf16(float lo_half, float hi_half) {      // RNE, one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){lo_half, hi_half}, bf16x2_t));
+}
+// 3-way bf16 split of one fp32 value: 16-bit patterns of hi, mid, lo
+__device__ __forceinline__ void split3(float v, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = pk_bf16(v, 0.f) & 0xFFFFu;
+    const float r1 = v - __uint_as_float(h << 16);
+    m = pk_bf16(r1, 0.f) & 0xFFFFu;
+    const float r2 = r1 - __uint_as_float(m << 16);
+    l = pk_bf16(r2, 0.f) & 0xFFFFu;
+}
+
+// ---- Q as the MFMA operand images of the bf16 pass 2 (K <= 16), one image per head and 64-sample tile --------------------------
+// Every block of pass 2 (1954 of them at M = 500k) needs the batch's Q as bf16 pieces laid out as its MFMA operands; built
+// from the fp32 Q inside pass 2 that is two split3 and 16 two-byte LDS stores per thread and tile, 3.5 % of the kernel without
+// the loss value.  The MLP forward, which has each Q element in a register once per step, can write the images instead
+// (nadm_mlp_fwd_images); pass 2 then copies 10-12 KB per tile with 16-byte loads.  Layout of one tile image (uint4 units; a
+// uint4 = the 8 bf16 of one lane of one operand):
+//   [0, 512)            R^T operands  [sample tile st = 0..3][operand 0 / 1][lane]
+//   [512, 512 + 128 W2) dP operands   [sample pair 0..1][operand 0 .. W2-1][lane]          W2 = 1 for K <= 8, 2 for K 9..16
+// with the slot assignment of decode_bce_bf16_kernel (see there).  Slots that hold no piece are zero and are never written:
+// the buffer must be zero-filled once.  Rows b .. 64*ceil(b/64)-1 of the last tile are written as zeros by the producer.
+constexpr int QI_TS = 64;                                  // samples per tile (= NADM_BF_TS of the pass-2 build)
+constexpr int QI_TILE_U4 = 768;                            // uint4 per tile image in global memory (K <= 8 uses the first 640)
+__device__ __host__ constexpr int qi_tile_u4(int kp) { return kp > 8 ? 768 : 640; }
+// element (sample qr of the tile, column qk of the head) with value v -> its pieces in the tile image `img` (uint16 view)
+__device__ __forceinline__ void q_image_put(uint16_t* __restrict__ img, const int kp, const int qr, const int qk, const float v) {
+    uint32_t h, md, lo;
+    split3(v, h, md, lo);
+    const int st = qr >> 4, i = qr & 15;
+    const int pair = qr >> 5, within = qr & 31, q8 = within >> 3, e = within & 7;
+    if (kp > 8) {
+        const int sl = qk >> 3, kk = qk & 7;                                              // k slot and position inside it
+        uint16_t* r1 = img + ((st * 2 + 0) * 64) * 8 + kk;                               // + lane * 8
+        uint16_t* r2 = img + ((st * 2 + 1) * 64) * 8 + kk;
+        r1[(i + 16 * sl) * 8] = (uint16_t)h;   r1[(i + 16 * (2 + sl)) * 8] = (uint16_t)md;   // [Qh Qh' Qm Qm']
+        r2[(i + 16 * sl) * 8] = (uint16_t)lo;  r2[(i + 16 * (2 + sl)) * 8] = (uint16_t)h;    // [Ql Ql' Qh Qh']
+        uint16_t* d1 = img + (512 + (pair * 2 + 0) * 64) * 8 + e;
+        uint16_t* d2 = img + (512 + (pair * 2 + 1) * 64) * 8 + e;
+        d1[(q8 * 16 + qk) * 8] = (uint16_t)h;                                             // column qk of Qh / Qm
+        d2[(q8 * 16 + qk) * 8] = (uint16_t)md;
+    } else {
+        uint16_t* r1 = img + ((st * 2 + 0) * 64) * 8 + qk;
+        uint16_t* r2 = img + ((st * 2 + 1) * 64) * 8 + qk;
+        r1[(i) * 8] = (uint16_t)h;        r1[(i + 32) * 8] = (uint16_t)h;                 // slots 0,2: Qh
+        r1[(i + 16) * 8] = (uint16_t)md;  r1[(i + 48) * 8] = (uint16_t)md;                // slots 1,3: Qm
+        r2[(i) * 8] = (uint16_t)lo;       r2[(i + 16) * 8] = (uint16_t)h;                 // slots 0,1: Ql, Qh
+        uint16_t* d1 = img + (512 + pair * 64) * 8 + e;
+        d1[(q8 * 16 + qk) * 8] = (uint16_t)h;                                             // columns 0..7: Qh
+        d1[(q8 * 16 + qk + 8) * 8] = (uint16_t)md;                                        // columns 8..15: Qm
+    }
+}
+// one Q element of the batch (sample s, column j of head hh, value v) into the head's images.  The rows from b to the end of
+// the last tile must read as zeros (a shorter batch than the previous one leaves no stale rows): `first_of_block` threads (one
+// per block and column) clear rows b + blockIdx.x, b + blockIdx.x + gridDim.x, ... of their column -- spread over the blocks,
+// because one block clearing up to 63 rows with dependent two-byte stores made it the kernel's critical path (+4.6 us)
+__device__ __forceinline__ void q_image_store(uint4* __restrict__ qimg, const int64_t head_stride_u4, const int hh, const int kp,
+                                              const int s, const int j, const float v, const int b, const bool first_of_block) {
+    if (qimg == nullptr || kp > 16) return;
+    uint16_t* head = reinterpret_cast<uint16_t*>(qimg + hh * head_stride_u4);
+    q_image_put(head + (int64_t)(s / QI_TS) * QI_TILE_U4 * 8, kp, s % QI_TS, j, v);
+    if (first_of_block)
+        for (int r = b + (int)blockIdx.x; r < (b + QI_TS - 1) / QI_TS * QI_TS; r += (int)gridDim.x)
+            q_image_put(head + (int64_t)(r / QI_TS) * QI_TILE_U4 * 8, kp, r % QI_TS, j, 0.f);
+}
+
 // ---- MLP weight gradients, one block of the (hidden/256, sample splits) grid: see mlp_bwd_b_kernel (nadm_small_kernels.hip).
 // A device function so that pass 3 can run these blocks as extra blocks of its own launch (both depend only on the MLP
 // backward's outputs; the ~200 small blocks fill the under-occupied last round of pass 3 instead of a launch of their own).

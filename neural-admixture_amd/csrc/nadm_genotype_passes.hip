@@ -550,21 +550,8 @@ constexpr int mf_chunk_snps(int kp) { return mf_waves(kp) * 16 * mf_ntw(kp); }
 // The VALU only does the per-genotype BCE algebra and the bf16 split.  Work unit of a wave: 2 SNP tiles x
 // 2 sample tiles.  Everything else (tile staging, chunking, dQ partial slabs) is as in the f32 MFMA kernel.
 // =================================================================================================
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ uint32_t pk_bf16(float lo_half, float hi_half) {      // RNE, one v_cvt_pk_bf16_f32
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_t){lo_half, hi_half}, bf16x2_t));
-}
-// 3-way bf16 split of one fp32 value: 16-bit patterns of hi, mid, lo
-__device__ __forceinline__ void split3(float v, uint32_t& h, uint32_t& m, uint32_t& l) {
-    h = pk_bf16(v, 0.f) & 0xFFFFu;
-    const float r1 = v - __uint_as_float(h << 16);
-    m = pk_bf16(r1, 0.f) & 0xFFFFu;
-    const float r2 = r1 - __uint_as_float(m << 16);
-    l = pk_bf16(r2, 0.f) & 0xFFFFu;
-}
+// (pk_bf16 / split3: nadm_common.h, shared with the producer of the Q operand images)
 // the same for TWO values at once: one v_cvt_pk_bf16_f32 per piece serves both, and the three results are already the
 // packed (v0 | v1 << 16) dwords the MFMA operands are built from -- half the instructions of two split3 calls
 __device__ __forceinline__ void split3_pair(float v0, float v1, uint32_t& H, uint32_t& Md, uint32_t& Lo) {
@@ -643,11 +630,14 @@ constexpr int BF_WAVES = NADM_BF_WAVES;
 constexpr int BF_NTW = NADM_BF_NTW;     // 16-SNP tiles per wave
 constexpr int BF_TS = NADM_BF_TS;       // samples per LDS tile
 
-template <int KP, bool LOSS, bool UNIT_P = true>
+// QIMG: the Q operands come ready-made from `qimg` (this head's tile images written by the MLP forward, nadm_common.h) instead
+// of being split from the fp32 Q by every block: same bf16 pieces, same results.
+template <int KP, bool LOSS, bool UNIT_P = true, bool QIMG = false>
 __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(NADM_BF_WPE, NADM_BF_WPE))) void decode_bce_bf16_kernel(
     const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
     float* P, const float* __restrict__ Q, int SP,
-    float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart, uint8_t* __restrict__ xg, AdamFused ad) {
+    float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart, uint8_t* __restrict__ xg, AdamFused ad,
+    const uint4* __restrict__ qimg) {
     static_assert(KP <= 16, "one or two 8-wide k slots");
     // W (KP 9..16): k spans two 8-wide MFMA slots.  The pieces can no longer share an MFMA's 16 rows / columns, so
     //   R^T  = [Ph Ph' Ph Ph'].[Qh Qh' Qm Qm'] + [Pm Pm' Pm Pm'].[Qh Qh' Qm Qm'] + [Ph Ph' Pl Pl'].[Ql Ql' Qh Qh']   (X' = k 8..15)
@@ -663,8 +653,12 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     constexpr int PPR = RB / 16;
     constexpr int NTHR = 64 * MF_WAVES;
     __shared__ __attribute__((aligned(16))) uint8_t s_x[MF_TS * RS];
-    __shared__ __attribute__((aligned(16))) uint4 s_qr[MF_TS / 16][2][64];   // B operands of R^T per 16-sample tile
-    __shared__ __attribute__((aligned(16))) uint4 s_qd[MF_TS / 32][W ? 2 : 1][64];   // B operands of dP per 32-sample pair
+    // one contiguous image, laid out like a tile image of nadm_common.h: B operands of R^T per 16-sample tile, then of dP per 32-sample pair
+    constexpr int IMG_U4 = (MF_TS / 16) * 2 * 64 + (MF_TS / 32) * (W ? 2 : 1) * 64;
+    static_assert(!QIMG || (MF_TS == QI_TS && IMG_U4 == qi_tile_u4(KP)), "tile images of the MLP forward are 64 samples deep");
+    __shared__ __attribute__((aligned(16))) uint4 s_qimg[IMG_U4];
+    uint4 (*const s_qr)[2][64] = reinterpret_cast<uint4 (*)[2][64]>(&s_qimg[0]);
+    uint4 (*const s_qd)[W ? 2 : 1][64] = reinterpret_cast<uint4 (*)[W ? 2 : 1][64]>(&s_qimg[(MF_TS / 16) * 2 * 64]);
     __shared__ __attribute__((aligned(16))) float s_dq[MF_WAVES][W ? 1 : 2][MF_TS * KP];   // K <= 8: [hi part | mid part] of the P operand, added up below
     // row stride / plane size of the transposition buffer in bf16 units: 16 SNPs + 4 pad.  With dense 32-byte rows the 8-byte
     // writes of a half-wave fall on 4 banks groups (4-way conflicts, 56 % of the LDS-busy cycles in r01's counters); 40-byte
@@ -685,8 +679,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     auto snp_of = [&](int t, int ab, int r) -> int64_t { return snp_wave0 + 4 * NTW * ab + 4 * t + (((r & 1) << 1) | (r >> 1)); };
 
     // zero the operand slots that are never written (k-slots 2,3 of the second R MFMA; columns 8..15 of the second dP MFMA)
-    for (int e = tid; e < (MF_TS / 16) * 2 * 64; e += NTHR) (&s_qr[0][0][0])[e] = make_uint4(0, 0, 0, 0);
-    for (int e = tid; e < (MF_TS / 32) * (W ? 2 : 1) * 64; e += NTHR) (&s_qd[0][0][0])[e] = make_uint4(0, 0, 0, 0);
+    if constexpr (!QIMG)                     // (a ready-made image carries its zeros)
+        for (int e = tid; e < IMG_U4; e += NTHR) s_qimg[e] = make_uint4(0, 0, 0, 0);
 
     // ---- the block's P rows [chunk SNPs x KP] -> LDS, once, with full 16 B / lane lines (the transposition buffers are free until
     // the first tile); the operands below are built from that image.  Read element by element from global memory -- 48 dword
@@ -782,14 +776,25 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     auto row_index = [&](int i0) -> int32_t { const int smp = i0 + pr; return idx[smp < b ? smp : b - 1]; };
     int32_t row_pref = row_index(0);
     uint4 stage;
-    float qstage[QPT];
+    float qstage[QIMG ? 1 : QPT];
+    static_assert(!QIMG || (IMG_U4 > 2 * NTHR && IMG_U4 <= 3 * NTHR), "three image pieces per thread, the third partly");
+    uint4 qi0, qi1, qi2;                                    // (named scalars: an array indexed inside the two lambdas stays in scratch memory)
     const int qr0 = has_q ? tid / KW : 0, qk = tid % KW;   // this thread's Q elements: rows qr0 + j*NTHR/KW of the tile, column qk
     auto issue = [&](int i0) {
+        if constexpr (QIMG) {
+            const uint4* src = qimg + (int64_t)(i0 / MF_TS) * QI_TILE_U4;
+            qi0 = src[tid];
+            qi1 = src[tid + NTHR];
+            qi2 = src[tid + 2 * NTHR < IMG_U4 ? tid + 2 * NTHR : IMG_U4 - 1];
+            __builtin_amdgcn_sched_barrier(0);              // or the scheduler sinks the three loads to their use at the END of the tile
+                                                            // (shorter live ranges) and every tile waits for an L2 round trip: +13 %
+        } else {
 #pragma unroll
-        for (int j = 0; j < QPT; ++j) {
-            const int qr = qr0 + j * (MF_TS / QPT);
-            const int smp = i0 + qr < b ? i0 + qr : b - 1;
-            qstage[j] = Q[(int64_t)smp * SP + (qk < KP ? qk : 0)];
+            for (int j = 0; j < QPT; ++j) {
+                const int qr = qr0 + j * (MF_TS / QPT);
+                const int smp = i0 + qr < b ? i0 + qr : b - 1;
+                qstage[j] = Q[(int64_t)smp * SP + (qk < KP ? qk : 0)];
+            }
         }
         stage = *reinterpret_cast<const uint4*>(xp + (int64_t)row_pref * ld + poff_c);
         row_pref = row_index(i0 + MF_TS);
@@ -801,6 +806,12 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
         // reads 100 MB in one place instead of 800 rows scattered over the resident matrix, which at 12.5 GB costs it 13 %
         // misses in the per-CU translation cache (UTCL1) and 16 us; here the store is one instruction per tile and thread.
         if (xg != nullptr && has_piece && ok) *reinterpret_cast<uint4*>(xg + (int64_t)(i0 + pr) * ld + poff) = stage;
+        if constexpr (QIMG) {
+            s_qimg[tid] = qi0;
+            s_qimg[tid + NTHR] = qi1;
+            if (tid + 2 * NTHR < IMG_U4) s_qimg[tid + 2 * NTHR] = qi2;
+            return;
+        }
         if (!has_q) return;
 #pragma unroll
         for (int j = 0; j < QPT; ++j) {
@@ -1254,16 +1265,20 @@ static int launch_gather_rows(const uint8_t* xp, int64_t ld, const int32_t* idx,
 template <int KP>
 static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, float* P,
                               const float* Q, int SP, float* dP, float* dqpart, float* losspart, int with_loss,
-                              hipStream_t st, uint8_t* xg, AdamFused ad) {
+                              hipStream_t st, uint8_t* xg, AdamFused ad, const uint4* qimg) {
     static_assert(KP <= 16 && mf_chunk_snps(KP) == BF_WAVES * 16 * BF_NTW, "chunking published by nadm_decode_chunk_snps");
     const int64_t chunks = (M + mf_chunk_snps(KP) - 1) / mf_chunk_snps(KP);
     dim3 grid((unsigned)chunks), block(64 * BF_WAVES);
-    if (with_loss & 2)          // loss value with P possibly outside [0, 1] (before the first restrict_P)
-        hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, true, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad);
-    else if (with_loss)
-        hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad);
-    else
-        hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad);
+    constexpr bool CAN_IMG = BF_TS == QI_TS;                 // (variant builds with another tile depth: decode_bce_impl refuses qimg)
+#define NADM_P2_LAUNCH(...) hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, __VA_ARGS__>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad, qimg)
+    if (with_loss & 2) {        // loss value with P possibly outside [0, 1] (before the first restrict_P)
+        if (qimg) NADM_P2_LAUNCH(true, false, CAN_IMG); else NADM_P2_LAUNCH(true, false, false);
+    } else if (with_loss) {
+        if (qimg) NADM_P2_LAUNCH(true, true, CAN_IMG); else NADM_P2_LAUNCH(true, true, false);
+    } else {
+        if (qimg) NADM_P2_LAUNCH(false, true, CAN_IMG); else NADM_P2_LAUNCH(false, true, false);
+    }
+#undef NADM_P2_LAUNCH
     return check_launch("decode_bce_bf16");
 }
 
@@ -1382,8 +1397,10 @@ extern "C" int nadm_pca_project(const uint8_t* xp, int64_t ld, const int32_t* id
 
 static int decode_bce_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                            float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
-                           float* losspart, int32_t with_loss, void* stream, uint8_t* xg, AdamFused ad) {
+                           float* losspart, int32_t with_loss, void* stream, uint8_t* xg, AdamFused ad, const uint4* qimg = nullptr) {
     if (!xp || !idx || !P || !Q || !dP || !dqpart) return fail("nadm_decode_bce: null pointer");
+    if (qimg && (kp > 16 || NADM_BF_TS != nadm::QI_TS)) return fail("nadm_decode_bce_images: Q images exist for padded K <= 16 only");
+    if ((uintptr_t)qimg & 15) return fail("nadm_decode_bce_images: qimg must be 16-byte aligned");
     if (with_loss < 0 || with_loss > 3) return fail("nadm_decode_bce: with_loss is a bit set (1: loss value, 2: P may lie outside [0,1])");
     if (!(with_loss & 1)) with_loss = 0;
     if (with_loss && !losspart) return fail("nadm_decode_bce: with_loss needs losspart");
@@ -1392,10 +1409,10 @@ static int decode_bce_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
     hipStream_t st = (hipStream_t)stream;
     if (kp <= 16) {
         switch (kp) {
-            case 4: return launch_decode_mfma<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
-            case 8: return launch_decode_mfma<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
-            case 12: return launch_decode_mfma<12>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
-            case 16: return launch_decode_mfma<16>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
+            case 4: return launch_decode_mfma<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad, qimg);
+            case 8: return launch_decode_mfma<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad, qimg);
+            case 12: return launch_decode_mfma<12>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad, qimg);
+            case 16: return launch_decode_mfma<16>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad, qimg);
             default: return fail("nadm_decode_bce: unsupported padded K (use nadm_pad_k)");
         }
     }
@@ -1445,6 +1462,19 @@ extern "C" int nadm_decode_bce_step(const uint8_t* xp, int64_t ld, const int32_t
     if (adam_fused_args(adam, "nadm_decode_bce_step: Adam state is NULL", &ad)) return 1;
     if ((uintptr_t)P & 15) return fail("nadm_decode_bce_step: P must be 16-byte aligned");
     return decode_bce_impl(xp, ld, idx, b, M, P, kp, Q, SP, dP, dqpart, losspart, with_loss, stream, xg, ad);
+}
+
+extern "C" int64_t nadm_q_image_bytes(int32_t b) { return (int64_t)((b + nadm::QI_TS - 1) / nadm::QI_TS) * nadm::QI_TILE_U4 * 16; }
+
+extern "C" int nadm_decode_bce_images(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                                      float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
+                                      float* losspart, int32_t with_loss, uint8_t* xg, const nadm_adam_t* adam, const void* qimg,
+                                      void* stream) {
+    AdamFused ad;
+    if (adam_fused_args(adam, "nadm_decode_bce_images: Adam state is NULL", &ad)) return 1;
+    if (ad.m && ((uintptr_t)P & 15)) return fail("nadm_decode_bce_images: P must be 16-byte aligned");
+    if (!qimg) return fail("nadm_decode_bce_images: qimg is NULL (use nadm_decode_bce_step)");
+    return decode_bce_impl(xp, ld, idx, b, M, P, kp, Q, SP, dP, dqpart, losspart, with_loss, stream, xg, ad, static_cast<const uint4*>(qimg));
 }
 
 static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(nadm_heads_t hd, const flo
                                                       const float* __restrict__ zpart, int64_t n_chunks, int b,
                                                       float* __restrict__ Z, float* __restrict__ rinv,
                                                       float* __restrict__ Zn, float* __restrict__ H,
-                                                      float* __restrict__ Q) {
+                                                      float* __restrict__ Q, uint4* __restrict__ qimg, int64_t qimg_head_u4) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int C = hd.C, CP = hd.CP, Hd = hd.Hd, SP = hd.SP;
     float* s_grp = sm;                        // [256] float4
@@ -153,7 +153,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(nadm_heads_t hd, const flo
         float sum = 0.f;
         for (int j = 0; j < k; ++j) { const float e = expf(lg[j] - mx); lg[j] = e; sum += e; }
         const float inv = 1.0f / sum;
-        for (int j = 0; j < kp; ++j) Q[(int64_t)(i0 + s) * SP + o + j] = (j < k) ? lg[j] * inv : 0.f;
+        for (int j = 0; j < kp; ++j) {
+            const float qv = (j < k) ? lg[j] * inv : 0.f;
+            Q[(int64_t)(i0 + s) * SP + o + j] = qv;
+            q_image_store(qimg, qimg_head_u4, hh, kp, i0 + s, j, qv, b, s == 0);
+        }
     }
 }
 
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
                                                            const float* __restrict__ zpart, int64_t n_chunks, int b,
                                                            float* __restrict__ Z, float* __restrict__ rinv,
                                                            float* __restrict__ Zn, float* __restrict__ H,
-                                                           float* __restrict__ Q) {
+                                                           float* __restrict__ Q, uint4* __restrict__ qimg, int64_t qimg_head_u4) {
     __shared__ __attribute__((aligned(16))) float s_grp[1024];
     __shared__ float s_zn[SB * 8];
     __shared__ float s_red[4][SB * MLP_KT];
@@ -493,7 +497,9 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
         float sum = 0.f, mine = 0.f;
         for (int jj = 0; jj < k; ++jj) { const float ex = expf(lg[jj] - mx); sum += ex; if (jj == j) mine = ex; }
         const float inv = 1.0f / sum;
-        Q[(int64_t)(i0 + s) * SP + c] = (j < k) ? mine * inv : 0.f;
+        const float qv = (j < k) ? mine * inv : 0.f;
+        Q[(int64_t)(i0 + s) * SP + c] = qv;
+        q_image_store(qimg, qimg_head_u4, hh, hd.kp[hh], i0 + s, j, qv, b, s == 0);
     }
 }
 
@@ -1254,26 +1260,39 @@ extern "C" int nadm_unpack2bit(const uint8_t* in_dev, uint8_t* out_dev, int64_t 
     return check_launch("unpack2bit");
 }
 
-extern "C" int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const float* zpart, int64_t n_chunks, int32_t b,
-                            float* Z, float* rinv, float* Zn, float* H, float* Q, void* stream) {
+static int mlp_fwd_impl(const nadm_heads_t* hd, const float* small, const float* zpart, int64_t n_chunks, int32_t b,
+                        float* Z, float* rinv, float* Zn, float* H, float* Q, uint4* qimg, int64_t qimg_head_u4, void* stream) {
     if (!hd || !small || !zpart || !Z || !rinv || !Zn || !H || !Q) return fail("nadm_mlp_fwd: null pointer");
     if (b <= 0) return fail("nadm_mlp_fwd: empty batch");
     if (hd->Hd <= 256 * MLP_JMAX && hd->C <= 8 && !getenv("NADM_MLP_GENERIC")) {
         const dim3 grid((b + MLP_SB - 1) / MLP_SB);
         const size_t lds = (size_t)(MLP_SB + 1) * hd->SP * 4;                    // s_logit + the head biases
         const bool c8 = hd->C == 8 && ((reinterpret_cast<uintptr_t>(small) + 4 * (size_t)hd->w1_off) & 15) == 0;
-#define NADM_FWD_LAUNCH(JH, C8) hipLaunchKernelGGL((mlp_fwd_fast_kernel<MLP_SB, JH, C8>), grid, dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q)
+#define NADM_FWD_LAUNCH(JH, C8) hipLaunchKernelGGL((mlp_fwd_fast_kernel<MLP_SB, JH, C8>), grid, dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q, qimg, qimg_head_u4)
         if (hd->Hd <= 1024) { if (c8) NADM_FWD_LAUNCH(4, true); else NADM_FWD_LAUNCH(4, false); }
         else { if (c8) NADM_FWD_LAUNCH(8, true); else NADM_FWD_LAUNCH(8, false); }
 #undef NADM_FWD_LAUNCH
     } else if (hd->Hd <= 2048) {
         const size_t lds = (size_t)(1024 + MLP_SB * (hd->CP + hd->Hd + hd->SP)) * 4;
-        hipLaunchKernelGGL((mlp_fwd_kernel<MLP_SB>), dim3((b + MLP_SB - 1) / MLP_SB), dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q);
+        hipLaunchKernelGGL((mlp_fwd_kernel<MLP_SB>), dim3((b + MLP_SB - 1) / MLP_SB), dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q, qimg, qimg_head_u4);
     } else {
         const size_t lds = (size_t)(1024 + hd->CP + hd->Hd + hd->SP) * 4;
-        hipLaunchKernelGGL((mlp_fwd_kernel<1>), dim3(b), dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q);
+        hipLaunchKernelGGL((mlp_fwd_kernel<1>), dim3(b), dim3(256), lds, (hipStream_t)stream, *hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q, qimg, qimg_head_u4);
     }
     return check_launch("mlp_fwd");
+}
+
+extern "C" int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const float* zpart, int64_t n_chunks, int32_t b,
+                            float* Z, float* rinv, float* Zn, float* H, float* Q, void* stream) {
+    return mlp_fwd_impl(hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q, nullptr, 0, stream);
+}
+
+extern "C" int nadm_mlp_fwd_images(const nadm_heads_t* hd, const float* small, const float* zpart, int64_t n_chunks, int32_t b,
+                                   float* Z, float* rinv, float* Zn, float* H, float* Q, void* qimg, int64_t qimg_head_bytes, void* stream) {
+    if (!qimg) return fail("nadm_mlp_fwd_images: qimg is NULL (use nadm_mlp_fwd)");
+    if (((uintptr_t)qimg & 15) || (qimg_head_bytes & 15)) return fail("nadm_mlp_fwd_images: qimg and the head stride must be multiples of 16 bytes");
+    if (qimg_head_bytes < nadm_q_image_bytes(b)) return fail("nadm_mlp_fwd_images: head stride smaller than nadm_q_image_bytes(b)");
+    return mlp_fwd_impl(hd, small, zpart, n_chunks, b, Z, rinv, Zn, H, Q, static_cast<uint4*>(qimg), qimg_head_bytes / 16, stream);
 }
 
 extern "C" int nadm_mlp_bwd_weights(const nadm_heads_t* hd, int32_t b, const float* Zn, const float* H, const float* dL,

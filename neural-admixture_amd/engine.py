@@ -58,6 +58,12 @@ class Engine:
         self.labels: Optional[torch.Tensor] = None      # int32 [rows], supervised mode only
         self.n_classes, self.sup_weight = 0, 0.0
         self.small_part = z(int(lib.nadm_sample_splits(b)) * L.n_small)
+        # Q as the bf16 MFMA operand images of pass 2, written by the MLP forward (nadm_mlp_fwd_images; heads with padded K <= 16):
+        # zero-filled once, one region per head.  _qimg_b = batch size of the images that are valid for self.Q right now
+        self.q_images = any(kp <= 16 for kp in L.kp)          # False: every block of pass 2 splits Q itself (test hook)
+        self._qimg_head = int(lib.nadm_q_image_bytes(b))
+        self.qimg = torch.zeros(len(L.ks) * self._qimg_head, dtype=torch.uint8, device=device) if self.q_images else None
+        self._qimg_b = -1
         self.loss_acc = torch.zeros(2, dtype=torch.float64, device=device)
         self.xp: Optional[torch.Tensor] = None          # packed genotypes [rows, ld]
         self.step_count = 0
@@ -193,9 +199,14 @@ class Engine:
         """RMSNorm + MLP + per-head softmax from partial sums [n_chunks, b, CP] (default: this engine's zpart).  Fills Z,
         rinv, Zn, H, Q."""
         L, st = self.lay, _stream()
-        check(lib.nadm_mlp_fwd(C.byref(L.heads), ptr(self.small), ptr(self.zpart if z_src is None else z_src),
-                               L.enc_chunks if n_chunks is None else n_chunks, b, ptr(self.Z), ptr(self.rinv),
-                               ptr(self.Zn), ptr(self.H), ptr(self.Q), st), "mlp_fwd")
+        args = (C.byref(L.heads), ptr(self.small), ptr(self.zpart if z_src is None else z_src),
+                L.enc_chunks if n_chunks is None else n_chunks, b, ptr(self.Z), ptr(self.rinv), ptr(self.Zn), ptr(self.H), ptr(self.Q))
+        if self.q_images and self.qimg is not None:
+            check(lib.nadm_mlp_fwd_images(*args, ptr(self.qimg), self._qimg_head, st), "mlp_fwd_images")
+            self._qimg_b = b
+        else:
+            check(lib.nadm_mlp_fwd(*args, st), "mlp_fwd")
+            self._qimg_b = -1
 
     def forward(self, idx: torch.Tensor, b: int) -> None:
         """idx int32 [b] device row indices into xp.  Fills Z, rinv, Zn, H, Q."""
@@ -274,7 +285,10 @@ class Engine:
                         C.c_void_p(self.dqpart.data_ptr() + (dq_offs[h] + c0 * b * kp) * fsz),
                         C.c_void_p(self.losspart.data_ptr() + (loss_offs[h] + c0) * fsz), (1 if self.p_unit else 3) if with_loss else 0)
                 xg = C.c_void_p(self._xg_buf().data_ptr() + m0 // 4) if (h == 0 and self.gather_batch) else None
-                if fused_adam is not None:                    # single-GPU step: Adam + clamp on these P rows in the kernel's epilogue
+                if self.q_images and self._qimg_b == b and kp <= 16:      # Q operands ready-made by this step's MLP forward
+                    check(lib.nadm_decode_bce_images(*args, xg, C.byref(self._adam_args(L.p_off[h] + m0 * kp, fused_adam)) if fused_adam is not None else None,
+                                                     C.c_void_p(self.qimg.data_ptr() + h * self._qimg_head), st), "decode_bce_images")
+                elif fused_adam is not None:                  # single-GPU step: Adam + clamp on these P rows in the kernel's epilogue
                     check(lib.nadm_decode_bce_step(*args, xg, C.byref(self._adam_args(L.p_off[h] + m0 * kp, fused_adam)), st), "decode_bce_step")
                 elif xg is not None:                          # head 0's pass also leaves the batch's rows back to back in xg
                     check(lib.nadm_decode_bce_gather(*args, xg, st), "decode_bce_gather")

@@ -1184,3 +1184,35 @@ def test_prefetched_epoch_orders_on_the_device_are_the_sampler_sequence():
         assert int(sums[e].item()) == int((want * torch.arange(n)).sum().item()), e
     assert torch.equal(g1.get_state(), g2.get_state())
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ks", [[5], [3], [8], [13], [2, 3, 9], [20, 4]])
+def test_q_operand_images_from_the_mlp_forward_give_the_same_pass2(ks):
+    """nadm_mlp_fwd_images + nadm_decode_bce_images: the MLP forward writes Q as the bf16 operand images every pass-2 block
+    would otherwise build itself; gradients, dQ slabs and loss must be bit-identical to the path without images.  Batches of
+    100, then 37, then 70 rows through the same engine: a shorter batch must not see the longer one's rows in its last tile.
+    K = 20 has no image (fp32 kernel) and rides along with a K = 4 head that has one."""
+    dev = _dev()
+    N, M = 130, 2301
+    Gm = O.synth_genotypes(N, M, 4, seed=41)
+    rng = np.random.default_rng(12)
+    p = O.make_params(3, (rng.standard_normal((M, 8)) / 48).astype(np.float32), rng.uniform(0.02, 0.98, (sum(ks), M)).astype(np.float32), 64, ks)
+    e1, e2 = make_engine(Gm, p, 100), make_engine(Gm, p, 100)
+    assert e1.q_images and e1.qimg is not None
+    e2.q_images = False
+    for b in (100, 37, 70):
+        idx = torch.from_numpy(rng.permutation(N)[:b].astype(np.int32)).to(dev)
+        for e in (e1, e2):
+            e.forward(idx, b)
+            e.backward(idx, b, True)
+        torch.cuda.synchronize()
+        assert e1._qimg_b == b and e2._qimg_b == -1
+        assert torch.equal(e1.Q, e2.Q)
+        assert torch.equal(e1.gbig, e2.gbig), b
+        assert torch.equal(e1.gsmall, e2.gsmall), b
+        assert e1.read_loss() == e2.read_loss()
+        e1.train_step(idx, b, 2e-3, False)
+        e2.train_step(idx, b, 2e-3, False)
+    torch.cuda.synchronize()
+    assert torch.equal(e1.big, e2.big) and torch.equal(e1.small, e2.small)
+
