@@ -164,10 +164,11 @@ class _EpochOrders:
             self.copied[i].synchronize()                 # RING epochs later: long since complete
         torch.randperm(self.n, generator=self.gen, out=self.pin[i])          # same two draws as epoch_order()
         torch.randperm(self.n, generator=self.gen, out=self.second)
-        self.wide.copy_(self.pin[i], non_blocking=True)
-        self.copied[i] = torch.cuda.Event()
-        self.copied[i].record()
-        self.buf[epoch & 1].copy_(self.wide)             # int64 -> int32 on the device
+        with torch.cuda.device(self.dev):                # the event below is recorded on this device's current stream
+            self.wide.copy_(self.pin[i], non_blocking=True)
+            self.copied[i] = torch.cuda.Event()
+            self.copied[i].record()
+            self.buf[epoch & 1].copy_(self.wide)         # int64 -> int32 on the device
         self.ready = self.buf[epoch & 1]
 
     def take(self, epoch: int, prefetch: bool) -> torch.Tensor:
