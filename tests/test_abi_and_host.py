@@ -422,6 +422,29 @@ def test_prefetched_epoch_orders_are_the_same_sequence():
     assert torch.equal(g1.get_state(), g2.get_state())
 
 
+def test_capped_host_threads_only_lowers_and_restores():
+    """train.capped_host_threads: pools above the limit come down to it, pools below it are left alone (raising an OpenBLAS
+    pool that was started with one thread crashes it), and everything is back afterwards -- also when the block raises."""
+    from neural_admixture_amd.train import capped_host_threads
+    from threadpoolctl import threadpool_info, threadpool_limits
+    before_torch, before = torch.get_num_threads(), [(i["user_api"], i["num_threads"]) for i in threadpool_info()]
+    with capped_host_threads(2):
+        assert torch.get_num_threads() == min(before_torch, 2)
+        assert all(i["num_threads"] <= 2 for i in threadpool_info())
+    assert torch.get_num_threads() == before_torch and [(i["user_api"], i["num_threads"]) for i in threadpool_info()] == before
+    with threadpool_limits(limits=1):
+        torch.set_num_threads(1)
+        try:
+            with capped_host_threads(4):
+                assert torch.get_num_threads() == 1 and all(i["num_threads"] == 1 for i in threadpool_info())
+        finally:
+            torch.set_num_threads(before_torch)
+    with pytest.raises(ZeroDivisionError):
+        with capped_host_threads(2):
+            1 / 0
+    assert torch.get_num_threads() == before_torch and [(i["user_api"], i["num_threads"]) for i in threadpool_info()] == before
+
+
 def test_vcf_reader_follows_the_reference_reader_conventions(tmp_path):
     """io.read_vcf (nadm_vcf_parse_gt) against a plain-Python statement of what the reference's reader computes
     (src/snp_reader.py:73-87,108-110: scikit-allel GT as int8 with -1 fills, summed over two alleles, negatives -> 3, then
