@@ -528,6 +528,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef NADM_BF_TS
 #define NADM_BF_TS 64        // samples per LDS tile
 #endif
+#ifndef NADM_TW_SWZ
+#define NADM_TW_SWZ 1        // rotate the chunks of the dR transposition buffer's rows (conflict-free, see the kernel)
+#endif
 #ifndef NADM_BF_WPE
 #define NADM_BF_WPE 3        // waves per SIMD the register allocator must leave room for
 #endif
@@ -664,7 +667,11 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     // writes of a half-wave fall on 4 banks groups (4-way conflicts, 56 % of the LDS-busy cycles in r01's counters); 40-byte
     // rows spread them.  -4 % on the kernel without the loss value (230 -> 221 us), nothing with it (VALU-bound); K > 8 keeps
     // the dense rows, its 50 KB of LDS would not fit three blocks per CU with the pad
-    constexpr int TWS = W ? 16 : 20, TWP = 32 * TWS;
+    // NADM_TW_SWZ: dense 32-byte rows with the four 8-byte chunks of row r rotated by (r >> 2) & 3 -- the writes of a half-wave
+    // (16 rows x 2 chunks) then fall on every bank exactly twice (their minimum) AND the transposing reads (4 consecutive rows x
+    // 4 chunks per 16 lanes) on every bank once, which no padded row stride gives (reads want stride = 8 mod 32 dwords, writes 2 x odd)
+    constexpr bool SWZ = NADM_TW_SWZ != 0;
+    constexpr int TWS = SWZ ? 16 : (W ? 16 : 20), TWP = 32 * TWS;
     __shared__ __attribute__((aligned(16))) uint16_t s_t[MF_WAVES][2][2][TWP];  // per wave: [SNP tile of the pair][hi / lo][32 samples][16 SNPs (+ pad)]
     __shared__ float s_loss[MF_WAVES];
 
@@ -852,6 +859,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     __syncthreads();
 
     uint16_t* const tw = &s_t[wave][0][0][0];
+    const int wchunk = SWZ ? ((a + (n >> 2)) & 3) : a;      // where this lane's 8-byte chunk of row 16*s2 + n goes
     const int ntiles = (b + MF_TS - 1) / MF_TS;
     for (int tl = 0; tl < ntiles; ++tl) {
         const int i0 = tl * MF_TS;
@@ -906,8 +914,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                                 lo[t2][h2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rem, bf16x2_t));
                             }
                             // transposition buffer of this SNP tile: T[t2][hl][sample 16*s2 + n][SNP 4a .. 4a+3]  (row = 16 bf16 = 32 B)
-                            *reinterpret_cast<uint2*>(tw + (2 * t2 + 0) * TWP + (16 * s2 + n) * TWS + 4 * a) = make_uint2(hi[t2][0], hi[t2][1]);
-                            *reinterpret_cast<uint2*>(tw + (2 * t2 + 1) * TWP + (16 * s2 + n) * TWS + 4 * a) = make_uint2(lo[t2][0], lo[t2][1]);
+                            *reinterpret_cast<uint2*>(tw + (2 * t2 + 0) * TWP + (16 * s2 + n) * TWS + 4 * wchunk) = make_uint2(hi[t2][0], hi[t2][1]);
+                            *reinterpret_cast<uint2*>(tw + (2 * t2 + 1) * TWP + (16 * s2 + n) * TWS + 4 * wchunk) = make_uint2(lo[t2][0], lo[t2][1]);
                         }
                         // dQ^T of this sample tile: the lane's 8 dR values (2 tiles x 4 SNPs) are the B operand
                         const bf16x8 bh = as_bf16x8(make_uint4(hi[0][0], hi[0][1], hi[1][0], hi[1][1]));
@@ -924,12 +932,14 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                     for (int t2 = 0; t2 < 2; ++t2) {
                         // A operand: lane (row = SNP n, slot a = samples 8a..8a+7): two transposing reads of 4 samples each
                         typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_p;
-                        const int trow = 8 * a + (n >> 2), tcol = (n & 3) * 4;
+                        const int trow = 8 * a + (n >> 2);
+                        const int tcol = SWZ ? 4 * (((n & 3) + 2 * a) & 3) : (n & 3) * 4;           // rows trow: (trow >> 2) & 3 = 2a
+                        const int tcol4 = SWZ ? 4 * (((n & 3) + 2 * a + 1) & 3) : (n & 3) * 4;      // rows trow + 4: 2a + 1
                         const uint16_t* th = tw + (2 * t2 + 0) * TWP, *tlw = tw + (2 * t2 + 1) * TWP;
                         const s16x4_t h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(th + trow * TWS + tcol));
-                        const s16x4_t h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(th + (trow + 4) * TWS + tcol));
+                        const s16x4_t h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(th + (trow + 4) * TWS + tcol4));
                         const s16x4_t l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(tlw + trow * TWS + tcol));
-                        const s16x4_t l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(tlw + (trow + 4) * TWS + tcol));
+                        const s16x4_t l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(tlw + (trow + 4) * TWS + tcol4));
                         const bf16x8 ah = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                         const bf16x8 al = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
                         const int t = 2 * tp + t2;
