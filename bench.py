@@ -68,6 +68,7 @@ def parse():
                     help="functional check of the N>1 flow on a ONE-GPU box: all ranks use cuda:0 and gloo carries the tensors "
                          "(RCCL refuses two ranks per device); not a measurement")
     ap.add_argument("--head-streams", type=int, default=None, help="multi-head models: concurrent pass-2 launches (Engine.head_streams)")
+    ap.add_argument("--no-defer-small", action="store_true", help="A/B: the small-parameter update as a launch of its own after pass 3 (Engine.defer_small = False)")
     ap.add_argument("--no-q-images", action="store_true", help="A/B: every pass-2 block splits Q into bf16 operands itself (Engine.q_images = False)")
     ap.add_argument("--cpu-rows", type=int, default=2400, help="rows of the same workload used for the bounded CPU baseline")
     return ap.parse_args()
@@ -240,6 +241,8 @@ def main():
         eng.head_streams = args.head_streams
     if args.no_q_images:
         eng.q_images = False
+    if args.no_defer_small:
+        eng.defer_small = False
     eng.load_params(V0, P0, init_encoder_weights(42, 8, args.hidden, ks))
     del V0, P0
     perm = torch.randperm(rows_local, generator=gperm).to(torch.int32).to(dev)

@@ -155,20 +155,53 @@ __device__ __forceinline__ uint32_t fp4_bf16_pair(const uint32_t w, const int se
 
 __device__ __forceinline__ uint32_t bf16_trunc_bits(float v) { return __float_as_uint(v) & 0xFFFF0000u; }
 
+// The sum of the MLP weight-gradient partials of the PREVIOUS step + Adam on the small parameters (what nadm_small_grads does
+// as a launch of its own: 4.7 us + a launch gap at the end of every step) as side blocks of pass 1: pass 1 reads none of the
+// small parameters, the MLP forward behind it reads all of them.  part == nullptr: no side blocks.
+struct SmallSide {
+    const float* part;
+    float *out, *p, *m, *v;
+    int splits, n;
+    float step_size, bc2_sqrt, grad_scale;
+};
+
 template <int CP>
 __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
                                                               const int32_t* __restrict__ idx, int b, int64_t M,
                                                               const float* __restrict__ V, float* __restrict__ zpart, int tiles_per_block,
-                                                              uint32_t missing_bf16) {
+                                                              uint32_t missing_bf16, int n_chunks, int n_splits, SmallSide ss) {
     static_assert(CP <= 8, "two MFMA column groups hold hi|mid and lo|0");
+    // 1-D grid: block = chunk + n_chunks * batch split (the dispatch order a 2-D grid would have), side blocks LAST: they run in
+    // the slots the partly filled last round leaves empty instead of pushing main blocks of the first round back
+    const int n_main = n_chunks * n_splits;
+    if ((int)blockIdx.x >= n_main) {
+        const int e = ((int)blockIdx.x - n_main) * 512 + (int)threadIdx.x;
+        if (e >= ss.n) return;
+        float mq = 0.f, vq = 0.f, pq = 0.f;
+        if (ss.m != nullptr) { mq = ss.m[e]; vq = ss.v[e]; pq = ss.p[e]; }
+        float a = 0.f;                                       // the order of additions of sum_splits() (nadm_small_kernels.hip)
+        for (int j0 = 0; j0 < ss.splits; j0 += 32) {
+            float v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = ss.part[(int64_t)(j0 + u < ss.splits ? j0 + u : ss.splits - 1) * ss.n + e];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) if (j0 + u < ss.splits) a += v[u];
+        }
+        ss.out[e] = a;
+        if (ss.m != nullptr) {
+            ss.p[e] = adam_element(pq, a, mq, vq, ss.step_size, ss.bc2_sqrt, ss.grad_scale, false);
+            ss.m[e] = mq; ss.v[e] = vq;
+        }
+        return;
+    }
     static_assert(EM_D * 128 == 64 * EM_WAVES, "one output element per thread in the cross-wave combine");
     __shared__ __attribute__((aligned(16))) float s_z[2][EM_WAVES][EM_D][16 * 8];
     __shared__ float s_out[EM_TILES_PER_BLOCK][16 * 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int64_t chunk = blockIdx.x;
+    const int64_t chunk = (int)blockIdx.x % n_chunks;
     const int64_t slice0 = chunk * EM_CHUNK_SNPS + wave * EM_SLICE;
-    const int tile_begin = blockIdx.y * tiles_per_block;
+    const int tile_begin = ((int)blockIdx.x / n_chunks) * tiles_per_block;
     const int tile_end = min((b + 15) / 16, tile_begin + tiles_per_block);
     // A missing call (code 3) is 0 in the model (neural_admixture.py:170) and 1.5 = bf16 0x3FC0 in the init-time PCA
     // projection (train.py:52), selected by the caller.  FP4 (E2M1) reads the nibble 00cc as c/2 -- 0, 0.5, 1, 1.5 -- so
@@ -1341,7 +1374,8 @@ static int enc_rows_per_block(int b) {
 }
 
 static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                           const float* V, int32_t CP, float* zpart, void* stream, uint32_t missing_bf16) {
+                           const float* V, int32_t CP, float* zpart, void* stream, uint32_t missing_bf16,
+                           SmallSide ss = SmallSide{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f}) {
     if (!xp || !idx || !V || !zpart) return fail("nadm_encode_fwd: null pointer");
     if (b <= 0 || M <= 0) return fail("nadm_encode_fwd: empty batch or M");
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_encode_fwd: ld must be a multiple of 16 and >= ceil(M/4)");
@@ -1362,11 +1396,13 @@ static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
         int tpb = (int)((ntiles + gy - 1) / gy);
         if (tpb > EM_TILES_PER_BLOCK) tpb = EM_TILES_PER_BLOCK;
         gy = (ntiles + tpb - 1) / tpb;
-        dim3 g2((unsigned)chunks, (unsigned)gy), b2(512);
-        if (CP == 4) hipLaunchKernelGGL((encode_fwd_mfma_kernel<4>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16);
-        else hipLaunchKernelGGL((encode_fwd_mfma_kernel<8>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16);
+        const int side_blocks = ss.part ? (ss.n + 511) / 512 : 0;
+        dim3 g2((unsigned)(chunks * gy + side_blocks)), b2(512);
+        if (CP == 4) hipLaunchKernelGGL((encode_fwd_mfma_kernel<4>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16, (int)chunks, (int)gy, ss);
+        else hipLaunchKernelGGL((encode_fwd_mfma_kernel<8>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16, (int)chunks, (int)gy, ss);
         return check_launch("encode_fwd_mfma");
     }
+    if (ss.part) return fail("nadm_encode_fwd_small: only the matrix-core pass (CP <= 8) hosts the side blocks");
     const bool wide = use_mfma_encode();      // VALU fallback for CP > 8 keeps the 2048-SNP chunking
 #define ENC_LAUNCH(cp, tiles)                                                                                          \
     {                                                                                                                  \
@@ -1397,6 +1433,21 @@ static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
 extern "C" int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                                const float* V, int32_t CP, float* zpart, void* stream) {
     return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0u);
+}
+
+extern "C" int nadm_encode_fwd_small(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                                     const float* V, int32_t CP, float* zpart, const float* small_part, int32_t splits, int32_t n_small,
+                                     float* grad_small, float* small, const nadm_adam_t* adam, void* stream) {
+    if (!small_part || !grad_small) return fail("nadm_encode_fwd_small: null pointer");
+    if (splits <= 0 || n_small <= 0) return fail("nadm_encode_fwd_small: empty");
+    SmallSide ss{small_part, grad_small, small, nullptr, nullptr, splits, n_small, 0.f, 0.f, 0.f};
+    if (adam) {
+        if (!adam->m || !adam->v || !small) return fail("nadm_encode_fwd_small: Adam state / parameters are NULL");
+        if (adam->step < 1 || adam->when != 0) return fail("nadm_encode_fwd_small: Adam step is 1-based, when must be 0");
+        ss.m = adam->m; ss.v = adam->v; ss.grad_scale = adam->grad_scale;
+        adam_scalars(adam->lr, adam->step, &ss.step_size, &ss.bc2_sqrt);
+    }
+    return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0u, ss);
 }
 
 extern "C" int nadm_pca_project(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,

@@ -41,12 +41,17 @@ class Engine:
         z = lambda n, dt=_f32: torch.zeros(int(n), dtype=dt, device=device)
         # parameters, gradients, Adam moments
         self.big, self.mbig, self.vbig = z(L.n_big), z(L.n_big), z(L.n_big)
-        self.small, self.msmall, self.vsmall = z(L.n_small), z(L.n_small), z(L.n_small)
+        # The small parameters, their gradient and moments are PROPERTIES (below): the single-GPU step leaves the sum of the
+        # weight-gradient partials + Adam on them to side blocks of the NEXT step's pass 1 (nadm_encode_fwd_small), and any other
+        # access first applies a pending update as a launch of its own -- nobody ever sees them one step behind
+        self._pending_small = None                            # (splits, lr, grad_scale, step) of the update still owed
+        self.defer_small = True                               # False: nadm_small_grads right after pass 3 (test hook / A-B)
+        self._small, self._msmall, self._vsmall = z(L.n_small), z(L.n_small), z(L.n_small)
         # gradients live in ONE flat buffer [small | pad | V | P...] so that the data-parallel step needs two all-reduces:
         # the P part right after pass 2, and small + V together after pass 3
         self._ns_pad = (L.n_small + 63) // 64 * 64
         self.gflat = z(self._ns_pad + L.n_big)
-        self.gsmall, self.gbig = self.gflat[: L.n_small], self.gflat[self._ns_pad:]
+        self._gsmall, self.gbig = self.gflat[: L.n_small], self.gflat[self._ns_pad:]
         # activations / scratch
         b = self.bmax
         self.zpart = z(L.enc_chunks * b * L.CP)
@@ -185,6 +190,25 @@ class Engine:
         L = self.lay
         return self.gbig[L.p_off[h]: L.p_off[h] + L.M * L.kp[h]].view(L.M, L.kp[h])[:, : L.ks[h]]
 
+    def flush_small(self) -> None:
+        """Apply the small-parameter update the last single-GPU step left to the next pass 1 (no-op if none is owed)."""
+        if self._pending_small is None:
+            return
+        splits, lr, scale, step = self._pending_small
+        self._pending_small = None
+        sa = AdamArgs(self._msmall.data_ptr(), self._vsmall.data_ptr(), lr, step, scale, 0)
+        check(lib.nadm_small_grads(ptr(self.small_part), splits, self.lay.n_small, ptr(self._gsmall), ptr(self._small), C.byref(sa), _stream()),
+              "small_grads")
+
+    def _flushed(self, t):
+        self.flush_small()
+        return t
+
+    small = property(lambda self: self._flushed(self._small), lambda self, t: setattr(self, "_small", t))
+    msmall = property(lambda self: self._flushed(self._msmall), lambda self, t: setattr(self, "_msmall", t))
+    vsmall = property(lambda self: self._flushed(self._vsmall), lambda self, t: setattr(self, "_vsmall", t))
+    gsmall = property(lambda self: self._flushed(self._gsmall), lambda self, t: setattr(self, "_gsmall", t))
+
     # ------------------------------------------------------------------ kernels
     def encode_partial(self, idx: torch.Tensor, b: int) -> None:
         """Pass 1: per-chunk partial sums of Z = X.V for the batch rows idx (int32 [b], device) into zpart."""
@@ -192,7 +216,16 @@ class Engine:
         if b > self.bmax:
             raise RuntimeError("batch larger than the engine was sized for")
         ev = self._timed("encode_fwd")
-        check(lib.nadm_encode_fwd(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self.big), L.CP, ptr(self.zpart), st), "encode_fwd")
+        if self._pending_small is not None and L.CP <= 8:     # the previous step's small update rides in this launch
+            splits, lr, scale, step = self._pending_small
+            self._pending_small = None
+            sa = AdamArgs(self._msmall.data_ptr(), self._vsmall.data_ptr(), lr, step, scale, 0)
+            check(lib.nadm_encode_fwd_small(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self.big), L.CP, ptr(self.zpart),
+                                            ptr(self.small_part), splits, L.n_small, ptr(self._gsmall), ptr(self._small), C.byref(sa), st),
+                  "encode_fwd_small")
+        else:
+            self.flush_small()
+            check(lib.nadm_encode_fwd(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self.big), L.CP, ptr(self.zpart), st), "encode_fwd")
         if ev: ev[1].record()
 
     def mlp_forward(self, b: int, z_src: Optional[torch.Tensor] = None, n_chunks: Optional[int] = None) -> None:
@@ -317,6 +350,7 @@ class Engine:
         ``dq_M`` = 1 takes already reduced [b, kp_h] blocks).  n_loss > 0 adds that many loss slots to loss_acc.
         ``weights=False`` leaves the weight gradients to nadm_mlp_bwd_weights."""
         L, st = self.lay, _stream()
+        self.flush_small()                                    # small_part is scratch of this call (no-op after a pass 1)
         check(lib.nadm_mlp_bwd(C.byref(L.heads), ptr(self.small), ptr(self.dqpart if dq_src is None else dq_src),
                                L.M if dq_M is None else dq_M, b, ptr(self.Z), ptr(self.rinv), ptr(self.Zn),
                                ptr(self.H), ptr(self.Q), ptr(self.dL), ptr(self.dHpre), ptr(self.dgp), ptr(self.small_part),
@@ -348,7 +382,10 @@ class Engine:
                                                C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz),
                                                C.byref(self._adam_args(m0 * L.CP, fused_adam)) if fused_adam is not None else None,
                                                C.byref(side) if side is not None else None, st), "encode_bwd_step")
-                if side is not None:
+                if side is not None and fused_adam is not None and self.defer_small:
+                    # sum of the partials + Adam on the small parameters: owed to the next pass 1 (or to whoever looks first)
+                    self._pending_small = (int(lib.nadm_sample_splits(b)), fused_adam[0], fused_adam[1], self.step_count)
+                elif side is not None:
                     sa = None
                     if fused_adam is not None:
                         sa = C.byref(AdamArgs(self.msmall.data_ptr(), self.vsmall.data_ptr(), fused_adam[0], self.step_count, fused_adam[1]))

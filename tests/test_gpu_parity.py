@@ -1216,3 +1216,47 @@ def test_q_operand_images_from_the_mlp_forward_give_the_same_pass2(ks):
     torch.cuda.synchronize()
     assert torch.equal(e1.big, e2.big) and torch.equal(e1.small, e2.small)
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ks,Hd,M,b", [([8], 1024, 60_000, 800), ([5], 64, 2301, 37), ([2, 3, 4], 96, 2301, 37)])
+def test_small_parameter_update_riding_in_the_next_pass1_equals_the_immediate_one(ks, Hd, M, b):
+    """Engine.defer_small: the single-GPU step leaves the sum of the weight-gradient partials + Adam on the small parameters to
+    side blocks of the NEXT step's pass 1 (nadm_encode_fwd_small).  Parameters, moments, gradients and losses stay bit-identical
+    to the immediate nadm_small_grads launch; reading eng.small (or the moments / gradient) between two steps applies the owed
+    update first; an encoder-only call (infer_q), a non-fused backward and load_params in between are all served correctly."""
+    dev = _dev()
+    N = max(b + 20, 90)
+    Gm = O.synth_genotypes(N, M, 4, seed=78)
+    rng = np.random.default_rng(6)
+    p = O.make_params(3, (rng.standard_normal((M, 8)) / 48).astype(np.float32), rng.uniform(0.05, 0.95, (sum(ks), M)).astype(np.float32), Hd, ks)
+    e1, e2 = make_engine(Gm, p, b), make_engine(Gm, p, b)
+    assert e1.defer_small and e1.fused_adam
+    e2.defer_small = False
+    for s in range(12):
+        idx = torch.from_numpy(rng.permutation(N)[:b].astype(np.int32)).to(dev)
+        e1.train_step(idx, b, 2e-3, s % 3 == 0)
+        e2.train_step(idx, b, 2e-3, s % 3 == 0)
+        assert e1._pending_small is not None and e2._pending_small is None
+        if s == 4:                                            # a look in between: applies the update, the next pass 1 then has none to do
+            assert torch.equal(e1.small, e2.small) and e1._pending_small is None
+            assert torch.equal(e1.msmall, e2.msmall) and torch.equal(e1.gsmall, e2.gsmall)
+        if s == 7:                                            # encoder-only pass in between (final-Q style): consumes the update
+            q1, q2 = e1.infer_q(idx, b), e2.infer_q(idx, b)
+            assert e1._pending_small is None and all(torch.equal(a, c) for a, c in zip(q1, q2))
+        if s == 9:                                            # a plain forward / backward pair in between
+            for e in (e1, e2):
+                e.forward(idx, b)
+                e.backward(idx, b, True)
+            assert torch.equal(e1.gsmall, e2.gsmall) and torch.equal(e1.gbig, e2.gbig)
+            e1.read_loss(); e2.read_loss()
+    torch.cuda.synchronize()
+    assert e1.read_loss() == e2.read_loss()
+    assert torch.equal(e1.small, e2.small) and torch.equal(e1.msmall, e2.msmall) and torch.equal(e1.vsmall, e2.vsmall)
+    assert torch.equal(e1.big, e2.big) and torch.equal(e1.mbig, e2.mbig)
+    # load_params with an update still owed: the update must not leak into the new parameters
+    e1.train_step(idx, b, 2e-3, False)
+    assert e1._pending_small is not None
+    for e in (e1, e2):
+        e.load_params(p.V, np.concatenate([P.T for P in p.P], axis=0), small_vec(p))
+    assert e1._pending_small is None and torch.equal(e1.small, e2.small) and float(e1.msmall.abs().max()) == 0.0
+
