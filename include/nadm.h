@@ -40,7 +40,7 @@ extern "C" {
 
 #define NADM_MAX_HEADS 32
 #define NADM_MAX_K 64
-#define NADM_ABI_VERSION 6   /* 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
+#define NADM_ABI_VERSION 7   /* 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
@@ -206,19 +206,36 @@ int nadm_encode_fwd_small(const uint8_t* xp, int64_t ld, const int32_t* idx, int
                           const float* V, int32_t CP, float* zpart, const float* small_part, int32_t splits, int32_t n_small,
                           float* grad_small, float* small, const nadm_adam_t* adam, void* stream);
 
+/* Data-parallel step: nadm_encode_fwd of the NEXT step with the update of V owed by this one in its prologue -- the all-reduced
+ * gradient lies in dV (neural_admixture.py:315-319), adam_v->when must be 1 and ->step that step's count; every wave applies
+ * optimizer.step() (neural_admixture.py:187-204,411; no clamp: V is unconstrained, :179-185) to the V rows it is about to use, so
+ * the 7 x 4 x M x C bytes of optimizer traffic of V need no launch of their own and V is read once.  The launch then uses ONE
+ * batch split (a V row belongs to exactly one block; b <= 832, CP <= 8 -- otherwise the update runs as a kernel of its own in
+ * front).  small_part != NULL: the small-parameter side blocks of nadm_encode_fwd_small ride along (the data-parallel step hands
+ * the all-reduced flat gradient as ONE split: small_part = grad_small, splits = 1). */
+int nadm_encode_fwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                         float* V, int32_t CP, float* zpart, const float* dV, const nadm_adam_t* adam_v,
+                         const float* small_part, int32_t splits, int32_t n_small, float* grad_small, float* small,
+                         const nadm_adam_t* adam_small, void* stream);
+
 /* ---- a11: MLP backward (softmax, Linear, ReLU, RMSNorm) ---------------------------------- */
 /* Reduces dqpart (the heads' slabs laid back to back in head order, head h holding
  * nadm_decode_chunks(M,kp_h)*b*kp_h floats), writes dZ [b,CP], the flat small-parameter gradient
  * grad_small [n_small] (NULL: left to nadm_mlp_bwd_weights), and when n_loss>0 adds the step's loss (sum of losspart[0..n_loss)) to
  * loss_acc[0] (running sum) and stores it in loss_acc[1] (last step); loss_acc is double[2].
- * Scratch: dL [b,SP], dHpre [b,Hd], dgp [b,CP], small_part [nadm_sample_splits(b), n_small].  dqpart is scratch of the step as
- * well: a slab of more than 2560 rows is folded to 64 rows IN PLACE first (its first 64 rows then hold partial sums); shorter
- * slabs are left untouched. */
-int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const float* dqpart, int64_t M, int32_t b,
+ * Scratch: dL [b,SP], dHpre [b,Hd], dgp [b,CP], small_part [nadm_sample_splits(b), n_small].  dqpart is IN/OUT scratch of the
+ * step (hence not const): a slab of more than 2560 rows is folded to 64 rows IN PLACE first (its first 64 rows then hold
+ * partial sums, the others are unchanged); shorter slabs are left untouched.  Do not read dqpart after this call. */
+int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, float* dqpart, int64_t M, int32_t b,
                  const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
                  float* dL, float* dHpre, float* dgp, float* small_part,
                  float* dZ, float* grad_small,
                  const float* losspart, int64_t n_loss, double* loss_acc, void* stream);
+
+/* out[e] = sum over r < rows of src[r * n + e]  (fixed order; n a multiple of 4, 16-byte aligned pointers): the fold of a
+ * partial slab -- zpart [chunks, b*CP] of nadm_encode_fwd, a head's dqpart [chunks, b*kp] -- to one row.  The SNP-sharded step
+ * (8(f)-4) folds its rank-local partial sums with it before the two small all-reduces of a step. */
+int nadm_sum_rows(const float* src, int64_t rows, int64_t n, float* out, void* stream);
 
 /* ---- 8(f): supervised mode,  weight * CrossEntropyLoss(sum)(Q_0, labels)  (neural_admixture.py:293,470-473;
  * the reference feeds the softmax OUTPUT of head 0 to CrossEntropyLoss, i.e. a second softmax; default weight 100).

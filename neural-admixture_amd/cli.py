@@ -3,7 +3,8 @@ Reads BED input straight into the packed layout, runs the RSVD + GMM initialisat
 writes ``{name}.{K}.Q/.P``, ``{name}.pt`` and ``{name}_config.json`` exactly where the reference does
 (src/main.py:38-44, src/inference.py:91-92).  BED and VCF inputs are read natively (io.read_bed_packed, io.read_vcf_packed);
 PGEN needs pgenlib through the reference's own reader.  ``--num_gpus N`` spawns one process per GPU like the reference
-(entry.py:186-190); ``--threads`` is accepted for command-line compatibility and caps the host thread pools."""
+(entry.py:186-190); ``--threads`` sets the size of the host thread pools like the reference's (entry.py:138-146): torch's pool
+at once, the BLAS / OpenMP pools inside train() (host_threads=), the environment variables for child processes."""
 from __future__ import annotations
 
 import argparse
@@ -91,7 +92,8 @@ def _train_worker(rank, args, num_gpus, data, V, pops, t0):
     device = torch.device(f"cuda:{dev_id}")
     K = args.k
     Ps, Qs, model = train(args.epochs, args.batch_size, args.learning_rate, K, args.seed, data, device, num_gpus, args.hidden_size,
-                          master, V, pops, args.min_k, args.max_k, args.n_components, parallelism=args.parallelism)
+                          master, V, pops, args.min_k, args.max_k, args.n_components, parallelism=args.parallelism,
+                          host_threads=args.threads)
     if master:
         save_model(model, args.name, args.save_dir)
         write_outputs(Qs, args.name, K, args.min_k, args.max_k, args.save_dir, Ps)
@@ -126,7 +128,9 @@ def main(argv=None):
             raise ValueError("Please provide either --k or both --min_k and --max_k.")
         num_gpus = max(1, args.num_gpus if args.share_gpu else min(args.num_gpus, torch.cuda.device_count()))   # entry.py:168-173
         for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS", "NUMEXPR_NUM_THREADS"):       # entry.py:138-146
-            os.environ[var] = str(args.threads)
+            os.environ[var] = str(args.threads)              # for child processes (the concurrent GMM fits, spawned ranks) ...
+        torch.set_num_threads(max(1, args.threads))          # ... this process's pools are already up: torch here, BLAS / OpenMP
+                                                             # through train(host_threads=) (threadpoolctl)
         from .svd import RSVD
         data = _read(args.data_path, torch.device("cuda:0"), keep_on_device=(num_gpus == 1))   # 2-bit transpose on the GPU
         log.info("")

@@ -25,11 +25,10 @@ namespace nadm {
 // pass 1: Z partial = X[:, chunk] . V[chunk, :]        lane <-> sample, V rows wave-uniform
 // =================================================================================================
 constexpr int ENC_TB = 128;            // bytes of each gathered row per tile  (512 SNPs)
-constexpr int ENC_TILES_DEFAULT = 2;   // tiles per chunk -> 1024 SNPs per chunk (4 when paired with the MFMA chunking)
+constexpr int ENC_TILES = 4;           // tiles per chunk -> 2048 SNPs per chunk, the chunking of the matrix-core kernel (EM_CHUNK_SNPS)
 constexpr int ENC_LDW = ENC_TB / 4 + 1;  // LDS row stride in dwords (+1: lane r reads row r -> conflict-free)
-constexpr int ENC_CHUNK_SNPS = ENC_TB * 4 * ENC_TILES_DEFAULT;
 
-template <int CP, int ENC_TILES>
+template <int CP>
 __global__ void encode_fwd_kernel(const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx,
                                   int b, int64_t M, const float* __restrict__ V, float* __restrict__ zpart,
                                   int rows_per_block) {
@@ -168,8 +167,9 @@ struct SmallSide {
 template <int CP>
 __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
                                                               const int32_t* __restrict__ idx, int b, int64_t M,
-                                                              const float* __restrict__ V, float* __restrict__ zpart, int tiles_per_block,
-                                                              uint32_t missing_bf16, int n_chunks, int n_splits, SmallSide ss) {
+                                                              const float* V, float* __restrict__ zpart, int tiles_per_block,
+                                                              uint32_t missing_bf16, int n_chunks, int n_splits, SmallSide ss,
+                                                              float* Vrw, const float* __restrict__ dV, AdamFused adv) {
     static_assert(CP <= 8, "two MFMA column groups hold hi|mid and lo|0");
     // 1-D grid: block = chunk + n_chunks * batch split (the dispatch order a 2-D grid would have), side blocks LAST: they run in
     // the slots the partly filled last round leaves empty instead of pushing main blocks of the first round back
@@ -195,8 +195,13 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
         return;
     }
     static_assert(EM_D * 128 == 64 * EM_WAVES, "one output element per thread in the cross-wave combine");
-    __shared__ __attribute__((aligned(16))) float s_z[2][EM_WAVES][EM_D][16 * 8];
-    __shared__ float s_out[EM_TILES_PER_BLOCK][16 * 8];
+    // one LDS allocation, two lives: the prologue's image of the block's V rows (s_v), then the partial sums of the main loop
+    constexpr int SV_WAVE = EM_SLICE * 8 + (EM_SLICE / 64) * 8;        // floats per wave: [256 SNPs][8] + 8 floats of skew per 64 SNPs
+    constexpr int SZ_FLOATS = 2 * EM_WAVES * EM_D * 128, SOUT_FLOATS = EM_TILES_PER_BLOCK * 128;
+    constexpr int S_FLOATS = EM_WAVES * SV_WAVE > SZ_FLOATS + SOUT_FLOATS ? EM_WAVES * SV_WAVE : SZ_FLOATS + SOUT_FLOATS;
+    __shared__ __attribute__((aligned(16))) float s_raw[S_FLOATS];
+    float (*const s_z)[EM_WAVES][EM_D][16 * 8] = reinterpret_cast<float (*)[EM_WAVES][EM_D][16 * 8]>(&s_raw[0]);
+    float (*const s_out)[16 * 8] = reinterpret_cast<float (*)[16 * 8]>(&s_raw[SZ_FLOATS]);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int64_t chunk = (int)blockIdx.x % n_chunks;
@@ -209,8 +214,62 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
     const uint32_t kmiss = missing_bf16 == 0u ? 0x55555555u : 0u;
     // ---- B operands: V rows of this wave's slice, split hi/mid/lo, for the 8 k-steps ----
     // k-step s, lane (q, j): rows kk = 8q + e  <->  SNP slice0 + 64q + 8s + e ; column j: c = j & 7
+    // The wave's [256 x CP] slice of V goes through LDS: CP full 16 B / lane loads per lane (r02 read it element by element --
+    // 64 dword loads per thread whose lanes touch 4 different sectors each: 4.5 us of the kernel's 41, profiles/r03_ablations.txt).
+    // Row m of the slice sits at float offset 8 m + 8 (m >> 6): the skew makes the column reads below (lanes = 4 row groups x 8
+    // columns, rows 64 apart) hit 32 different banks.
     bf16x8 b1[8], b2[8];
     {
+        float* const sv = &s_raw[wave * SV_WAVE];
+        float4 vst[CP];
+        if (adv.m != nullptr) {
+            // Data-parallel step: the previous step's Adam update of V, from the all-reduced gradient lying in dV, applied to the
+            // wave's rows on their way in (like pass 2 does for P, AdamFused.pre).  The launch then has ONE batch split, so a V row
+            // belongs to exactly one wave: no launch of its own for 112 MB of optimizer traffic (adam2_kernel: 23 us), and V is
+            // read once.  Same element function as nadm_adam, no clamp (V is unconstrained, neural_admixture.py:179-185).
+#pragma unroll
+            for (int j0 = 0; j0 < CP; j0 += 4) {
+                float4 v4[4], g4[4], m4[4], s4[4];
+                int64_t off[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = 4 * (lane + 64 * (j0 + u));
+                    const int64_t m = slice0 + e / CP;
+                    off[u] = (m < M ? m : M - 1) * CP + e % CP;
+                    v4[u] = *reinterpret_cast<const float4*>(Vrw + off[u]);
+                    g4[u] = *reinterpret_cast<const float4*>(dV + off[u]);
+                    m4[u] = *reinterpret_cast<const float4*>(adv.m + off[u]);
+                    s4[u] = *reinterpret_cast<const float4*>(adv.v + off[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float pp[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w}, gg[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
+                    float mm[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w}, vv[4] = {s4[u].x, s4[u].y, s4[u].z, s4[u].w};
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) pp[q4] = adam_element(pp[q4], gg[q4], mm[q4], vv[q4], adv.step_size, adv.bc2_sqrt, adv.grad_scale, false);
+                    vst[j0 + u] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+                    const int e = 4 * (lane + 64 * (j0 + u));
+                    if (slice0 + e / CP < M) {                // (a clamped row would be updated twice)
+                        *reinterpret_cast<float4*>(Vrw + off[u]) = vst[j0 + u];
+                        *reinterpret_cast<float4*>(adv.m + off[u]) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+                        *reinterpret_cast<float4*>(adv.v + off[u]) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CP; ++j) {                    // unconditional, clamped; masked at the LDS store
+                const int e = 4 * (lane + 64 * j);
+                const int64_t m = slice0 + e / CP;
+                vst[j] = *reinterpret_cast<const float4*>(V + (m < M ? m : M - 1) * CP + e % CP);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CP; ++j) {
+            const int e = 4 * (lane + 64 * j), ml = e / CP;
+            *reinterpret_cast<float4*>(sv + 8 * ml + 8 * (ml >> 6) + e % CP) = (slice0 + ml < M) ? vst[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();                      // the slice is written and read by this wave only (LDS operations of a wave complete in order)
         const int c = i & 7;
         const bool upper = i >= 8;
 #pragma unroll
@@ -221,8 +280,8 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
                 uint32_t p1[2], p2[2];
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
-                    const int64_t m = slice0 + 64 * q + 8 * s8 + 4 * (d & 1) + 2 * hh + (d >> 1);   // element order of the A operand
-                    const float v = (m < M && c < CP) ? V[m * CP + c] : 0.f;
+                    const int ml = 64 * q + 8 * s8 + 4 * (d & 1) + 2 * hh + (d >> 1);                // element order of the A operand
+                    const float v = c < CP ? sv[8 * ml + 8 * q + c] : 0.f;                           // (rows past M hold zeros)
                     const uint32_t hi = bf16_trunc_bits(v);
                     const float r1 = v - __uint_as_float(hi);
                     const uint32_t mid = bf16_trunc_bits(r1);
@@ -606,49 +665,72 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast
 // Returns dR (gradient w.r.t. the pre-clamp reconstruction) and accumulates the BCE loss terms; x = genotype/2 with missing
 // already mapped to 0 (fp4_pair below).
 //   gradient   den = (1 - d) * d from the UNCLAMPED d: inside [0, 1] that is r(1 - r) bit for bit (r == d there), outside it
-//              is negative.  t = den * (-inf) is +inf exactly where d is out of range, -inf where den > 0 and NaN where
-//              den == 0; max3(den, 1e-12, t) ignores the NaN (IEEE maxNum), keeps the 1e-12 floor in range and becomes +inf
-//              out of range, so the reciprocal -- and with it the gradient -- is exactly 0 there (the reference's clamp_
-//              backward masks on the PRE-clamp value, bounds inclusive).  The numerator can then use d itself: no clamp
-//              instruction on the gradient path at all.
-//   loss       x*max(log r, -100) + (1-x)*max(log(1-r), -100) needs its two clamps only for r == 0 / r == 1 (log = -inf;
-//              an fp32 r is never in (0, e^-100)).  log2(v * 2^20 + 2^(20 - 100/ln2)) - 20 equals log2 v for every
-//              normal v (the addend is below half an ulp of v * 2^20) and -100/ln2 for v == 0: one packed fma per pair
-//              replaces two max, and since the weights x and 1-x add up to 1 the "- 20" is a constant per genotype that
+//              is negative.  inv = med3(rcp(den), 0, KMAX) with KMAX = rcp(1e-12) as v_rcp_f32 computes it: rcp is monotonic, so
+//              for den >= 1e-12 this is rcp(den), for 0 <= den < 1e-12 (rcp >= KMAX, +inf at 0) it is KMAX = rcp(max(den, 1e-12)),
+//              and for den < 0 -- d out of range -- rcp is negative and the median is exactly 0: the reference's clamp_ backward
+//              masks on the PRE-clamp value, bounds inclusive.  The numerator can then use d itself: no clamp instruction on the
+//              gradient path at all.  (r02 formed max3(den, 1e-12, den * -inf) in front of the reciprocal: one packed multiply
+//              more per pair, 10 us of the kernel.)
+//   loss       x*max(log r, -100) + (1-x)*max(log(1-r), -100), x in {0, .5, 1}.
+//     exact    (bce_loss_exact2; the steps before the first restrict_P and the fallback below) needs the two clamps only for
+//              r == 0 / r == 1 (log = -inf; an fp32 r is never in (0, e^-100)).  log2(v * 2^20 + 2^(20 - 100/ln2)) - 20 equals
+//              log2 v for every normal v (the addend is below half an ulp of v * 2^20) and -100/ln2 for v == 0: one packed fma
+//              per pair replaces two max, and since the weights x and 1-x add up to 1 the "- 20" is a constant per genotype that
 //              the caller subtracts once per tile pair.  r for the logs: d is never negative (P >= 0, Q >= 0 and the dropped
 //              split terms are 2^-24 relative); 1 - r needs the clamp from above only, and 2*max(v, 0) = v + |v| is one add
 //              of the fast class (the factor 2 goes into the scale) instead of a v_max.  log r itself may use d as long as
 //              P lies in [0, 1] (d <= 1 + a rounding error, log2 of that is < 2e-7): true from the first restrict_P on.
 //              UNIT_P = false clamps d from above for the step(s) before that -- the reference's supervised run starts
 //              from per-class means of the raw codes, which reach 2 (train.py:82).
-constexpr float LOSS_LOG_SHIFT = 20.f;                    // log2 of the scale
-template <bool LOSS, bool UNIT_P>
-__device__ __forceinline__ f32x2_t bce_elem2(const float d0, const float d1, const f32x2_t x, f32x2_t& lossacc) {
-    const f32x2_t d = {d0, d1};
-    const f32x2_t omd = (f32x2_t){1.f, 1.f} - d;
+//     fast     (r03, bce_loss_prod2; UNIT_P only) ONE logarithm per PAIR of genotypes instead of four.  With c = 2x in {0, 1, 2}
+//              twice the term of a genotype is c*log d + (2-c)*log(1-d) = log(u*v), (u, v) = (1-d, 1-d), (d, 1-d), (d, d): the
+//              factors are picked with two 0/1 selectors s1 = [c >= 1], s2 = [c == 2] (two more v_cvt_scalef32_pk_f32_fp4 of the
+//              same code word, masked), u = o + s1*(d - o), and the four factors of a pair are multiplied before the one v_log.
+//              Every factor is either 0 or >= 6e-8 for 1-d and arbitrary for d; the product of four underflows or is 0 exactly
+//              when a clamp of the reference could be active (a zero factor) or d is tiny (< ~1e-10) -- then, and only then, the
+//              logarithm is -inf and the wave recomputes the loss of that tile pair with the exact form (cold branch in the
+//              loop, decode_bce_bf16_kernel).  Same value up to the rounding of three multiplications per pair (relative 2e-7
+//              on a term; the loss tolerance is 5e-6 on the sum).
+constexpr float LOSS_LOG_SHIFT = 20.f;                    // log2 of the scale of the exact form
+__device__ __forceinline__ f32x2_t two_max0(const f32x2_t v) {                 // 2 * max(v, 0), exact.  As asm: the compiler would pair
+    f32x2_t r;                                                                 // the two adds into a v_pk_add_f32, which has no |abs|
+    asm("v_add_f32_e64 %0, %1, |%1|" : "=v"(r.x) : "v"(v.x));                  // modifier, behind two extra v_and
+    asm("v_add_f32_e64 %0, %1, |%1|" : "=v"(r.y) : "v"(v.y));
+    return r;
+}
+// gradient w.r.t. the pre-clamp reconstruction for two genotypes; omd = 1 - d is handed back for the loss
+__device__ __forceinline__ f32x2_t bce_grad2(const f32x2_t d, const f32x2_t x, const float kmax, f32x2_t& omd) {
+    omd = (f32x2_t){1.f, 1.f} - d;
     const f32x2_t den = omd * d;
-    const f32x2_t t = den * (f32x2_t){-__builtin_inff(), -__builtin_inff()};
-    const f32x2_t inv = {__builtin_amdgcn_rcpf(__builtin_fmaxf(__builtin_fmaxf(den.x, 1e-12f), t.x)),
-                         __builtin_amdgcn_rcpf(__builtin_fmaxf(__builtin_fmaxf(den.y, 1e-12f), t.y))};
-    const f32x2_t g = (d - x) * inv;
-    if constexpr (LOSS) {
-        constexpr float kScale = 1048576.f;                                    // 2^20
-        constexpr float kFloor = 3.900782386632024e-38f;                       // 2^20 * e^-100 (a normal number): log2 = 20 - 100/ln2
-        f32x2_t omr2;                                                          // 2 * max(1 - d, 0), exact.  As asm: the compiler would
-        asm("v_add_f32_e64 %0, %1, |%1|" : "=v"(omr2.x) : "v"(omd.x));        // pair the two adds into a v_pk_add_f32, which has no
-        asm("v_add_f32_e64 %0, %1, |%1|" : "=v"(omr2.y) : "v"(omd.y));        // |abs| modifier, behind two extra v_and
-        f32x2_t dl = d;
-        if constexpr (!UNIT_P) dl = (f32x2_t){__builtin_fminf(d.x, 1.f), __builtin_fminf(d.y, 1.f)};
-        const f32x2_t a1 = __builtin_elementwise_fma(dl, (f32x2_t){kScale, kScale}, (f32x2_t){kFloor, kFloor});
-        const f32x2_t a0 = __builtin_elementwise_fma(omr2, (f32x2_t){0.5f * kScale, 0.5f * kScale}, (f32x2_t){kFloor, kFloor});
-        const f32x2_t l1 = {__builtin_amdgcn_logf(a1.x), __builtin_amdgcn_logf(a1.y)};
-        const f32x2_t l0 = {__builtin_amdgcn_logf(a0.x), __builtin_amdgcn_logf(a0.y)};
-        lossacc = __builtin_elementwise_fma(x, l1, lossacc);
-        lossacc = __builtin_elementwise_fma((f32x2_t){1.f, 1.f} - x, l0, lossacc);
-        asm volatile("" : "+v"(lossacc));     // pin the accumulation here: otherwise LLVM sinks all the logs of a tile pair
-                                              // to the end of the loop body and keeps their 32 inputs alive (+60 VGPRs)
-    }
-    return g;
+    const f32x2_t inv = {__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(den.x), 0.f, kmax), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(den.y), 0.f, kmax)};
+    return (d - x) * inv;
+}
+// exact form: adds x*log2(r') + (1-x)*log2((1-r)') + 20 per genotype to lossacc (packed halves)
+template <bool UNIT_P>
+__device__ __forceinline__ void bce_loss_exact2(const f32x2_t d, const f32x2_t omd, const f32x2_t x, f32x2_t& lossacc) {
+    constexpr float kScale = 1048576.f;                                    // 2^20
+    constexpr float kFloor = 3.900782386632024e-38f;                       // 2^20 * e^-100 (a normal number): log2 = 20 - 100/ln2
+    const f32x2_t omr2 = two_max0(omd);
+    f32x2_t dl = d;
+    if constexpr (!UNIT_P) dl = (f32x2_t){__builtin_fminf(d.x, 1.f), __builtin_fminf(d.y, 1.f)};
+    const f32x2_t a1 = __builtin_elementwise_fma(dl, (f32x2_t){kScale, kScale}, (f32x2_t){kFloor, kFloor});
+    const f32x2_t a0 = __builtin_elementwise_fma(omr2, (f32x2_t){0.5f * kScale, 0.5f * kScale}, (f32x2_t){kFloor, kFloor});
+    const f32x2_t l1 = {__builtin_amdgcn_logf(a1.x), __builtin_amdgcn_logf(a1.y)};
+    const f32x2_t l0 = {__builtin_amdgcn_logf(a0.x), __builtin_amdgcn_logf(a0.y)};
+    lossacc = __builtin_elementwise_fma(x, l1, lossacc);
+    lossacc = __builtin_elementwise_fma((f32x2_t){1.f, 1.f} - x, l0, lossacc);
+    asm volatile("" : "+v"(lossacc));     // pin the accumulation here: otherwise LLVM sinks all the logs of a tile pair
+                                          // to the end of the loop body and keeps their 32 inputs alive (+60 VGPRs)
+}
+// fast form: adds log2(16 * u0 v0 u1 v1) = 2 * (the two genotypes' terms in log2 units) + 4 to acc; -inf (or NaN) flags the pair
+__device__ __forceinline__ void bce_loss_prod2(const f32x2_t d, const f32x2_t omd, const f32x2_t s1, const f32x2_t s2, float& acc) {
+    const f32x2_t o2 = two_max0(omd);                                           // 2 * (1 - r)
+    const f32x2_t e2 = __builtin_elementwise_fma(d, (f32x2_t){2.f, 2.f}, -o2);  // 2 * (d - (1 - r))
+    const f32x2_t u = __builtin_elementwise_fma(s1, e2, o2);                    // 2d if c >= 1 else 2(1-r)
+    const f32x2_t v = __builtin_elementwise_fma(s2, e2, o2);                    // 2d if c == 2 else 2(1-r)
+    const f32x2_t tt = u * v;
+    acc += __builtin_amdgcn_logf(tt.x * tt.y);
+    asm volatile("" : "+v"(acc));
 }
 
 // Two genotypes -> two floats in ONE instruction: a nibble 00cc read as FP4 (E2M1) is exactly cc/2 (0, .5, 1), so
@@ -891,6 +973,34 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 
+    float kmax_v = 1e-12f;                                 // 1 / 1e-12 as v_rcp_f32 computes it (opaque to the constant folder)
+    asm volatile("v_rcp_f32 %0, %0" : "+v"(kmax_v));
+    const float kmax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, kmax_v)));
+#ifndef NADM_FAST_LOSS_MAXKP
+#define NADM_FAST_LOSS_MAXKP 8      // K 9..16 (7 MFMAs per tile, at the 168-VGPR ceiling): 769 us with the fast form against 694 without (K = 16, M = 1M)
+#endif
+    constexpr bool FAST_LOSS = LOSS && UNIT_P && KP <= NADM_FAST_LOSS_MAXKP;   // one logarithm per pair of genotypes, exact form as the cold fallback
+    // the lane's codes of one 16-sample tile: nibble = one 2-bit code, codes 0,2 / 1,3 of each byte (byte t = 4 SNPs of tile t)
+    auto load_codes = [&](int st, uint32_t& ev, uint32_t& od) {
+        uint32_t w;
+        if constexpr (NTW == 4) w = *reinterpret_cast<const uint32_t*>(&s_x[(16 * st + n) * RS + wave * 16 + 4 * a]);
+        else w = *reinterpret_cast<const uint16_t*>(&s_x[(16 * st + n) * RS + wave * 8 + 2 * a]);
+        w &= ~((w & (w >> 1) & 0x55555555u) * 3u);         // missing (3) -> 0
+        ev = w & 0x33333333u;
+        od = (w >> 2) & 0x33333333u;
+    };
+    // R^T tile t (16 SNPs x 16 samples) from the resident P operands and one sample tile's Q operands
+    auto recon = [&](int t, const uint4& q1, const uint4& q2) -> f32x4 {
+        f32x4 D = (f32x4){0.f, 0.f, 0.f, 0.f};
+        D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r1[t]), as_bf16x8(q1), D, 0, 0, 0);
+        if constexpr (W) {
+            D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r2[t]), as_bf16x8(q1), D, 0, 0, 0);
+            D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r3[t]), as_bf16x8(q2), D, 0, 0, 0);
+        } else {
+            D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r2[t]), as_bf16x8(q2), D, 0, 0, 0);
+        }
+        return D;
+    };
     uint16_t* const tw = &s_t[wave][0][0][0];
     const int wchunk = SWZ ? ((a + (n >> 2)) & 3) : a;      // where this lane's 8-byte chunk of row 16*s2 + n goes
     const int ntiles = (b + MF_TS - 1) / MF_TS;
@@ -902,20 +1012,16 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
 #pragma unroll 1
         for (int p = 0; p < MF_TS / 32; ++p) {
             if (i0 + 32 * p < b) {                                     // block-uniform
-                uint32_t even[2], odd[2];                              // nibble = one 2-bit code: codes 0,2 / 1,3 of each byte
+                uint32_t even[2], odd[2];
                 uint4 qb1[2], qb2[2];
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const int st = 2 * p + s2;
-                    uint32_t w;                                         // the lane's NTW bytes: byte t = 4 SNPs of tile t
-                    if constexpr (NTW == 4) w = *reinterpret_cast<const uint32_t*>(&s_x[(16 * st + n) * RS + wave * 16 + 4 * a]);
-                    else w = *reinterpret_cast<const uint16_t*>(&s_x[(16 * st + n) * RS + wave * 8 + 2 * a]);
-                    w &= ~((w & (w >> 1) & 0x55555555u) * 3u);         // missing (3) -> 0
-                    even[s2] = w & 0x33333333u;
-                    odd[s2] = (w >> 2) & 0x33333333u;
+                    load_codes(st, even[s2], odd[s2]);
                     qb1[s2] = s_qr[st][0][lane];
                     qb2[s2] = s_qr[st][1][lane];
                 }
+                float it_acc = 0.f;                                    // fast loss of this tile pair: sum of log2(16 * product of 4 factors)
                 const uint4 qd1 = s_qd[p][0][lane];
                 uint4 qd2 = make_uint4(0, 0, 0, 0);
                 if constexpr (W) qd2 = s_qd[p][1][lane];
@@ -930,17 +1036,17 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
 #pragma unroll
                         for (int t2 = 0; t2 < 2; ++t2) {
                             const int t = 2 * tp + t2;
-                            f32x4 D = (f32x4){0.f, 0.f, 0.f, 0.f};
-                            D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r1[t]), as_bf16x8(qb1[s2]), D, 0, 0, 0);
-                            if constexpr (W) {
-                                D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r2[t]), as_bf16x8(qb1[s2]), D, 0, 0, 0);
-                                D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r3[t]), as_bf16x8(qb2[s2]), D, 0, 0, 0);
-                            } else {
-                                D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r2[t]), as_bf16x8(qb2[s2]), D, 0, 0, 0);
-                            }
+                            const f32x4 D = recon(t, qb1[s2], qb2[s2]);
 #pragma unroll
                             for (int h2 = 0; h2 < 2; ++h2) {
-                                const f32x2_t dR = bce_elem2<LOSS, UNIT_P>(D[2 * h2], D[2 * h2 + 1], fp4_pair(h2 ? odd[s2] : even[s2], t), lossacc);
+                                const uint32_t cw = h2 ? odd[s2] : even[s2];
+                                const f32x2_t d = {D[2 * h2], D[2 * h2 + 1]}, x = fp4_pair(cw, t);
+                                f32x2_t omd;
+                                const f32x2_t dR = bce_grad2(d, x, kmax, omd);
+                                if constexpr (FAST_LOSS)      // selectors [c >= 1], [c == 2]: a nibble 0010 is 1.0 in FP4
+                                    bce_loss_prod2(d, omd, fp4_pair((cw | (cw << 1)) & 0x22222222u, t), fp4_pair(cw & 0x22222222u, t), it_acc);
+                                else if constexpr (LOSS)
+                                    bce_loss_exact2<UNIT_P>(d, omd, x, lossacc);
                                 const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector(dR, bf16x2_t));
                                 hi[t2][h2] = hp;
                                 const f32x2_t rem = dR - (f32x2_t){__uint_as_float(hp << 16), __uint_as_float(hp & 0xFFFF0000u)};
@@ -984,8 +1090,34 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                         }
                     }
                 }
-                if constexpr (LOSS)        // the "- 20" of the shifted logs: 2 * NTW * 4 genotypes per lane and tile pair, half of them per packed half
+                if constexpr (FAST_LOSS) {
+                    // it_acc = sum over the lane's 4 * NTW pairs of 2 * (their terms in log2 units) + 4.  -inf (a zero or underflowed
+                    // product: a clamp of the reference may be active) or NaN anywhere in the wave: recompute the tile pair's
+                    // loss in the exact form -- R^T again from the operands still in LDS / registers, loss algebra only
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(__builtin_fabsf(it_acc) < __builtin_inff())) != 0, 0)) {
+                        f32x2_t ex = {0.f, 0.f};
+#pragma unroll 1
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const int st = 2 * p + s2;
+                            uint32_t ev, od;
+                            load_codes(st, ev, od);
+                            const uint4 q1 = s_qr[st][0][lane], q2 = s_qr[st][1][lane];
+#pragma unroll
+                            for (int t = 0; t < NTW; ++t) {
+                                const f32x4 D = recon(t, q1, q2);
+#pragma unroll
+                                for (int h2 = 0; h2 < 2; ++h2) {
+                                    const f32x2_t d = {D[2 * h2], D[2 * h2 + 1]};
+                                    bce_loss_exact2<true>(d, (f32x2_t){1.f, 1.f} - d, fp4_pair(h2 ? od : ev, t), ex);
+                                }
+                            }
+                        }
+                        it_acc = 2.f * ((ex.x + ex.y) - LOSS_LOG_SHIFT * NTW * 8) + 4.f * NTW * 4;
+                    }
+                    lossacc.x += 0.5f * (it_acc - 4.f * NTW * 4);     // "+ 4" per pair: the factor 16 = 2^4 in every product
+                } else if constexpr (LOSS) {   // the "- 20" of the shifted logs: 2 * NTW * 4 genotypes per lane and tile pair, half of them per packed half
                     lossacc -= (f32x2_t){LOSS_LOG_SHIFT * NTW * 4, LOSS_LOG_SHIFT * NTW * 4};
+                }
                 // K <= 8: dQ^T rows k (from the hi piece of P, lanes a < 2) and k + 8 (from the mid piece, lanes a >= 2) are two
                 // partial sums of the same dQ element: both are parked in LDS and meet in the cross-wave sum below (a register fold
                 // with v_permlane32_swap cost 16 VALU instructions per tile pair).  W: rows 4a + r ARE k.
@@ -1281,7 +1413,7 @@ __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ p, 
         ad.m[e] = mq; ad.v[e] = vq;
     }
 }
-static int launch_adam_range(float* p, const float* g, AdamFused ad, int64_t n, hipStream_t st, int clamp01 = 1) {
+static int launch_adam_range(float* p, const float* g, AdamFused ad, int64_t n, hipStream_t st, int clamp01) {
     int64_t gx = (n + 255) / 256;
     if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(adam_range_kernel, dim3((unsigned)gx), dim3(256), 0, st, p, g, ad, n, clamp01);
@@ -1330,7 +1462,7 @@ static int launch_decode(const uint8_t* xp, int64_t ld, const int32_t* idx, int 
                          const float* Q, int SP, float* dP, float* dqpart, float* losspart, int with_loss,
                          hipStream_t st, uint8_t* xg, AdamFused ad) {
     constexpr int SPL = dec_spl(KP);
-    if (ad.m && ad.pre && launch_adam_range(P, dP, ad, M * KP, st)) return 1;      // no prologue in this kernel: update first
+    if (ad.m && ad.pre && launch_adam_range(P, dP, ad, M * KP, st, 1)) return 1;   // no prologue in this kernel: update first
     const int64_t chunks = (M + 256 * SPL - 1) / (256 * SPL);
     dim3 grid((unsigned)chunks), block(256);
     if (with_loss)
@@ -1339,22 +1471,17 @@ static int launch_decode(const uint8_t* xp, int64_t ld, const int32_t* idx, int 
         hipLaunchKernelGGL((decode_bce_kernel<KP, SPL, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
     if (check_launch("decode_bce")) return 1;
     if (xg && launch_gather_rows(xp, ld, idx, b, M, xg, st)) return 1;
-    return (ad.m && !ad.pre) ? launch_adam_range(P, dP, ad, M * KP, st) : 0;
+    return (ad.m && !ad.pre) ? launch_adam_range(P, dP, ad, M * KP, st, 1) : 0;
 }
 
 }  // namespace nadm
 
 using namespace nadm;
 
-// the matrix-core kernels of passes 1 and 3 cover CP <= 8; wider encoders (n_components > 8) run the VALU kernels
-static bool use_mfma_encode() { return true; }
-
-// NOTE: the chunk count must not depend on CP (callers size zpart before they pass CP); the MFMA kernel
-// covers CP <= 8 and the VALU kernel writes the same 2048-SNP chunks when it is the fallback.
-extern "C" int64_t nadm_encode_chunks(int64_t M) {
-    if (use_mfma_encode()) return (M + EM_CHUNK_SNPS - 1) / EM_CHUNK_SNPS;
-    return (M + ENC_CHUNK_SNPS - 1) / ENC_CHUNK_SNPS;
-}
+// The matrix-core kernels of passes 1 and 3 cover CP <= 8; wider encoders (n_components > 8) run the VALU kernels.
+// The chunk count must not depend on CP (callers size zpart before they pass CP): both pass-1 kernels write 2048-SNP chunks.
+static_assert(ENC_TB * 4 * ENC_TILES == EM_CHUNK_SNPS, "one chunking for both pass-1 kernels");
+extern "C" int64_t nadm_encode_chunks(int64_t M) { return (M + EM_CHUNK_SNPS - 1) / EM_CHUNK_SNPS; }
 
 extern "C" int32_t nadm_decode_chunk_snps(int kp) {
     if (kp <= 16) return mf_chunk_snps(kp);
@@ -1375,7 +1502,8 @@ static int enc_rows_per_block(int b) {
 
 static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                            const float* V, int32_t CP, float* zpart, void* stream, uint32_t missing_bf16,
-                           SmallSide ss = SmallSide{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f}) {
+                           SmallSide ss = SmallSide{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f},
+                           float* Vrw = nullptr, const float* dV = nullptr, AdamFused adv = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0}) {
     if (!xp || !idx || !V || !zpart) return fail("nadm_encode_fwd: null pointer");
     if (b <= 0 || M <= 0) return fail("nadm_encode_fwd: empty batch or M");
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_encode_fwd: ld must be a multiple of 16 and >= ceil(M/4)");
@@ -1383,7 +1511,7 @@ static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
     dim3 grid((unsigned)nadm_encode_chunks(M), (unsigned)((b + rpb - 1) / rpb)), block(rpb);
     const size_t lds = (size_t)rpb * ENC_LDW * 4;
     hipStream_t st = (hipStream_t)stream;
-    if (CP <= 8 && use_mfma_encode()) {
+    if (CP <= 8) {
         // Every block first splits its 2048 x CP slice of V into bf16 operands (about as much work as 12 sample tiles), so
         // a block should see many tiles; but ~2 blocks per CU are needed to fill the chip.  grid.y = as few batch splits as
         // give >= 480 blocks (never fewer than 4 tiles per block, at most EM_TILES_PER_BLOCK).  At M = 500k, b = 800:
@@ -1393,21 +1521,26 @@ static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
         int64_t gy = (480 + chunks - 1) / chunks;
         if (gy > (ntiles + 3) / 4) gy = (ntiles + 3) / 4;
         if (gy < 1) gy = 1;
+        if (adv.m && ntiles <= EM_TILES_PER_BLOCK) gy = 1;                    // prologue update of V: every row in exactly one block
+        else if (adv.m) {                                                     // batch too tall for one split: the update as a launch of its own
+            if (launch_adam_range(Vrw, dV, adv, M * CP, st, 0)) return 1;
+            adv.m = nullptr;
+        }
         int tpb = (int)((ntiles + gy - 1) / gy);
         if (tpb > EM_TILES_PER_BLOCK) tpb = EM_TILES_PER_BLOCK;
         gy = (ntiles + tpb - 1) / tpb;
         const int side_blocks = ss.part ? (ss.n + 511) / 512 : 0;
         dim3 g2((unsigned)(chunks * gy + side_blocks)), b2(512);
-        if (CP == 4) hipLaunchKernelGGL((encode_fwd_mfma_kernel<4>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16, (int)chunks, (int)gy, ss);
-        else hipLaunchKernelGGL((encode_fwd_mfma_kernel<8>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16, (int)chunks, (int)gy, ss);
+        if (CP == 4) hipLaunchKernelGGL((encode_fwd_mfma_kernel<4>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16, (int)chunks, (int)gy, ss, Vrw, dV, adv);
+        else hipLaunchKernelGGL((encode_fwd_mfma_kernel<8>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16, (int)chunks, (int)gy, ss, Vrw, dV, adv);
         return check_launch("encode_fwd_mfma");
     }
     if (ss.part) return fail("nadm_encode_fwd_small: only the matrix-core pass (CP <= 8) hosts the side blocks");
-    const bool wide = use_mfma_encode();      // VALU fallback for CP > 8 keeps the 2048-SNP chunking
-#define ENC_LAUNCH(cp, tiles)                                                                                          \
+    if (adv.m && launch_adam_range(Vrw, dV, adv, M * CP, st, 0)) return 1;   // VALU pass 1: the update as a launch of its own
+#define ENC_LAUNCH(cp)                                                                                                 \
     {                                                                                                                  \
         if (lds > 48 * 1024) {                                                                                         \
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_fwd_kernel<cp, tiles>),     \
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&encode_fwd_kernel<cp>),            \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
             if (e != hipSuccess) {                                                                                     \
                 snprintf(err_buf(), 512, "nadm_encode_fwd: cannot raise dynamic LDS limit to %zu: %s", lds,            \
@@ -1415,19 +1548,32 @@ static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
                 return 1;                                                                                              \
             }                                                                                                          \
         }                                                                                                              \
-        hipLaunchKernelGGL((encode_fwd_kernel<cp, tiles>), grid, block, lds, st, xp, ld, idx, b, M, V, zpart, rpb);    \
+        hipLaunchKernelGGL((encode_fwd_kernel<cp>), grid, block, lds, st, xp, ld, idx, b, M, V, zpart, rpb);           \
     }
 #define ENC_CASE(cp)                                                                                                   \
     case cp:                                                                                                           \
-        if (wide) ENC_LAUNCH(cp, 4) else ENC_LAUNCH(cp, ENC_TILES_DEFAULT)                                             \
+        ENC_LAUNCH(cp)                                                                                                 \
         break;
     switch (CP) {
-        ENC_CASE(4) ENC_CASE(8) ENC_CASE(12) ENC_CASE(16) ENC_CASE(24) ENC_CASE(32)
+        ENC_CASE(12) ENC_CASE(16) ENC_CASE(24) ENC_CASE(32)          // (CP 4, 8: the matrix-core kernel above)
         default: return fail("nadm_encode_fwd: unsupported CP (4,8,12,16,24,32)");
     }
 #undef ENC_LAUNCH
 #undef ENC_CASE
     return check_launch("encode_fwd");
+}
+
+static int adam_fused_args(const nadm_adam_t* adam, const char* who, AdamFused* out) {
+    *out = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0};
+    if (!adam) return 0;
+    if (!adam->m || !adam->v) return fail(who);
+    if (adam->step < 1) return fail("nadm_*_step: Adam step is 1-based");
+    if (((uintptr_t)adam->m | (uintptr_t)adam->v) & 15) return fail("nadm_*_step: Adam state must be 16-byte aligned");
+    out->m = adam->m; out->v = adam->v; out->grad_scale = adam->grad_scale;
+    out->pre = adam->when == 1 ? 1 : 0;
+    if (adam->when != 0 && adam->when != 1) return fail("nadm_*_step: nadm_adam_t.when is 0 (epilogue) or 1 (prologue, pass 2 only)");
+    adam_scalars(adam->lr, adam->step, &out->step_size, &out->bc2_sqrt);
+    return 0;
 }
 
 extern "C" int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
@@ -1450,9 +1596,32 @@ extern "C" int nadm_encode_fwd_small(const uint8_t* xp, int64_t ld, const int32_
     return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0u, ss);
 }
 
+extern "C" int nadm_encode_fwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                                    float* V, int32_t CP, float* zpart, const float* dV, const nadm_adam_t* adam_v,
+                                    const float* small_part, int32_t splits, int32_t n_small, float* grad_small, float* small,
+                                    const nadm_adam_t* adam_small, void* stream) {
+    if (!adam_v || !dV || !V) return fail("nadm_encode_fwd_step: V, dV and the Adam state of V are required (use nadm_encode_fwd / _small otherwise)");
+    AdamFused adv;
+    if (adam_fused_args(adam_v, "nadm_encode_fwd_step: Adam state of V is NULL", &adv)) return 1;
+    if (adam_v->when != 1) return fail("nadm_encode_fwd_step: the V update runs in the prologue (nadm_adam_t.when = 1)");
+    if (((uintptr_t)V | (uintptr_t)dV) & 15) return fail("nadm_encode_fwd_step: V and dV must be 16-byte aligned");
+    SmallSide ss{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f};
+    if (small_part) {
+        if (!grad_small || splits <= 0 || n_small <= 0) return fail("nadm_encode_fwd_step: small-parameter side work needs grad_small, splits, n_small");
+        ss = SmallSide{small_part, grad_small, small, nullptr, nullptr, splits, n_small, 0.f, 0.f, 0.f};
+        if (adam_small) {
+            if (!adam_small->m || !adam_small->v || !small) return fail("nadm_encode_fwd_step: Adam state / parameters of the small update are NULL");
+            if (adam_small->step < 1 || adam_small->when != 0) return fail("nadm_encode_fwd_step: small update: step is 1-based, when must be 0");
+            ss.m = adam_small->m; ss.v = adam_small->v; ss.grad_scale = adam_small->grad_scale;
+            adam_scalars(adam_small->lr, adam_small->step, &ss.step_size, &ss.bc2_sqrt);
+        }
+    }
+    return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0u, ss, V, dV, adv);
+}
+
 extern "C" int nadm_pca_project(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                                 const float* V, int32_t CP, float* zpart, void* stream) {
-    if (CP > 8 || !use_mfma_encode()) return fail("nadm_pca_project: only the matrix-core pass (CP <= 8) has the missing = 1.5 variant");
+    if (CP > 8) return fail("nadm_pca_project: only the matrix-core pass (CP <= 8) has the missing = 1.5 variant");
     return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0x3FC0u);
 }
 
@@ -1478,10 +1647,6 @@ static int decode_bce_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
         }
     }
     switch (kp) {
-        case 4: return launch_decode<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
-        case 8: return launch_decode<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
-        case 12: return launch_decode<12>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
-        case 16: return launch_decode<16>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
         case 24: return launch_decode<24>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
         case 32: return launch_decode<32>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
         case 48: return launch_decode<48>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad);
@@ -1501,19 +1666,6 @@ extern "C" int nadm_decode_bce_gather(const uint8_t* xp, int64_t ld, const int32
                                       float* losspart, int32_t with_loss, uint8_t* xg, void* stream) {
     if (!xg) return fail("nadm_decode_bce_gather: null pointer");
     return decode_bce_impl(xp, ld, idx, b, M, const_cast<float*>(P), kp, Q, SP, dP, dqpart, losspart, with_loss, stream, xg, AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0});
-}
-
-static int adam_fused_args(const nadm_adam_t* adam, const char* who, AdamFused* out) {
-    *out = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0};
-    if (!adam) return 0;
-    if (!adam->m || !adam->v) return fail(who);
-    if (adam->step < 1) return fail("nadm_*_step: Adam step is 1-based");
-    if (((uintptr_t)adam->m | (uintptr_t)adam->v) & 15) return fail("nadm_*_step: Adam state must be 16-byte aligned");
-    out->m = adam->m; out->v = adam->v; out->grad_scale = adam->grad_scale;
-    out->pre = adam->when == 1 ? 1 : 0;
-    if (adam->when != 0 && adam->when != 1) return fail("nadm_*_step: nadm_adam_t.when is 0 (epilogue) or 1 (prologue, pass 2 only)");
-    adam_scalars(adam->lr, adam->step, &out->step_size, &out->bc2_sqrt);
-    return 0;
 }
 
 extern "C" int nadm_decode_bce_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
@@ -1547,7 +1699,7 @@ static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_encode_bwd: ld must be a multiple of 16 and >= ceil(M/4)");
     dim3 grid((unsigned)((M + 1023) / 1024)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (CP <= 8 && use_mfma_encode()) {
+    if (CP <= 8) {
         MlpSide side;
         memset(&side, 0, sizeof(side));
         int64_t extra = 0;
@@ -1562,8 +1714,6 @@ static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
         return check_launch("encode_bwd_mfma");
     }
     switch (CP) {
-        case 4: hipLaunchKernelGGL((encode_bwd_kernel<4>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
-        case 8: hipLaunchKernelGGL((encode_bwd_kernel<8>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
         case 12: hipLaunchKernelGGL((encode_bwd_kernel<12>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
         case 16: hipLaunchKernelGGL((encode_bwd_kernel<16>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
         case 24: hipLaunchKernelGGL((encode_bwd_kernel<24>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
@@ -1593,6 +1743,6 @@ extern "C" int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx
 
 extern "C" int nadm_pca_project_t(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                                   const float* Y, int32_t CP, float* out, void* stream) {
-    if (CP > 8 || !use_mfma_encode()) return fail("nadm_pca_project_t: only the matrix-core pass (CP <= 8) has the missing = 1.5 variant");
+    if (CP > 8) return fail("nadm_pca_project_t: only the matrix-core pass (CP <= 8) has the missing = 1.5 variant");
     return encode_bwd_impl(xp, ld, idx, b, M, Y, CP, out, stream, 0x3FC0u);
 }

@@ -1327,7 +1327,44 @@ __global__ __launch_bounds__(256) void dq_prereduce_kernel(float* __restrict__ d
     slab[(int64_t)y * row4] = a;
 }
 
-extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const float* dqpart, int64_t M, int32_t b,
+// out[e] = sum over rows r of src[r * n + e], rows added in ascending order within each of 32 interleaved groups, groups combined
+// in ascending order: fixed order, no atomics.  The SNP-sharded step folds its partial Z / dQ slabs with it before the all-reduce.
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ src, int64_t rows, int64_t n4, float* __restrict__ out) {
+    __shared__ float4 s_part[256];
+    const int tid = threadIdx.x, c = tid & 7, g = tid >> 3;           // 8 float4 columns x 32 row groups per block
+    const int64_t col = (int64_t)blockIdx.x * 8 + c;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < n4) {
+        const float4* base = reinterpret_cast<const float4*>(src) + col;
+        constexpr int D = 8;                                           // rows per trip: loaded unconditionally (clamped), added under a mask
+        for (int64_t r0 = g; r0 < rows; r0 += 32 * D) {
+            float4 v[D];
+#pragma unroll
+            for (int u = 0; u < D; ++u) { const int64_t r = r0 + 32 * u; v[u] = base[(r < rows ? r : rows - 1) * n4]; }
+#pragma unroll
+            for (int u = 0; u < D; ++u)
+                if (r0 + 32 * u < rows) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+        }
+    }
+    s_part[tid] = a;
+    __syncthreads();
+    if (g == 0 && col < n4) {
+        float4 t = s_part[c];
+        for (int gg = 1; gg < 32; ++gg) { const float4 v = s_part[gg * 8 + c]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        reinterpret_cast<float4*>(out)[col] = t;
+    }
+}
+
+extern "C" int nadm_sum_rows(const float* src, int64_t rows, int64_t n, float* out, void* stream) {
+    if (!src || !out) return fail("nadm_sum_rows: null pointer");
+    if (rows <= 0 || n <= 0 || (n & 3)) return fail("nadm_sum_rows: need rows > 0 and a row length that is a positive multiple of 4");
+    if (((uintptr_t)src | (uintptr_t)out) & 15) return fail("nadm_sum_rows: 16-byte alignment");
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)((n4 + 7) / 8)), dim3(256), 0, (hipStream_t)stream, src, rows, n4, out);
+    return check_launch("sum_rows");
+}
+
+extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, float* dqpart, int64_t M, int32_t b,
                             const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
                             float* dL, float* dHpre, float* dgp, float* small_part, float* dZ, float* grad_small,
                             const float* losspart, int64_t n_loss, double* loss_acc, void* stream) {
@@ -1346,7 +1383,7 @@ extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, const fl
         }
         if (max_rows > DQ_R_MIN_ROWS) {
             hipLaunchKernelGGL(dq_prereduce_kernel, dim3((unsigned)((max_row4 + 255) / 256), DQ_R, hd->n_heads), dim3(256), 0, st,
-                               const_cast<float*>(dqpart), dqc, *hd, b);
+                               dqpart, dqc, *hd, b);
             if (check_launch("dq_prereduce")) return 1;
             for (int h = 0; h < hd->n_heads; ++h)                       // the kernel's rule: heads with more than DQ_R rows were folded
                 if (dqc.n[h] > DQ_R) dqc.n[h] = DQ_R;

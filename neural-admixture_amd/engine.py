@@ -40,7 +40,11 @@ class Engine:
         self.bmax = int(max_batch)
         z = lambda n, dt=_f32: torch.zeros(int(n), dtype=dt, device=device)
         # parameters, gradients, Adam moments
-        self.big, self.mbig, self.vbig = z(L.n_big), z(L.n_big), z(L.n_big)
+        # `big`, `mbig`, `vbig` (and `small` & co. below) are PROPERTIES: the data-parallel step leaves the P update to the prologue of the
+        # next pass 2 and the single-GPU step leaves the small-parameter update to the next pass 1; any access from outside the step
+        # sequence first applies what is owed, so nobody ever reads parameters or moments one step behind.  The step methods
+        # themselves use the underscore names.
+        self._big, self._mbig, self._vbig = z(L.n_big), z(L.n_big), z(L.n_big)
         # The small parameters, their gradient and moments are PROPERTIES (below): the single-GPU step leaves the sum of the
         # weight-gradient partials + Adam on them to side blocks of the NEXT step's pass 1 (nadm_encode_fwd_small), and any other
         # access first applies a pending update as a launch of its own -- nobody ever sees them one step behind
@@ -85,15 +89,11 @@ class Engine:
         self.sync_tail_message = True                         # see train_step_ddp.send
         self.timers: Optional[dict] = None                    # {name: [(start, end) HIP events]} when a dict (bench.py)
         self.timed_names = None                               # restrict the timers to these kernel names (None = all)
-        # train_step(): optional second stream for the work that does not depend on pass 3.  Measured on MI355X (b=800,
-        # M=500k, K=8): the ~35 us of hidden kernels are cancelled by the cross-stream event waits (0.569 vs 0.563 ms/step),
-        # so it is off by default.
-        self.overlap = False
-        self._side, self._ev = None, None
         self._n_cu: Optional[int] = None
         self.head_streams = 2                                 # decode_all: concurrent pass-2 launches of a multi-head model
         self._head_streams, self._head_events = None, None
         self._pending_ddp = None                              # (works, lr, grad_scale, step) of a deferred P update
+        self._pending_vs = None                               # (lr, grad_scale, step) of a deferred update of V and the small parameters
 
     def _xg_buf(self) -> torch.Tensor:
         if self._xg is None:
@@ -159,28 +159,30 @@ class Engine:
         """V_MC [M,C]; P_SM [sum(ks), M] (reference P_init layout, train.py:63,67); small = flat
         g|W1|b1|Wk|bk in the nadm.h order."""
         L = self.lay
+        self._pending_small = self._pending_ddp = self._pending_vs = None     # whatever was owed is overwritten
+        self._qimg_b = -1
         big = np.zeros(L.n_big, dtype=np.float32)
         big[: L.M * L.CP].reshape(L.M, L.CP)[:, : L.C] = V_MC
         ini = 0
         for h, k in enumerate(L.ks):
             big[L.p_off[h]: L.p_off[h] + L.M * L.kp[h]].reshape(L.M, L.kp[h])[:, :k] = P_SM[ini:ini + k].T
             ini += k
-        self.big.copy_(torch.from_numpy(big))
+        self._big.copy_(torch.from_numpy(big))
         # the loss value of pass 2 may skip the clamp of the reconstruction while every P entry lies in [0, 1]; true after the
         # first restrict_P, and for the GMM initialisation (clipped to [5e-6, 1 - 5e-6]) -- not for the supervised one
         self.p_unit = bool(np.min(P_SM) >= 0.0 and np.max(P_SM) <= 1.0) if np.size(P_SM) else True
         self.small.copy_(torch.from_numpy(np.ascontiguousarray(small, dtype=np.float32)))
-        for t in (self.mbig, self.vbig, self.msmall, self.vsmall, self.gbig, self.gsmall):
+        for t in (self._mbig, self._vbig, self.msmall, self.vsmall, self.gbig, self.gsmall):
             t.zero_()
         self.step_count = 0
 
     def V(self) -> torch.Tensor:
         L = self.lay
-        return self.big[: L.M * L.CP].view(L.M, L.CP)[:, : L.C]
+        return self._big[: L.M * L.CP].view(L.M, L.CP)[:, : L.C]
 
     def P(self, h: int) -> torch.Tensor:
         L = self.lay
-        return self.big[L.p_off[h]: L.p_off[h] + L.M * L.kp[h]].view(L.M, L.kp[h])[:, : L.ks[h]]
+        return self._big[L.p_off[h]: L.p_off[h] + L.M * L.kp[h]].view(L.M, L.kp[h])[:, : L.ks[h]]
 
     def gV(self) -> torch.Tensor:
         L = self.lay
@@ -191,18 +193,44 @@ class Engine:
         return self.gbig[L.p_off[h]: L.p_off[h] + L.M * L.kp[h]].view(L.M, L.kp[h])[:, : L.ks[h]]
 
     def flush_small(self) -> None:
-        """Apply the small-parameter update the last single-GPU step left to the next pass 1 (no-op if none is owed)."""
+        """Apply the small-parameter update the last step left to the next pass 1 (no-op if none is owed): the single-GPU step's
+        (sum of the weight-gradient partials + Adam), or the data-parallel step's, which comes with the update of V."""
+        if self._pending_vs is not None:
+            lr, scale, step = self._pending_vs
+            self.adam_v_small(lr, scale, step)
+            self._pending_vs = None
         if self._pending_small is None:
             return
         splits, lr, scale, step = self._pending_small
-        self._pending_small = None
         sa = AdamArgs(self._msmall.data_ptr(), self._vsmall.data_ptr(), lr, step, scale, 0)
         check(lib.nadm_small_grads(ptr(self.small_part), splits, self.lay.n_small, ptr(self._gsmall), ptr(self._small), C.byref(sa), _stream()),
               "small_grads")
+        self._pending_small = None                            # only now: a refused launch must not lose the update
 
     def _flushed(self, t):
         self.flush_small()
         return t
+
+    def _p_flushed(self, t):
+        self.finish_ddp()
+        return t
+
+    big = property(lambda self: self._p_flushed(self._big), lambda self, t: setattr(self, "_big", t))
+    mbig = property(lambda self: self._p_flushed(self._mbig), lambda self, t: setattr(self, "_mbig", t))
+    vbig = property(lambda self: self._p_flushed(self._vbig), lambda self, t: setattr(self, "_vbig", t))
+
+    def _set_q(self, t):
+        self._Q = t
+        self._qimg_b = -1                                     # Q rewritten from outside: its operand images are stale
+
+    # Q is written by mlp_forward() through the underscore name; an assignment from outside (tests, a caller that edits Q before
+    # decode_all) drops the bf16 operand images of pass 2, which then splits Q itself.  In-place edits of the tensor: invalidate_q().
+    Q = property(lambda self: self._Q, _set_q)
+
+    def invalidate_q(self) -> None:
+        """Call after editing Q (or P through a raw view) in place: pass 2 rebuilds its operands from the fp32 values."""
+        self._qimg_b = -1
+        self.p_unit = False                                   # P may hold anything: the loss path clamps until the next restrict_P
 
     small = property(lambda self: self._flushed(self._small), lambda self, t: setattr(self, "_small", t))
     msmall = property(lambda self: self._flushed(self._msmall), lambda self, t: setattr(self, "_msmall", t))
@@ -216,16 +244,26 @@ class Engine:
         if b > self.bmax:
             raise RuntimeError("batch larger than the engine was sized for")
         ev = self._timed("encode_fwd")
-        if self._pending_small is not None and L.CP <= 8:     # the previous step's small update rides in this launch
-            splits, lr, scale, step = self._pending_small
-            self._pending_small = None
+        if self._pending_vs is not None and L.CP <= 8:
+            # data-parallel step: the previous step's update of V (prologue of this launch, from the all-reduced gradient in gbig)
+            # and of the small parameters (side blocks; the all-reduced flat gradient is their one "split")
+            lr, scale, step = self._pending_vs
+            av = AdamArgs(self._mbig.data_ptr(), self._vbig.data_ptr(), lr, step, scale, 1)
             sa = AdamArgs(self._msmall.data_ptr(), self._vsmall.data_ptr(), lr, step, scale, 0)
-            check(lib.nadm_encode_fwd_small(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self.big), L.CP, ptr(self.zpart),
+            check(lib.nadm_encode_fwd_step(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self._big), L.CP, ptr(self.zpart), ptr(self.gbig),
+                                           C.byref(av), ptr(self._gsmall), 1, L.n_small, ptr(self._gsmall), ptr(self._small), C.byref(sa), st),
+                  "encode_fwd_step")
+            self._pending_vs = None
+        elif self._pending_small is not None and L.CP <= 8:   # the previous step's small update rides in this launch
+            splits, lr, scale, step = self._pending_small
+            sa = AdamArgs(self._msmall.data_ptr(), self._vsmall.data_ptr(), lr, step, scale, 0)
+            check(lib.nadm_encode_fwd_small(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self._big), L.CP, ptr(self.zpart),
                                             ptr(self.small_part), splits, L.n_small, ptr(self._gsmall), ptr(self._small), C.byref(sa), st),
                   "encode_fwd_small")
+            self._pending_small = None                        # only now: a refused launch must not lose the update
         else:
             self.flush_small()
-            check(lib.nadm_encode_fwd(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self.big), L.CP, ptr(self.zpart), st), "encode_fwd")
+            check(lib.nadm_encode_fwd(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self._big), L.CP, ptr(self.zpart), st), "encode_fwd")
         if ev: ev[1].record()
 
     def mlp_forward(self, b: int, z_src: Optional[torch.Tensor] = None, n_chunks: Optional[int] = None) -> None:
@@ -275,9 +313,9 @@ class Engine:
         update in the kernel's epilogue with the current step count, or (lr, grad_scale, step) for the PREVIOUS step's update in
         the prologue of pass 2 (data-parallel step, nadm_adam_t.when = 1)."""
         if len(fused) == 3:
-            return AdamArgs(self.mbig.data_ptr() + off_floats * 4, self.vbig.data_ptr() + off_floats * 4, fused[0], fused[2], fused[1], 1)
+            return AdamArgs(self._mbig.data_ptr() + off_floats * 4, self._vbig.data_ptr() + off_floats * 4, fused[0], fused[2], fused[1], 1)
         lr, scale = fused
-        return AdamArgs(self.mbig.data_ptr() + off_floats * 4, self.vbig.data_ptr() + off_floats * 4, lr, self.step_count, scale, 0)
+        return AdamArgs(self._mbig.data_ptr() + off_floats * 4, self._vbig.data_ptr() + off_floats * 4, lr, self.step_count, scale, 0)
 
     def decode_all(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_grad_ready=None, p_parts=1,
                    supervised: bool = True, fused_adam=None) -> int:
@@ -312,7 +350,7 @@ class Engine:
             for m0, m1 in (self._round_ranges(csnps, align, 3 if kp <= 8 else 2) if p_parts == "rounds" else self._snp_ranges(p_parts, align)):
                 c0 = m0 // csnps
                 args = (C.c_void_p(self.xp.data_ptr() + m0 // 4), self.ld, ptr(idx), b, m1 - m0,
-                        C.c_void_p(self.big.data_ptr() + (L.p_off[h] + m0 * kp) * fsz), kp,
+                        C.c_void_p(self._big.data_ptr() + (L.p_off[h] + m0 * kp) * fsz), kp,
                         C.c_void_p(self.Q.data_ptr() + L.qoff[h] * fsz), L.SP,
                         C.c_void_p(self.gbig.data_ptr() + (L.p_off[h] + m0 * kp) * fsz),
                         C.c_void_p(self.dqpart.data_ptr() + (dq_offs[h] + c0 * b * kp) * fsz),
@@ -378,7 +416,7 @@ class Engine:
             side = mw if i == 0 else None
             if fused_adam is not None or side is not None:    # Adam on these V rows in the epilogue and / or the side blocks
                 check(lib.nadm_encode_bwd_step(C.c_void_p(src.data_ptr() + m0 // 4), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), L.CP,
-                                               C.c_void_p(self.big.data_ptr() + m0 * L.CP * fsz),
+                                               C.c_void_p(self._big.data_ptr() + m0 * L.CP * fsz),
                                                C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz),
                                                C.byref(self._adam_args(m0 * L.CP, fused_adam)) if fused_adam is not None else None,
                                                C.byref(side) if side is not None else None, st), "encode_bwd_step")
@@ -398,22 +436,16 @@ class Engine:
                 on_grad_ready(0 if i == 0 else self._ns_pad + m0 * L.CP, self._ns_pad + m1 * L.CP)
         if ev: ev[1].record()
 
-    def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_decoder_done=None, on_mlp_bwd_done=None,
-                 on_grad_ready=None, p_parts=1, v_parts: int = 1, fused_adam=None, side_weights: bool = False, pre_adam=None) -> None:
+    def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True, on_grad_ready=None, p_parts=1, v_parts: int = 1,
+                 fused_adam=None, side_weights: bool = False, pre_adam=None) -> None:
         """Decoder + BCE fwd/bwd per head, MLP backward, dV.  Gradients land in gbig / gsmall (views of gflat).
-        ``on_decoder_done`` (optional callable) is invoked after all the dP kernels are enqueued.  With
-        ``on_mlp_bwd_done`` the MLP weight gradients are left to that callback (nadm_mlp_bwd_weights on another stream).
         ``on_grad_ready(lo, hi)`` is invoked each time a contiguous piece gflat[lo:hi] of the big gradients is final and
         enqueued; passes 2 and 3 are launched on ``p_parts`` / ``v_parts`` SNP sub-ranges so that the data-parallel step can
         all-reduce one piece while the next is being computed (each head's P, or the two parts of a single head's P; the
         small gradients travel with the first piece of dV).  ``pre_adam`` = (lr, grad_scale, step): pass 2 first applies that
         (previous) step's Adam + clamp to its P rows from the gradient lying in gbig, then overwrites it (data-parallel step)."""
         n_loss = self.decode_all(idx, b, with_loss, on_grad_ready, p_parts, fused_adam=fused_adam if pre_adam is None else pre_adam)
-        if on_decoder_done is not None:
-            on_decoder_done()
-        self.mlp_backward(b, n_loss if with_loss else 0, weights=on_mlp_bwd_done is None and not side_weights)
-        if on_mlp_bwd_done is not None:
-            on_mlp_bwd_done()
+        self.mlp_backward(b, n_loss if with_loss else 0, weights=not side_weights)
         self.encode_backward(idx, b, on_grad_ready, v_parts, fused_adam=fused_adam, side_weights=side_weights)
 
     def adam_part(self, part: str, lr: float, grad_scale: float = 1.0, stream=None) -> None:
@@ -422,50 +454,46 @@ class Engine:
         st = _stream() if stream is None else stream
         if part == "P":
             off = L.clamp_from * fsz
-            check(lib.nadm_adam(C.c_void_p(self.big.data_ptr() + off), C.c_void_p(self.gbig.data_ptr() + off),
-                                C.c_void_p(self.mbig.data_ptr() + off), C.c_void_p(self.vbig.data_ptr() + off),
+            check(lib.nadm_adam(C.c_void_p(self._big.data_ptr() + off), C.c_void_p(self.gbig.data_ptr() + off),
+                                C.c_void_p(self._mbig.data_ptr() + off), C.c_void_p(self._vbig.data_ptr() + off),
                                 L.n_big - L.clamp_from, 0, lr, self.step_count, grad_scale, st), "adam(P)")
         elif part == "V":
-            check(lib.nadm_adam(ptr(self.big), ptr(self.gbig), ptr(self.mbig), ptr(self.vbig), L.clamp_from, L.clamp_from,
+            check(lib.nadm_adam(ptr(self._big), ptr(self.gbig), ptr(self._mbig), ptr(self._vbig), L.clamp_from, L.clamp_from,
                                 lr, self.step_count, grad_scale, st), "adam(V)")
         else:
             check(lib.nadm_adam(ptr(self.small), ptr(self.gsmall), ptr(self.msmall), ptr(self.vsmall), L.n_small, L.n_small,
                                 lr, self.step_count, grad_scale, st), "adam(small)")
 
-    def adam_v_small(self, lr: float, grad_scale: float) -> None:
-        """Adam on V and on the small parameters in ONE launch (nadm_adam2) for the CURRENT step_count: in the data-parallel step
-        both become final together, behind the [small | dV] all-reduce."""
+    def adam_v_small(self, lr: float, grad_scale: float, step: Optional[int] = None) -> None:
+        """Adam on V and on the small parameters in ONE launch (nadm_adam2) for step count ``step`` (default: the current one): in
+        the data-parallel step both become final together, behind the [small | dV] all-reduce."""
         L = self.lay
-        check(lib.nadm_adam2(ptr(self.big), ptr(self.gbig), ptr(self.mbig), ptr(self.vbig), L.clamp_from, L.clamp_from,
-                             ptr(self.small), ptr(self.gsmall), ptr(self.msmall), ptr(self.vsmall), L.n_small,
-                             lr, self.step_count, grad_scale, _stream()), "adam2(V, small)")
+        check(lib.nadm_adam2(ptr(self._big), ptr(self.gbig), ptr(self._mbig), ptr(self._vbig), L.clamp_from, L.clamp_from,
+                             ptr(self._small), ptr(self._gsmall), ptr(self._msmall), ptr(self._vsmall), L.n_small,
+                             lr, self.step_count if step is None else step, grad_scale, _stream()), "adam2(V, small)")
 
     def adam_p_range(self, lo: int, hi: int, lr: float, grad_scale: float, step: int, stream=None) -> None:
         """Adam + clamp on elements [lo, hi) of the big buffer (a range inside the P matrices) for step count ``step``."""
         fsz = 4
         st = _stream() if stream is None else stream
-        check(lib.nadm_adam(C.c_void_p(self.big.data_ptr() + lo * fsz), C.c_void_p(self.gbig.data_ptr() + lo * fsz),
-                            C.c_void_p(self.mbig.data_ptr() + lo * fsz), C.c_void_p(self.vbig.data_ptr() + lo * fsz),
+        check(lib.nadm_adam(C.c_void_p(self._big.data_ptr() + lo * fsz), C.c_void_p(self.gbig.data_ptr() + lo * fsz),
+                            C.c_void_p(self._mbig.data_ptr() + lo * fsz), C.c_void_p(self._vbig.data_ptr() + lo * fsz),
                             hi - lo, 0, lr, step, grad_scale, st), "adam(P range)")
 
     def adam(self, lr: float, grad_scale: float = 1.0) -> None:
         L, st = self.lay, _stream()
         self.step_count += 1
         ev = self._timed("adam")
-        check(lib.nadm_adam(ptr(self.big), ptr(self.gbig), ptr(self.mbig), ptr(self.vbig), L.n_big, L.clamp_from,
+        check(lib.nadm_adam(ptr(self._big), ptr(self.gbig), ptr(self._mbig), ptr(self._vbig), L.n_big, L.clamp_from,
                             lr, self.step_count, grad_scale, st), "adam(big)")
         self.adam_part("small", lr, grad_scale)
         self.p_unit = True                                    # the launch clamps P to [0, 1] (restrict_P)
         if ev: ev[1].record()
 
     def train_step(self, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True) -> None:
-        """One single-GPU step (neural_admixture.py:403-414 without the per-step host sync).
-
-        With ``overlap``: same kernels, same inputs and therefore the same bits as forward() + backward() + adam(), but the
-        pieces that do not depend on pass 3 run on a second HIP stream underneath it: Adam + clamp of the P matrices as soon as pass 2 is
-        done (HBM-bound, while passes 2'/3 are issue-bound), the MLP weight gradients and the small Adam as soon as the
-        MLP backward has produced dZ.  Enabled with ``Engine.overlap = True`` (off by default, see __init__)."""
-        if self.fused_adam and not self.overlap:
+        """One single-GPU step (neural_admixture.py:403-414 without the per-step host sync)."""
+        self.finish_ddp()                                     # (a data-parallel step before this one may have left updates pending)
+        if self.fused_adam:
             # Adam on P and V where their gradients are completed (epilogues of passes 2 and 3, nadm_*_step): same element
             # update, same bits as the separate launches; the big gradient buffer is not written in this mode
             self.forward(idx, b)
@@ -473,40 +501,9 @@ class Engine:
             self.backward(idx, b, with_loss, fused_adam=(lr, 1.0), side_weights=True)    # small parameters: nadm_small_grads
             self.p_unit = True                                # restrict_P ran in pass 2's epilogue
             return
-        if not self.overlap or self.device.type != "cuda":
-            self.forward(idx, b)
-            self.backward(idx, b, with_loss)
-            self.adam(lr)
-            return
-        L = self.lay
-        main = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-            self._ev = [torch.cuda.Event() for _ in range(3)]
-        side, (ev_dec, ev_a, ev_side) = self._side, self._ev
-        sst = C.c_void_p(side.cuda_stream)
         self.forward(idx, b)
-        self.step_count += 1
-        fsz = 4
-
-        def after_decoder():                                  # P gradients are final: update P underneath the rest
-            ev_dec.record(main)
-            side.wait_event(ev_dec)
-            self.adam_part("P", lr, 1.0, sst)
-
-        def after_mlp_bwd():                                  # dL, dHpre, dgp are final: weight gradients + small Adam
-            ev_a.record(main)
-            side.wait_event(ev_a)
-            check(lib.nadm_mlp_bwd_weights(C.byref(L.heads), b, ptr(self.Zn), ptr(self.H), ptr(self.dL), ptr(self.dHpre), ptr(self.dgp),
-                                           ptr(self.small_part), ptr(self.gsmall), sst), "mlp_bwd_weights")
-            self.adam_part("small", lr, 1.0, sst)
-            ev_side.record(side)
-        self.backward(idx, b, with_loss, on_decoder_done=after_decoder, on_mlp_bwd_done=after_mlp_bwd)
-        ev = self._timed("adam")
-        self.adam_part("V", lr, 1.0)
-        if ev: ev[1].record()
-        main.wait_event(ev_side)                              # the next step reads P and the small parameters
-        self.p_unit = True
+        self.backward(idx, b, with_loss)
+        self.adam(lr)
 
     def train_step_ddp(self, idx: torch.Tensor, b: int, lr: float, world: int, with_loss: bool = True,
                        defer_tail: bool = False) -> None:
@@ -518,9 +515,11 @@ class Engine:
         one message after pass 3.
 
         ``defer_tail``: the next step needs V and the small parameters at once (pass 1, MLP) but P only when its pass 2
-        starts.  The LAST P piece is therefore sent AFTER the small + dV message, and the Adam update of ALL P pieces is left to
-        the prologue of the next step's pass 2 (every block updates its own rows from the all-reduced gradient before it uses
-        them) -- or to finish_ddp().  Same arithmetic, same results; the caller must call finish_ddp() before reading P."""
+        starts.  The LAST P piece is therefore sent AFTER the small + dV message, and NO Adam launch follows the messages: the
+        update of ALL P pieces is left to the prologue of the next step's pass 2 (every block updates its own rows from the
+        all-reduced gradient before it uses them), the update of V to the prologue of the next step's pass 1, and the small
+        parameters' to side blocks of that launch -- or to finish_ddp().  Same arithmetic, same results; the parameter
+        accessors (big, small, V(), P(), ...) apply what is pending first."""
         import torch.distributed as dist
         L = self.lay
         works, pieces = [], []
@@ -579,13 +578,18 @@ class Engine:
                 w.wait()
             if lo >= p_start:                                 # a P piece: Adam on it while later messages are still in flight
                 self.adam_p_range(lo - off, hi - off, lr, scale, self.step_count)
-        self.adam_v_small(lr, scale)                          # every [small | dV] piece is in: V and the small parameters, one launch
+        if defer_tail:                                        # every [small | dV] piece is in: V and the small parameters are updated by
+            self._pending_vs = (lr, scale, self.step_count)   # the next step's pass 1 (or by finish_ddp / the first accessor)
+        else:
+            self.adam_v_small(lr, scale)                      # one launch for both
         if ev: ev[1].record()
         self._pending_ddp = (p_works, lr, scale, self.step_count) if defer_tail else None
         self.p_unit = True                                    # P is clamped by its Adam launch / by the prologue of the pass that reads it next
 
     def finish_ddp(self) -> None:
-        """Apply the P update train_step_ddp(defer_tail=True) left to the next step's pass 2 (call before reading P)."""
+        """Apply the updates train_step_ddp(defer_tail=True) left to the next step's passes 1 and 2 (end of training; the parameter
+        accessors call it)."""
+        self.flush_small()                                    # V + small parameters (or a single-GPU step's small update)
         if not self._pending_ddp:
             return
         works, lr, scale, step = self._pending_ddp

@@ -19,7 +19,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .engine import Engine
+from ._lib import lib, check, ptr
+from .engine import Engine, _stream
 from .layout import ModelLayout
 
 
@@ -68,6 +69,10 @@ class SnpShardedEngine(Engine):
         super().load_params(np.ascontiguousarray(V_MC[self.m0:self.m1]), np.ascontiguousarray(P_SM[:, self.m0:self.m1]), small)
 
     # ------------------------------------------------------------------ step
+    def sum_rows(self, src: torch.Tensor, rows: int, n: int, out: torch.Tensor) -> None:
+        """out[:n] = sum of the ``rows`` rows of length n at the start of src (nadm_sum_rows: fixed order)."""
+        check(lib.nadm_sum_rows(ptr(src), rows, n, ptr(out), _stream()), "sum_rows")
+
     def _all_reduce(self, t: torch.Tensor) -> None:
         if self.world > 1 or dist.is_initialized():
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -77,7 +82,7 @@ class SnpShardedEngine(Engine):
         L = self.lay
         self.encode_partial(idx, b)
         zs = self._zsum[: b * L.CP]
-        torch.sum(self.zpart[: L.enc_chunks * b * L.CP].view(L.enc_chunks, b * L.CP), dim=0, out=zs)
+        self.sum_rows(self.zpart, L.enc_chunks, b * L.CP, zs)
         self._all_reduce(zs)
         self.mlp_forward(b, zs, 1)
 
@@ -92,7 +97,7 @@ class SnpShardedEngine(Engine):
         o = 0
         for h, kp in enumerate(L.kp):                          # per head: [chunks_h, b*kp] -> [b*kp], blocks laid back to back
             ch = L.dec_chunks[h]
-            torch.sum(self.dqpart[dq_offs[h]: dq_offs[h] + ch * b * kp].view(ch, b * kp), dim=0, out=dqs[o: o + b * kp])
+            self.sum_rows(self.dqpart[dq_offs[h]:], ch, b * kp, dqs[o:])
             o += b * kp
         self._all_reduce(dqs)
         side = fused_adam is not None                         # fused step: weight-gradient partials ride on pass 3's launch

@@ -164,9 +164,11 @@ def capped_host_threads(limit: int = 4):
 
 def train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int, data: torch.Tensor, device: torch.device,
           num_gpus: int, hidden_size: int, master: bool, V: np.ndarray, pops, min_k: int = None, max_k: int = None,
-          n_components: int = None, *, parallelism: str = "dp"):
-    """The reference's boundary function (see the module docstring and _train); host thread pools capped while it runs."""
-    with capped_host_threads():
+          n_components: int = None, *, parallelism: str = "dp", host_threads: int = 4):
+    """The reference's boundary function (see the module docstring and _train).  The host thread pools (torch intra-op, BLAS,
+    OpenMP) are capped at ``host_threads`` while it runs -- the reference's CLI does that with --threads (entry.py:138-146), and
+    this package's CLI passes its --threads here; the epoch loop itself always runs with torch's pool at 1 (model.py)."""
+    with capped_host_threads(max(1, int(host_threads))):
         return _train(epochs, batch_size, learning_rate, K, seed, data, device, num_gpus, hidden_size, master, V, pops, min_k, max_k,
                       n_components, parallelism=parallelism)
 

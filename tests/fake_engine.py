@@ -22,7 +22,7 @@ class OracleEngine(Engine):
     def _params(self) -> O.Params:
         L, h = self.lay, self.lay.heads
         sm = self.small.numpy()
-        big = self.big.numpy()
+        big = self._big.numpy()
         V = big[: L.M * L.CP].reshape(L.M, L.CP)[:, : L.C].copy()
         P = [big[L.p_off[i]: L.p_off[i] + L.M * L.kp[i]].reshape(L.M, L.kp[i])[:, :k].copy() for i, k in enumerate(L.ks)]
         Wk = [sm[h.wk_off[i]: h.wk_off[i] + k * L.Hd].reshape(k, L.Hd).copy() for i, k in enumerate(L.ks)]
@@ -40,7 +40,7 @@ class OracleEngine(Engine):
             Q[:, L.qoff[i]: L.qoff[i] + k] = Qs[i]
         self.Q[: b * L.SP] = torch.from_numpy(Q.reshape(-1))
 
-    def backward(self, idx, b, with_loss=True, on_decoder_done=None, on_mlp_bwd_done=None, on_grad_ready=None, p_parts=1, v_parts=1,
+    def backward(self, idx, b, with_loss=True, on_grad_ready=None, p_parts=1, v_parts=1,
                  pre_adam=None):
         L, h = self.lay, self.lay.heads
         if pre_adam is not None:                        # the product's pass 2 applies the previous step's P update in its prologue
@@ -59,8 +59,6 @@ class OracleEngine(Engine):
             sm[h.wk_off[i]: h.wk_off[i] + k * L.Hd] = g[f"Wk{i}"].reshape(-1)
             sm[h.bk_off[i]: h.bk_off[i] + k] = g[f"bk{i}"]
         self.gbig.copy_(torch.from_numpy(big))
-        if on_decoder_done is not None:
-            on_decoder_done()
         self.gsmall.copy_(torch.from_numpy(sm))
         if on_grad_ready is not None:                   # same message plan as the product: P pieces, then small+V pieces
             split = self._ns_pad + L.clamp_from
@@ -79,12 +77,14 @@ class OracleEngine(Engine):
         for part in ("P", "V", "small"):
             self.adam_part(part, lr, grad_scale)
 
-    def adam_v_small(self, lr, grad_scale):
-        self.adam_part("V", lr, grad_scale)
-        self.adam_part("small", lr, grad_scale)
+    def adam_v_small(self, lr, grad_scale, step=None):
+        t = self.step_count if step is None else step
+        cf = self.lay.clamp_from
+        self._adam_on(self._big[:cf], self.gbig[:cf], self._mbig[:cf], self._vbig[:cf], False, lr, grad_scale, t)
+        self._adam_on(self._small, self._gsmall, self._msmall, self._vsmall, False, lr, grad_scale, t)
 
     def adam_p_range(self, lo, hi, lr, grad_scale, step, stream=None):
-        self._adam_on(self.big[lo:hi], self.gbig[lo:hi], self.mbig[lo:hi], self.vbig[lo:hi], True, lr, grad_scale, step)
+        self._adam_on(self._big[lo:hi], self.gbig[lo:hi], self._mbig[lo:hi], self._vbig[lo:hi], True, lr, grad_scale, step)
 
     def adam_part(self, part, lr, grad_scale=1.0, stream=None):
         t = self.step_count
@@ -93,9 +93,9 @@ class OracleEngine(Engine):
         if part == "small":
             p_, g_, m_, v_, clamp = self.small, self.gsmall, self.msmall, self.vsmall, False
         elif part == "V":
-            p_, g_, m_, v_, clamp = self.big[:cf], self.gbig[:cf], self.mbig[:cf], self.vbig[:cf], False
+            p_, g_, m_, v_, clamp = self._big[:cf], self.gbig[:cf], self._mbig[:cf], self._vbig[:cf], False
         else:
-            p_, g_, m_, v_, clamp = self.big[cf:], self.gbig[cf:], self.mbig[cf:], self.vbig[cf:], True
+            p_, g_, m_, v_, clamp = self._big[cf:], self.gbig[cf:], self._mbig[cf:], self._vbig[cf:], True
         self._adam_on(p_, g_, m_, v_, clamp, lr, grad_scale, t)
 
     @staticmethod
@@ -135,6 +135,9 @@ class OracleSnpEngine(OracleEngine, SnpShardedEngine):
     backward = SnpShardedEngine.backward
     train_step = SnpShardedEngine.train_step
     read_loss = SnpShardedEngine.read_loss
+
+    def sum_rows(self, src, rows, n, out):                    # (the product folds the slabs with nadm_sum_rows)
+        torch.sum(src[: rows * n].view(rows, n), dim=0, out=out[:n])
 
     def encode_partial(self, idx, b):
         L = self.lay

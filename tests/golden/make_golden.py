@@ -352,6 +352,7 @@ if __name__ == "__main__":
         "multibatch": case_multibatch,
         "multihead_run": case_multihead_run,
         "ddp": lambda: case_ddp(2),
+        "ddp4": lambda: case_ddp(4),                       # N = 203 over 4 ranks: one wrapped duplicate, 16-row batches, ragged last one (3 rows)
         "demo": case_demo,
         "supervised": case_supervised,
         "one_step_supervised": lambda: one_step_case("one_step_supervised", 64, 509, [5], 64, 8, seed=8, sup=True),

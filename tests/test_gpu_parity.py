@@ -254,28 +254,89 @@ def test_fast_and_generic_mlp_kernels_agree(monkeypatch):
         assert abs(outs[0][4] - outs[1][4]) <= 1e-6 * abs(outs[1][4])
 
 
-def test_two_stream_step_is_bit_identical_to_the_single_stream_step():
-    """Engine.train_step overlaps the P / small-parameter updates and the MLP weight gradients with pass 3 on a second
-    stream; same kernels on the same inputs -> the parameters after several steps must be identical bit for bit."""
-    rng = np.random.default_rng(12)
-    N, M, ks, Hd = 300, 6000, [3, 8], 128
-    Gm = O.synth_genotypes(N, M, 4, seed=3)
+@pytest.mark.parametrize("name", ["one_step_k3", "one_step_multihead", "one_step_k8_h1024", "one_step_edge",
+                                  "one_step_supervised", "one_step_k7_h1024", "one_step_heads2to10"])
+def test_production_step_against_reference_fixture(name):
+    """The step the trainer and bench.py run -- Engine.train_step: Q operand images, Adam in the epilogues of passes 2 and 3,
+    small-parameter update riding in the next pass 1 -- against the parameters and losses the reference's own
+    forward / backward / optimizer.step / restrict_P produced for three steps (the unfused sequence has its own test above)."""
+    d = np.load(f"{G}/{name}.npz")
+    ks = [int(k) for k in d["ks"]]
+    p = O.make_params(int(d["seed"]), d["V0"], d["P0"], int(d["Hd"]), ks)
+    Gm = d["G"]
+    b = Gm.shape[0]
+    e = make_engine(Gm, p, b)
+    assert e.fused_adam and e.defer_small and e.q_images
+    idx = torch.arange(b, dtype=torch.int32, device=e.device)
+    if "labels" in d.files:
+        e.set_labels(d["labels"], ks[0], 100.0)
+    # one_step_edge: P rows at exactly 0 / 1 with r == 0 entries -- the BCE backward divides by the 1e-12 floor there, single
+    # gradients of 5e11 go through Adam, and which side of a rounding boundary r falls on decides whether an entry sees one: P
+    # is compared at 1e-4 (Adam's step is lr = 2e-3 whatever the gradient's size), the other parameters are not compared
+    edge = name.endswith("edge")
+    for s in range(3):
+        e.train_step(idx, b, float(d["lr"]), with_loss=True)
+        torch.cuda.synchronize()
+        _, last = e.read_loss()
+        assert abs(last - float(d[f"loss{s}"])) / float(d[f"loss{s}"]) < 5e-6
+        if not edge:
+            assert mx(e.V().cpu().numpy(), d[f"after{s}_V"]) < 5e-6
+            sm = split_small(e.lay, e.small.cpu().numpy())       # (the property applies the update owed to the next pass 1)
+            assert mx(sm["W1"], d[f"after{s}_common_encoder_0_weight"]) < 5e-6
+            assert mx(sm["b1"], d[f"after{s}_common_encoder_0_bias"]) < 5e-6
+            assert mx(sm["g"], d[f"after{s}_batch_norm_weight"]) < 5e-6
+            for h in range(len(ks)):
+                assert mx(sm[f"Wk{h}"], d[f"after{s}_multihead_encoder_heads_{h}_weight"]) < 5e-6
+        for h in range(len(ks)):
+            assert mx(e.P(h).cpu().numpy(), d[f"after{s}_decoders_decoders_{h}_weight"]) < (1e-4 if edge else 5e-6)
+
+
+@pytest.mark.parametrize("ks", [[5], [13]])
+def test_pair_product_loss_and_its_exact_fallback(ks):
+    """Pass 2 (P in [0, 1]) takes ONE logarithm per pair of genotypes -- log2 of the product of the four factors d / 1-d the codes
+    select -- and recomputes a tile pair in the exact two-logarithms-per-genotype form when a product is 0 or underflows, i.e.
+    whenever one of the reference's max(log, -100) clamps could be active.  Exact zeros (P rows of zeros under non-zero
+    genotypes: d == 0, loss term 100 per allele copy), P rows of ones (1 - d == 0 up to rounding) and P rows of 1e-12 (d^2
+    underflows) are planted; the loss must equal the exact form's (with_loss bit 1 selects it) to rounding and the oracle's
+    where the reconstruction does not sit on a rounding boundary; gradients do not depend on the loss form at all."""
+    rng = np.random.default_rng(21)
+    N, M, Hd = 70, 3000, 64
+    Gm = O.synth_genotypes(N, M, 4, seed=9, missing=0.03)
+    Gm[:, 100:140] = rng.integers(0, 3, size=(N, 40))            # non-zero genotypes over the all-zero P rows
     V0 = (rng.standard_normal((M, 8)) / np.sqrt(M)).astype(np.float32)
     P0 = rng.uniform(0.02, 0.98, size=(sum(ks), M)).astype(np.float32)
-    p = O.make_params(5, V0, P0, Hd, ks)
-    outs = []
-    for overlap in (True, False):
-        e = make_engine(Gm, p, 128)
-        e.overlap = overlap
-        perm = torch.from_numpy(np.random.default_rng(1).permutation(N).astype(np.int32)).to(e.device)
-        for s in range(6):
-            o = (s * 128) % (N - 128)
-            e.train_step(perm[o:o + 128], 128, 2e-3, with_loss=(s % 2 == 0))
+    P0[:, 100:140] = 0.0
+    P0[:, 300:320] = 1e-12
+    p = O.make_params(3, V0, P0, Hd, ks)
+    loss_o, grads_o, _ = O.step_grads(p, Gm)
+    idx = None
+    res = {}
+    for form in ("fast", "exact"):
+        e = make_engine(Gm, p, N)
+        idx = torch.arange(N, dtype=torch.int32, device=e.device)
+        assert e.p_unit
+        e.p_unit = form == "fast"                              # False: with_loss = 3, the exact form in every tile
+        e.forward(idx, N)
+        e.backward(idx, N, True)
         torch.cuda.synchronize()
-        outs.append((e.big.cpu().numpy().copy(), e.small.cpu().numpy().copy(), e.mbig.cpu().numpy().copy(), e.vsmall.cpu().numpy().copy(),
-                     e.read_loss()[0]))
-    for a, c in zip(outs[0], outs[1]):
-        assert np.array_equal(np.asarray(a), np.asarray(c))
+        res[form] = (e.read_loss()[1], e.gbig.cpu().numpy().copy(), e.dZ.cpu().numpy().copy())
+    assert np.isfinite(res["fast"][0])
+    assert abs(res["fast"][0] - res["exact"][0]) <= 2e-6 * abs(res["exact"][0])
+    assert abs(res["fast"][0] - loss_o) <= 5e-6 * abs(loss_o)
+    assert np.array_equal(res["fast"][1], res["exact"][1]) and np.array_equal(res["fast"][2], res["exact"][2])
+    # rows of ones: 1 - d is 0 or 6e-8 depending on the summation order, so only the two forms on the SAME reconstruction compare
+    P1 = P0.copy()
+    P1[:, 200:230] = 1.0
+    p1 = O.make_params(3, V0, P1, Hd, ks)
+    out = []
+    for form in ("fast", "exact"):
+        e = make_engine(Gm, p1, N)
+        e.p_unit = form == "fast"
+        e.forward(idx, N)
+        e.backward(idx, N, True)
+        torch.cuda.synchronize()
+        out.append(e.read_loss()[1])
+    assert np.isfinite(out[0]) and abs(out[0] - out[1]) <= 2e-6 * abs(out[1])
 
 
 def test_snp_subrange_launches_give_identical_gradients_and_cover_the_flat_buffer():

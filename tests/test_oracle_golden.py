@@ -111,16 +111,22 @@ def test_multihead_trajectory():
     assert np.allclose(losses, d["hi_losses"].reshape(int(d["epochs"]), -1).sum(1), rtol=1e-6)
 
 
-def test_ddp_emulation_world2():
-    d = np.load(f"{G}/ddp_w2.npz")
+@pytest.mark.parametrize("world", [2, 4])
+def test_ddp_emulation(world):
+    """world 2: 102 rows per rank, batches of 32 (last one 6); world 4: N = 203 is padded to 204 by wrapping one index
+    (DistributedSampler, loaders.py:26-27), 51 rows per rank, batches of 64 // 4 = 16 (neural_admixture.py:287), last one 3."""
+    d = np.load(f"{G}/ddp_w{world}.npz")
+    assert int(d["world"]) == world
     Gm = O.unpack2bit(d["G_packed"], int(d["M"]))
     p = O.make_params(int(d["seed"]), d["V0"], d["P0"], int(d["Hd"]), [int(d["K"])])
     orders = []
-    p, Qs, losses = O.train_run(Gm, p, int(d["epochs"]), int(d["batch"]), float(d["lr"]), int(d["seed"]), world=2,
+    p, Qs, losses = O.train_run(Gm, p, int(d["epochs"]), int(d["batch"]), float(d["lr"]), int(d["seed"]), world=world,
                                 record_orders=orders)
-    eo = O.EpochOrder(int(d["N"]), int(d["seed"]), 2)
-    for r in range(2):
+    eo = O.EpochOrder(int(d["N"]), int(d["seed"]), world)
+    for r in range(world):
         assert np.array_equal(eo.rank_indices(orders[0], r), d["rank_orders"][r])   # DistributedSampler shard
+    if world == 4:
+        assert len(np.unique(d["rank_orders"])) == int(d["N"]) and d["rank_orders"].size == int(d["N"]) + 1   # one wrapped duplicate
     assert mx(Qs[0], d["Q"]) < 1e-4 and mx(p.P[0], d["P"]) < 1e-5 and mx(p.V, d["V"]) < 1e-4
     assert np.allclose(losses, d["losses_rank0"].reshape(int(d["epochs"]), -1).sum(1), rtol=1e-6)
 

@@ -25,14 +25,19 @@ def main():
     j = next(k for k in range(i, len(txt)) if txt[k].startswith("\t.end_amdhsa_kernel") or re.match(r"^\s*\.amdhsa_kernel", txt[k]))
     body = txt[i:j]
     labels = {m.group(1): k for k, l in enumerate(body) if (m := re.match(r"^(\.LBB\w+):", l))}
-    best = None
+    loops = []
     for k, l in enumerate(body):
         m = re.match(r"\s+s_cbranch\w*\s+(\.LBB\w+)", l) or re.match(r"\s+s_branch\s+(\.LBB\w+)", l)
         if m and m.group(1) in labels and labels[m.group(1)] < k:
-            seg = body[labels[m.group(1)]:k + 1]
-            n_mfma = sum("v_mfma" in s for s in seg)
-            if n_mfma and (best is None or len(seg) < len(best)):
-                best = seg
+            loops.append((labels[m.group(1)], k + 1))
+    # the hot loop = the loop with the most MFMAs of its own (lines of nested loops -- the cold fallback of pass 2 -- excluded)
+    best, best_n = None, -1
+    for lo, hi in loops:
+        inner = [(a, b_) for a, b_ in loops if lo <= a and b_ <= hi and (a, b_) != (lo, hi)]
+        own = [body[k] for k in range(lo, hi) if not any(a <= k < b_ for a, b_ in inner)]
+        n = sum("v_mfma" in s_ for s_ in own)
+        if n > best_n:
+            best, best_n = own, n
     cnt = collections.Counter()
     for l in best:
         t = l.strip().split()
