@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak (same guide); the three GEMM-shaped products run as bf16 pieces
 N_SIMD = 256 * 4          # 256 CUs x 4 SIMDs
 VALU_CYCLES_PER_INST = 4  # one wave64 VALU instruction occupies its SIMD for 4 cycles (tools/ubench_valu.hip; packed f32 alike)
-PROFILE_ROUND = "r02"     # profiles/<round>_pmc_*.json hold the counter passes of the kernels of THIS build (tools/pmc_profile.py)
+PROFILE_ROUND = "r03"     # profiles/<round>_pmc_*.json hold the counter passes of the kernels of THIS build (tools/pmc_profile.py)
 
 
 def parse():
@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--no-defer-small", action="store_true", help="A/B: the small-parameter update as a launch of its own after pass 3 (Engine.defer_small = False)")
     ap.add_argument("--no-q-images", action="store_true", help="A/B: every pass-2 block splits Q into bf16 operands itself (Engine.q_images = False)")
     ap.add_argument("--cpu-rows", type=int, default=2400, help="rows of the same workload used for the bounded CPU baseline")
+    ap.add_argument("--cpu-steps", type=int, default=12, help="timed steps of the CPU baseline (min / median / max reported)")
     return ap.parse_args()
 
 
@@ -152,11 +153,14 @@ def cpu_baseline(eng, args, dev):
                sm[h.b1_off:h.b1_off + L.Hd], sm[h.wk_off[0]:h.wk_off[0] + K * L.Hd].reshape(K, L.Hd), sm[h.bk_off[0]:h.bk_off[0] + K])
     idx = np.arange(n)
     cp.step(G, idx[:b], 2e-3)                      # warm-up step (page-in, thread pool)
-    nsteps = max(1, n // b)
-    t0 = time.perf_counter()
-    for s in range(nsteps):
-        cp.step(G, idx[s * b:(s + 1) * b], 2e-3)
-    dt = time.perf_counter() - t0
+    nb = max(1, n // b)
+    nsteps = max(args.cpu_steps, 1)
+    times = []
+    for s in range(nsteps):                        # the sample's batches, cycled: every step does the full work of one batch
+        t0 = time.perf_counter()
+        cp.step(G, idx[(s % nb) * b:(s % nb + 1) * b], 2e-3)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.sum(times))
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -167,7 +171,10 @@ def cpu_baseline(eng, args, dev):
     except OSError:
         pass
     return {"value": nsteps * b * L.M / dt, "unit": "genotypes/s", "cores": cp.threads(), "kind": "port",
-            "sample": f"{nsteps} steps of {b} rows x {L.M} SNPs (first {n} rows of the same matrix), fused C/OpenMP port of the step, cpu={model}"}
+            "value_best_step": b * L.M / float(np.min(times)), "value_median_step": b * L.M / float(np.median(times)),
+            "step_s": {"min": float(np.min(times)), "median": float(np.median(times)), "max": float(np.max(times)), "n": nsteps},
+            "sample": f"{nsteps} timed steps (after 1 warm-up) of {b} rows x {L.M} SNPs cycling over the first {n} rows of the same matrix, "
+                      f"fused C/OpenMP port of the step (oracle/nadm_oracle_c.c), cpu={model}"}
 
 
 def main():
@@ -324,9 +331,18 @@ def main():
     dom = "decode_bce"
     fused = (snp or not ddp) and getattr(eng, "fused_adam", False)
     rows_b, m_loc = (gb, eng.M) if snp else (b, M)                       # snp: global batch x own SNP slice
-    x_passes = 1 if getattr(eng, "one_pass_heads", len(ks) == 1) else len(ks)   # heads served by ONE walk over X, or one walk each
-    alg_8d = x_passes * rows_b * m_loc / 4 + (36 if fused else 8) * m_loc * S
+    # X is priced ONCE whatever the number of heads (0.25 B per genotype and pass); the launches of a multi-head model
+    # walk X once per head, which is real traffic but not algorithmic -- reported separately as x_walks / bytes_incl_x_rewalks
+    x_walks = len(ks)
+    alg_8d = rows_b * m_loc / 4 + (36 if fused else 8) * m_loc * S
     alg_min = rows_b * m_loc / 4 + (24 if fused else 8) * m_loc * S
+    kp_sum = sum(int(k_) for k_ in eng.lay.kp)
+    composition = {                                                      # known bytes of the pass-2 launch(es) per access pattern (tools/pmc_profile.py)
+        "x_pieces_read": x_walks * rows_b * m_loc / 4.0,
+        "param_stream_read": (12 if fused else 4) * m_loc * kp_sum * 1.0 + (0 if fused else 0),
+        "batch_copy_write": rows_b * m_loc / 4.0 if getattr(eng, "gather_batch", False) else 0.0,
+        "dq_slab_write": sum(int(c_) * rows_b * int(k_) * 4.0 for c_, k_ in zip(eng.lay.dec_chunks, eng.lay.kp)),
+        "param_stream_write": (12 if fused else 4) * m_loc * kp_sum * 1.0}
     t_dom = kms[dom] * 1e-3
     wk = f"{rows_b}x{m_loc}x{'-'.join(map(str, ks))}:{'fused' if fused else 'unfused'}:{'loss' if with_loss else 'noloss'}"
     hbm = load_profile("pmc_hbm", wk) if rank == 0 else None
@@ -368,9 +384,16 @@ def main():
                    "clock_ramp_steps_untimed": n_ramp},
         "roofline": {"bound": "hbm", "limiter": "valu_issue", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_8d": achieved / HBM_PEAK_GBS, "frac_min": alg_min / t_dom / 1e9 / HBM_PEAK_GBS,
+                     # what the counters say the launch is bound by: the fraction of all SIMD-cycles of the launch spent issuing VALU and
+                     # matrix instructions (they do not overlap on a SIMD), and the VALU instruction rate against 1024 SIMDs x clk / 4
+                     "issue_frac": (issue["simd_valu_busy_frac"] + issue["simd_mfma_busy_frac"]) if issue and issue["simd_valu_busy_frac"] is not None else None,
+                     "valu_busy_frac": issue["simd_valu_busy_frac"] if issue else None, "mfma_busy_frac": issue["simd_mfma_busy_frac"] if issue else None,
+                     "valu_issue_rate_frac": issue["achieved_frac_of_valu_issue_peak"] if issue else None,
+                     "x_walks": x_walks, "bytes_incl_x_rewalks": alg_8d + (x_walks - 1) * rows_b * m_loc / 4,
                      "traffic": hbm["traffic_bytes_per_launch"] if hbm else None,
-                     "traffic_source": (f"profiles/{PROFILE_ROUND}_pmc_hbm.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, src_hash {hbm['src_hash']})"
+                     "traffic_source": (f"profiles/{PROFILE_ROUND}_pmc_hbm.json (separate --pmc passes of FETCH_SIZE and WRITE_SIZE; {hbm['correction']}; src_hash {hbm['src_hash']})"
                                         if hbm else None),
+                     "traffic_composition": composition,
                      "kernel_ms": kms, "alg_bytes_per_launch": alg_8d, "alg_bytes_min_per_launch": alg_min,
                      "alg_bytes_note": "frac/frac_8d: 2-bit pass over the batch + %d B per P parameter (SURVEY 8d rule; %s); frac_min: the same pass "
                                        "+ %d B per P parameter, the bytes the launch has to move" % (

@@ -9,5 +9,6 @@ from .layout import ModelLayout   # noqa: F401
 from .engine import Engine        # noqa: F401
 from .model import Q_P, NeuralAdmixture   # noqa: F401
 from .train import train          # noqa: F401
+from . import pack2bit            # noqa: F401  (the reference's native module by its own names: pack2bit.cu:144-147)
 
-__all__ = ["train", "Engine", "ModelLayout", "Q_P", "NeuralAdmixture"]
+__all__ = ["train", "Engine", "ModelLayout", "Q_P", "NeuralAdmixture", "pack2bit"]

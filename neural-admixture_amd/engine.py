@@ -86,10 +86,8 @@ class Engine:
         self._xg_key = None
         self.side_weights = device.type == "cuda"            # MLP weight-gradient partials as extra blocks of pass 3's launch
         self.fused_adam = device.type == "cuda"               # Adam in the epilogues of passes 2 and 3, see train_step
-        self.sync_tail_message = True                         # see train_step_ddp.send
         self.timers: Optional[dict] = None                    # {name: [(start, end) HIP events]} when a dict (bench.py)
         self.timed_names = None                               # restrict the timers to these kernel names (None = all)
-        self._n_cu: Optional[int] = None
         self.head_streams = 2                                 # decode_all: concurrent pass-2 launches of a multi-head model
         self._head_streams, self._head_events = None, None
         self._pending_ddp = None                              # (works, lr, grad_scale, step) of a deferred P update
@@ -292,22 +290,6 @@ class Engine:
         cuts = [min(M, (units * i // n_parts) * align) for i in range(n_parts)] + [M]
         return [(cuts[i], cuts[i + 1]) for i in range(n_parts) if cuts[i + 1] > cuts[i]]
 
-    def _round_ranges(self, chunk_snps: int, align: int, blocks_per_cu: int):
-        """Two ranges for one pass-2 launch pair: the first covers the FULL rounds of resident blocks (CUs x blocks per CU),
-        the second the partial last round.  A pass-2 block lives ~100 us, kernels on one stream do not overlap, so cutting
-        anywhere else would add a second under-filled tail; cutting here costs nothing and lets the all-reduce of the
-        first ~3/4 of a P gradient run under the last round."""
-        M = self.lay.M
-        if self._n_cu is None:
-            self._n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 256
-        slots = self._n_cu * blocks_per_cu
-        chunks = (M + chunk_snps - 1) // chunk_snps
-        full = (chunks // slots) * slots
-        m_cut = (full * chunk_snps) // align * align
-        if full == 0 or full == chunks or m_cut <= 0 or m_cut >= M:
-            return [(0, M)]
-        return [(0, m_cut), (m_cut, M)]
-
     def _adam_args(self, off_floats: int, fused) -> "AdamArgs":
         """nadm_adam_t for the rows of the big buffer that start at float offset ``off_floats``; fused = (lr, grad_scale) for an
         update in the kernel's epilogue with the current step count, or (lr, grad_scale, step) for the PREVIOUS step's update in
@@ -347,7 +329,7 @@ class Engine:
                 st = C.c_void_p(main.cuda_stream)
             csnps = int(lib.nadm_decode_chunk_snps(kp))
             align = csnps * 1024 // math.gcd(csnps, 1024)
-            for m0, m1 in (self._round_ranges(csnps, align, 3 if kp <= 8 else 2) if p_parts == "rounds" else self._snp_ranges(p_parts, align)):
+            for m0, m1 in self._snp_ranges(p_parts, align):
                 c0 = m0 // csnps
                 args = (C.c_void_p(self.xp.data_ptr() + m0 // 4), self.ld, ptr(idx), b, m1 - m0,
                         C.c_void_p(self._big.data_ptr() + (L.p_off[h] + m0 * kp) * fsz), kp,
@@ -492,7 +474,8 @@ class Engine:
 
     def train_step(self, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True) -> None:
         """One single-GPU step (neural_admixture.py:403-414 without the per-step host sync)."""
-        self.finish_ddp()                                     # (a data-parallel step before this one may have left updates pending)
+        if self._pending_ddp:                                 # a data-parallel step before this one left its P update to "the next pass 2":
+            self.finish_ddp()                                 # this step's pass 2 has no prologue update (V / small: this step's pass 1 takes them)
         if self.fused_adam:
             # Adam on P and V where their gradients are completed (epilogues of passes 2 and 3, nadm_*_step): same element
             # update, same bits as the separate launches; the big gradient buffer is not written in this mode
@@ -508,48 +491,32 @@ class Engine:
     def train_step_ddp(self, idx: torch.Tensor, b: int, lr: float, world: int, with_loss: bool = True,
                        defer_tail: bool = False) -> None:
         """Sample-sharded data-parallel step: local gradients -> all-reduce(sum) over RCCL -> Adam with
-        grad_scale 1/world (DDP's mean, neural_admixture.py:315-319).  Every piece of the flat gradient buffer is
-        all-reduced as soon as the kernel that completes it is enqueued, so the messages run underneath the remaining
-        kernels: P of head h under pass 2 of head h+1 (a single head: the part computed by the full rounds of blocks
-        under the last round), the last P piece under the MLP backward and pass 3; the small gradients and dV follow as
-        one message after pass 3.
+        grad_scale 1/world (DDP's mean, neural_admixture.py:315-319).  Message plan: every head's P gradient is handed to RCCL
+        when the pass-2 launch that completes it has been enqueued (asynchronous: it travels underneath the next head's pass 2,
+        the MLP backward and pass 3); the small gradients and dV follow as ONE message right behind pass 3, issued on the
+        compute stream itself -- it is the message the next step's pass 1 waits for, and a collective on the caller's stream
+        costs no cross-stream event hand-off (torch >= 2.8 runs async_op=False collectives there).
 
-        ``defer_tail``: the next step needs V and the small parameters at once (pass 1, MLP) but P only when its pass 2
-        starts.  The LAST P piece is therefore sent AFTER the small + dV message, and NO Adam launch follows the messages: the
-        update of ALL P pieces is left to the prologue of the next step's pass 2 (every block updates its own rows from the
-        all-reduced gradient before it uses them), the update of V to the prologue of the next step's pass 1, and the small
-        parameters' to side blocks of that launch -- or to finish_ddp().  Same arithmetic, same results; the parameter
-        accessors (big, small, V(), P(), ...) apply what is pending first."""
+        ``defer_tail`` (the trainer's and the bench's mode): NO Adam launch follows the messages.  The update of P is left to the
+        prologue of the next step's pass 2 (every block updates its own rows from the all-reduced gradient before it uses them),
+        the update of V to the prologue of the next step's pass 1, the small parameters' to side blocks of that launch -- or to
+        finish_ddp().  Same arithmetic, same results; the parameter accessors (big, small, V(), P(), ...) apply what is pending
+        first.
+
+        (r02 cut a single head's pass 2 in two launches at its last round of resident blocks to put 3/4 of dP on the wire
+        earlier: on a 1-rank group the second launch and the two extra stream hand-offs cost 41 us of a 0.48 ms step, and dP has
+        until the NEXT step's pass 2 to arrive anyway -- profiles/r03_ddp_plan.txt.)"""
         import torch.distributed as dist
         L = self.lay
         works, pieces = [], []
-        deferred = []
-        p_start, p_end = self._ns_pad + L.clamp_from, self._ns_pad + L.n_big
-
-        def send(lo, hi):
-            # P pieces: asynchronous, on the process group's own stream, underneath the kernels that follow.  The [small | dV]
-            # message is the one the next kernels (Adam on V, the next step's pass 1) wait for: issued synchronously it runs
-            # on the COMPUTE stream, right behind pass 3 and right in front of Adam, with no cross-stream event hand-off on
-            # either side (each costs 20-30 us on this stack; torch >= 2.8 runs async_op=False collectives on the caller's
-            # current stream).
-            on_compute_stream = self.sync_tail_message and lo < p_start
-            works.append(dist.all_reduce(self.gflat[lo:hi], op=dist.ReduceOp.SUM, async_op=not on_compute_stream))
-            pieces.append((lo, hi))
-
-        held = []                                             # defer_tail: the LAST P piece, not yet sent
+        p_start = self._ns_pad + L.clamp_from
 
         def reduce_piece(lo, hi):                             # gflat = [small | pad | V | P heads]
-            # Every piece goes to RCCL right when the kernel that completes it has been enqueued -- BEFORE the next kernel is:
-            # the collective waits on an event recorded at this point of the compute stream, so a piece handed over later
-            # would also wait for whatever was enqueued in between (the first part of a cut pass 2 must go out before the
-            # second part is launched, or it travels after it instead of underneath it).
-            if defer_tail and lo >= p_start and hi == p_end:
-                held.append((lo, hi))
-                return
-            send(lo, hi)
-            if held and lo < p_start:                         # first [small | dV] piece is on its way: now the last P piece
-                deferred.append(held[-1])
-                send(*held.pop())
+            # A piece goes to RCCL right when the kernel that completes it has been enqueued -- BEFORE the next kernel is: the
+            # collective waits on an event recorded at this point of the compute stream, so a piece handed over later would also
+            # wait for whatever was enqueued in between
+            works.append(dist.all_reduce(self.gflat[lo:hi], op=dist.ReduceOp.SUM, async_op=lo >= p_start))
+            pieces.append((lo, hi))
         self.forward(idx, b)
         # The previous step's P update (defer_tail): its all-reduced gradient lies in gbig; this step's pass 2 applies Adam + clamp
         # to every block's own P rows in its prologue (nadm_adam_t.when = 1), so the update costs no launch and no extra read of P.
@@ -561,9 +528,7 @@ class Engine:
                     w.wait()                                  # the compute stream waits for the messages, the host does not
             pre = (plr, pscale, pstep)
             self._pending_ddp = None
-        # message plan: one per head (a head's all-reduce runs under the next head's pass 2); a single head is cut where
-        # its last round of blocks starts (_round_ranges); then the small gradients + dV as one message
-        self.backward(idx, b, with_loss, on_grad_ready=reduce_piece, p_parts="rounds" if len(L.ks) == 1 else 1, v_parts=1, pre_adam=pre,
+        self.backward(idx, b, with_loss, on_grad_ready=reduce_piece, p_parts=1, v_parts=1, pre_adam=pre,
                       **({"side_weights": True} if self.side_weights else {}))
         scale = 1.0 / world
         self.step_count += 1

@@ -57,7 +57,7 @@ def loglikelihood_packed(engine, data_u8_cpu, P: np.ndarray, Q: np.ndarray, eps:
     # resident = the engine holds ALL samples in sample order AND all M SNPs.  A SnpShardedEngine holds every row but only
     # its own SNP slice (engine.M < P.shape[0]): its rows cannot be matched against the gathered [M_total, k] matrix.
     resident = (engine.xp is not None and engine.xp.shape[0] == N and not getattr(engine, "rows_are_sharded", False)
-                and engine.M == P.shape[0])
+                and engine.M == P.shape[0] and engine.device.type == "cuda")
     if resident and P.shape[1] <= 16 and engine.device.type == "cuda":
         return loglikelihood_hip(engine.xp, engine.M, P, Q, eps)
     if resident:

@@ -542,3 +542,17 @@ def test_bed_reader_applies_the_reference_biallelic_check(tmp_path):
                       (rng.choice(np.array([0, 1], dtype=np.uint8), size=(9, 21)), "no2")): # max == 1
         with pytest.raises(AssertionError, match="biallelic"):
             read_bed_packed(write(bad, name))
+
+
+def test_pack2bit_module_has_the_reference_names_and_refuses_misplaced_tensors():
+    """neural_admixture_amd.pack2bit = the reference's JIT-built module by its own names (pack2bit.cu:144-147); the device / shape
+    checks raise RuntimeError with the reference's TORCH_CHECK messages (pack2bit.cu:66-76,121-130) before anything touches a GPU."""
+    import inspect
+    from neural_admixture_amd import pack2bit
+    assert list(inspect.signature(pack2bit.pack2bit_cpu_to_gpu).parameters) == ["input_cpu", "output_gpu"]
+    assert list(inspect.signature(pack2bit.unpack2bit_gpu_to_gpu).parameters) == ["input_gpu", "output_gpu"]
+    g = torch.zeros((3, 10), dtype=torch.uint8)
+    with pytest.raises(RuntimeError, match="Output tensor must be on CUDA device"):
+        pack2bit.pack2bit_cpu_to_gpu(g, torch.zeros((3, 3), dtype=torch.uint8))
+    with pytest.raises(RuntimeError, match="Input tensor must be on CUDA device"):
+        pack2bit.unpack2bit_gpu_to_gpu(torch.zeros((3, 3), dtype=torch.uint8), g)

@@ -833,22 +833,21 @@ def test_ddp_step_on_rccl_world1_equals_plain_step():
         torch.cuda.synchronize()
         assert torch.equal(e1.big, e2.big) and torch.equal(e1.small, e2.small)
         assert e1.read_loss() == e2.read_loss()
-        # wide enough for the round-boundary cut of pass 2 (two P messages), multi-head (one message per head), and the
-        # deferred last P piece (sent after [small | dV], applied at the start of the next step / by finish_ddp)
-        # ... and the K > 8 (two k slots) and K > 16 (generic kernel: the update is a launch in front of it) variants of pass 2
+        # several rounds of pass-2 blocks, multi-head (one P message per head), and the deferred updates: P in the prologue of
+        # the next pass 2, V in the prologue of the next pass 1 + the small parameters in its side blocks (or finish_ddp / the
+        # accessors) ... and the K > 8 (two k slots) and K > 16 (generic kernel: the update is a launch in front of it) variants
         for M2, ks2 in ((300_000, [5]), (40_000, [2, 3, 4]), (6_000, [13]), (3_000, [20])):
             Gw = O.synth_genotypes(12, M2, 3, seed=5)
             pw = O.make_params(2, (rng.standard_normal((M2, 8)) / 500).astype(np.float32),
                                rng.uniform(0.1, 0.9, (sum(ks2), M2)).astype(np.float32), 64, ks2)
             ea, eb, ec = make_engine(Gw, pw, 12), make_engine(Gw, pw, 12), make_engine(Gw, pw, 12)
-            if M2 >= 300_000:
-                assert len(eb._round_ranges(256, 1024, 3)) == 2
             ix = torch.arange(12, dtype=torch.int32, device=dev)
             for _ in range(3):
                 ea.train_step(ix, 12, 2e-3, True)
                 eb.train_step_ddp(ix, 12, 2e-3, 1, True)
                 ec.train_step_ddp(ix, 12, 2e-3, 1, True, defer_tail=True)
-                assert ec._pending_ddp is not None and len(ec._pending_ddp[0]) >= 1     # P pieces left to the next pass 2 / finish_ddp
+                assert ec._pending_ddp is not None and len(ec._pending_ddp[0]) == len(ks2)   # one P message per head, left to the next pass 2 / finish_ddp
+                assert ec._pending_vs is not None                                           # V + small parameters: left to the next pass 1
             ec.finish_ddp()
             torch.cuda.synchronize()
             assert torch.equal(ea.big, eb.big) and torch.equal(ea.big, ec.big) and torch.equal(ea.small, ec.small)
@@ -1321,3 +1320,41 @@ def test_small_parameter_update_riding_in_the_next_pass1_equals_the_immediate_on
         e.load_params(p.V, np.concatenate([P.T for P in p.P], axis=0), small_vec(p))
     assert e1._pending_small is None and torch.equal(e1.small, e2.small) and float(e1.msmall.abs().max()) == 0.0
 
+
+
+@pytest.mark.gpu
+def test_pack2bit_module_runs_the_reference_call_sequence():
+    """The reference's own sequence around its native module, through neural_admixture_amd.pack2bit: allocate
+    ``packed_data [N, (M + 3) // 4]`` and pack the whole matrix once (model/train.py:121,126), then per batch gather packed rows
+    (DataLoader over the packed tensor, src/loaders.py:62-72), allocate ``unpacked_step [b, M]`` and unpack
+    (model/neural_admixture.py:404-406; the final-Q pass does the same with sequential batches of <= 1024, :374-378).  Bit-exact
+    against the layout fixture and the oracle's pack rule, caller-owned buffers, shape errors as RuntimeError."""
+    from neural_admixture_amd import pack2bit
+    dev = _dev()
+    d = np.load(f"{G}/pack_layout.npz")
+    rng = np.random.default_rng(5)
+    for Gm in (d["G"], d["G_hibits"], rng.integers(0, 4, size=(2311, 4099), dtype=np.uint8), rng.integers(0, 256, size=(9000, 37), dtype=np.uint8)):
+        N, M = Gm.shape
+        data = torch.from_numpy(np.ascontiguousarray(Gm))
+        packed_data = torch.empty((N, (M + 3) // 4), dtype=torch.uint8, device=dev)             # train.py:121
+        assert pack2bit.pack2bit_cpu_to_gpu(data, packed_data) is None                          # train.py:126
+        assert np.array_equal(packed_data.cpu().numpy(), O.pack2bit(Gm))
+        if Gm is d["G"]:
+            assert np.array_equal(packed_data.cpu().numpy(), d["packed"])
+        gen = torch.Generator().manual_seed(3)
+        loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(packed_data), batch_size=min(N, 800),
+                                             sampler=torch.utils.data.RandomSampler(range(N), generator=gen), drop_last=False)
+        seen = 0
+        gen2 = torch.Generator().manual_seed(3)
+        order = torch.randperm(N, generator=gen2).numpy()
+        for (x_step,) in loader:
+            unpacked_step = torch.empty((x_step.shape[0], M), dtype=torch.uint8, device=dev)   # neural_admixture.py:405
+            assert pack2bit.unpack2bit_gpu_to_gpu(x_step, unpacked_step) is None               # :406
+            rows = order[seen: seen + x_step.shape[0]]
+            assert np.array_equal(unpacked_step.cpu().numpy(), Gm[rows] & 3)
+            seen += x_step.shape[0]
+        assert seen == N
+    with pytest.raises(RuntimeError, match="Output tensor column dimension mismatch"):
+        pack2bit.pack2bit_cpu_to_gpu(torch.zeros((4, 9), dtype=torch.uint8), torch.empty((4, 2), dtype=torch.uint8, device=dev))
+    with pytest.raises(RuntimeError, match="Input tensor row dimension mismatch"):
+        pack2bit.unpack2bit_gpu_to_gpu(torch.empty((3, 3), dtype=torch.uint8, device=dev), torch.empty((4, 9), dtype=torch.uint8, device=dev))

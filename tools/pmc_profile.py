@@ -2,10 +2,15 @@
 """Counter passes of one bench step with rocprofv3 (--pmc only, kernel dispatch records; never combined with tracing
 domains) -> gpurun_out/<round>_pmc_hbm.{json,txt} and gpurun_out/<round>_pmc_sq.{json,txt}; copy them to profiles/.
 
-    python tools/pmc_profile.py [hbm] [sq] [-- bench flags]
+    python tools/pmc_profile.py [calib] [hbm] [sq] [-- bench flags]
 
-hbm: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they do not fit one pass on gfx950).  Corrected as
-     MI355X_MICROARCH.md "HBM" prescribes: FETCH_SIZE x2 for wide coalesced streams, WRITE_SIZE as counted.
+calib: what FETCH_SIZE / WRITE_SIZE count for the access patterns of pass 2 (tools/calib_fetch.hip: kernels with a known byte
+     count each) -> gpurun_out/<round>_pmc_calib.json = counted / known per pattern.  MI355X_MICROARCH.md "HBM": a wide coalesced
+     stream is tallied at half its bytes on gfx950, "other access widths and WRITE_SIZE are uncalibrated: calibrate on a known
+     byte count in your own access pattern".
+hbm: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (they do not fit one pass on gfx950), converted to bytes with the calibrated
+     ratios, weighted by the known composition of the launch's reads (X pieces / P, m, v streams) and writes (batch copy / dQ
+     slab / P, m, v streams); without a calibration file: FETCH_SIZE x2, WRITE_SIZE as counted (the guide's rule, r02).
 sq : issue counters of the pass-2 kernel in two passes.  SQ counters are recorded per shader engine (32 records per
      dispatch); the JSON holds per-launch TOTALS (sum over the shader engines).
 Both JSON files carry ``src_hash`` (sha256 of the kernel sources, bench.source_hash) and ``workload_key``: bench.py reports
@@ -55,6 +60,44 @@ def per_kernel(db):
     return {k: {n: (len(dd), sum(dd.values()) / len(dd)) for n, dd in d.items()} for k, d in agg.items()}
 
 
+def calibrate():
+    """counted / known bytes per access pattern -> <round>_pmc_calib.json"""
+    exe = os.path.join(ROOT, "tools", "abl", "calib")
+    if not os.path.exists(exe):
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", os.path.join(ROOT, "tools", "calib_fetch.hip"), "-o", exe], check=True)
+    out = {"round": RND, "unit_note": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; ratio = counted KiB * 1024 / known bytes of the launch"}
+    known = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = f"/tmp/pmc_calib_{c}"
+        shutil.rmtree(d, ignore_errors=True)
+        r = subprocess.run(["rocprofv3", "--pmc", c, "-d", d, "-o", "run", "--", exe], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                           capture_output=True, text=True)
+        m = re.search(r"known_bytes (.*)", r.stdout)
+        toks = m.group(1).split()
+        known = {toks[i]: int(toks[i + 1]) for i in range(0, len(toks), 2)}
+        db = [os.path.join(p_, f) for p_, _, fs in os.walk(d) for f in fs if f.endswith(".db")][0]
+        for k, dd in per_kernel(db).items():
+            name = next((n for n in known if n in k), None)
+            if name and c in dd:
+                out.setdefault(name, {"known_bytes": known[name]})[c.lower() + "_kib"] = dd[c][1]
+    for name, d in out.items():
+        if isinstance(d, dict) and "known_bytes" in d:
+            key = "fetch_size_kib" if name.endswith("read") else "write_size_kib"
+            d["ratio"] = d.get(key, 0.0) * 1024.0 / d["known_bytes"]
+    json.dump(out, open(os.path.join(OUT, f"{RND}_pmc_calib.json"), "w"), indent=1)
+    print(json.dumps(out))
+    return out
+
+
+def load_calib():
+    for d in (OUT, os.path.join(ROOT, "profiles")):
+        try:
+            return json.load(open(os.path.join(d, f"{RND}_pmc_calib.json")))
+        except (OSError, ValueError):
+            pass
+    return None
+
+
 def workload_key(line):
     return line["roofline"]["workload_key"]
 
@@ -68,6 +111,9 @@ def main():
     what = argv or ["hbm", "sq"]
     os.makedirs(OUT, exist_ok=True)
     src = bench.source_hash()
+    if "calib" in what:
+        calibrate()
+        what = [w for w in what if w != "calib"]
     if "hbm" in what:
         txt, vals, line = [], {}, None
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -83,12 +129,28 @@ def main():
         f = sum(vals[k]["FETCH_SIZE"][1] for k in dec)
         w = sum(vals[k]["WRITE_SIZE"][1] for k in dec)
         nl = max(1, len(dec))
+        cal = load_calib()
+        rl = line["roofline"]
+        comp = rl.get("traffic_composition")       # known bytes of the launch per access pattern (bench.py)
+        if cal and comp:
+            rd = {"rows64_read": comp["x_pieces_read"], "stream_read": comp["param_stream_read"]}
+            wr = {"rows64_write": comp["batch_copy_write"], "slab_write": comp["dq_slab_write"], "stream_write": comp["param_stream_write"]}
+            r_read = sum(v * cal[k]["ratio"] for k, v in rd.items()) / max(1.0, sum(rd.values()))
+            r_write = sum(v * cal[k]["ratio"] for k, v in wr.items()) / max(1.0, sum(wr.values()))
+            traffic = f * 1024.0 / r_read + w * 1024.0 / r_write
+            corr = ("counted KiB x 1024 / (counted-per-known-byte ratio of the launch's own access patterns, tools/calib_fetch.hip -> "
+                    f"{RND}_pmc_calib.json): reads {r_read:.3f} (X pieces {cal['rows64_read']['ratio']:.3f}, parameter streams {cal['stream_read']['ratio']:.3f}), "
+                    f"writes {r_write:.3f} (batch copy {cal['rows64_write']['ratio']:.3f}, dQ slab {cal['slab_write']['ratio']:.3f}, parameter streams "
+                    f"{cal['stream_write']['ratio']:.3f}); all pass-2 launches of one step summed")
+            known = {"reads": rd, "writes": wr, "expected_fetch_kib": sum(v * cal[k]["ratio"] for k, v in rd.items()) / 1024.0,
+                     "expected_write_kib": sum(v * cal[k]["ratio"] for k, v in wr.items()) / 1024.0}
+        else:
+            traffic, known = (2 * f + w) * 1024.0, None
+            corr = ("FETCH_SIZE x2 (gfx950 tallies the 128 B requests of wide coalesced streams at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as "
+                    "counted; all pass-2 launches of one step summed (no calibration file)")
         out = {"round": RND, "src_hash": src, "workload_key": workload_key(line), "kernels": [k[:80] for k in dec],
-               "fetch_size_kib_raw": f, "write_size_kib_raw": w,
-               "correction": "FETCH_SIZE x2 (gfx950 tallies the 128 B requests of wide coalesced streams at 64 B, MI355X_MICROARCH.md HBM section; "
-                             "calibrated in round 1 on the stand-alone Adam launch: 4 x 32 MiB read, 62.6 MiB counted); WRITE_SIZE as counted; "
-                             "all pass-2 launches of one step summed",
-               "traffic_bytes_per_launch": (2 * f + w) * 1024.0, "launches_per_step": nl,
+               "fetch_size_kib_raw": f, "write_size_kib_raw": w, "correction": corr, "known_composition": known,
+               "traffic_bytes_per_launch": traffic, "launches_per_step": nl,
                "alg_bytes_per_launch_8d": line["roofline"]["alg_bytes_per_launch"], "alg_bytes_min_per_launch": line["roofline"]["alg_bytes_min_per_launch"]}
         json.dump(out, open(os.path.join(OUT, f"{RND}_pmc_hbm.json"), "w"), indent=1)
         open(os.path.join(OUT, f"{RND}_pmc_hbm.txt"), "w").write(
