@@ -340,7 +340,7 @@ def main():
     composition = {                                                      # known bytes of the pass-2 launch(es) per access pattern (tools/pmc_profile.py)
         "x_pieces_read": x_walks * rows_b * m_loc / 4.0,
         "param_stream_read": (12 if fused else 4) * m_loc * kp_sum * 1.0 + (0 if fused else 0),
-        "batch_copy_write": rows_b * m_loc / 4.0 if getattr(eng, "gather_batch", False) else 0.0,
+        "batch_copy_write": rows_b * m_loc / 4.0 if eng._gather() else 0.0,
         "dq_slab_write": sum(int(c_) * rows_b * int(k_) * 4.0 for c_, k_ in zip(eng.lay.dec_chunks, eng.lay.kp)),
         "param_stream_write": (12 if fused else 4) * m_loc * kp_sum * 1.0}
     t_dom = kms[dom] * 1e-3

@@ -80,7 +80,10 @@ class Engine:
         # optional per-kernel timing (bench.py): name -> list of (start_event, end_event) on the launch stream
         # pass 2 writes the batch's gathered rows back to back into xg and pass 3 reads them from there (include/nadm.h,
         # nadm_decode_bce_gather): same bytes, same results, no scattered reads over the resident matrix in pass 3
-        self.gather_batch = device.type == "cuda"
+        # ... worth it only when the resident matrix is large: at 12.5 GB pass 3 missed the per-CU translation cache on 13 % of its
+        # scattered requests (68 us instead of 52, profiles/r01_pmc_tlb.txt), at 2.5 GB it did not -- below GATHER_MIN_BYTES the
+        # copy (b * ld bytes written per step) is skipped and pass 3 gathers the rows itself.  None = decide by the resident size.
+        self.gather_batch: Optional[bool] = None
         self._xg: Optional[torch.Tensor] = None
         self._iota: Optional[torch.Tensor] = None
         self._xg_key = None
@@ -92,6 +95,13 @@ class Engine:
         self._head_streams, self._head_events = None, None
         self._pending_ddp = None                              # (works, lr, grad_scale, step) of a deferred P update
         self._pending_vs = None                               # (lr, grad_scale, step) of a deferred update of V and the small parameters
+
+    GATHER_MIN_BYTES = 4 << 30
+
+    def _gather(self) -> bool:
+        if self.gather_batch is not None:
+            return bool(self.gather_batch)
+        return self.device.type == "cuda" and self.xp is not None and self.xp.numel() > self.GATHER_MIN_BYTES
 
     def _xg_buf(self) -> torch.Tensor:
         if self._xg is None:
@@ -337,7 +347,7 @@ class Engine:
                         C.c_void_p(self.gbig.data_ptr() + (L.p_off[h] + m0 * kp) * fsz),
                         C.c_void_p(self.dqpart.data_ptr() + (dq_offs[h] + c0 * b * kp) * fsz),
                         C.c_void_p(self.losspart.data_ptr() + (loss_offs[h] + c0) * fsz), (1 if self.p_unit else 3) if with_loss else 0)
-                xg = C.c_void_p(self._xg_buf().data_ptr() + m0 // 4) if (h == 0 and self.gather_batch) else None
+                xg = C.c_void_p(self._xg_buf().data_ptr() + m0 // 4) if (h == 0 and self._gather()) else None
                 if self.q_images and self._qimg_b == b and kp <= 16:      # Q operands ready-made by this step's MLP forward
                     check(lib.nadm_decode_bce_images(*args, xg, C.byref(self._adam_args(L.p_off[h] + m0 * kp, fused_adam)) if fused_adam is not None else None,
                                                      C.c_void_p(self.qimg.data_ptr() + h * self._qimg_head), st), "decode_bce_images")
@@ -355,7 +365,7 @@ class Engine:
                 main.wait_event(self._head_events[j + 1])
             st = _stream()
         if ev: ev[1].record()
-        self._xg_key = (idx.data_ptr(), b) if self.gather_batch else None   # pass 3 of THIS step, same batch: may read the copy
+        self._xg_key = (idx.data_ptr(), b) if self._gather() else None   # pass 3 of THIS step, same batch: may read the copy
         n_loss = L.n_loss
         if self.labels is not None and supervised:
             check(lib.nadm_supervised_ce(ptr(self.Q), L.SP, L.ks[0], L.kp[0], ptr(self.labels), ptr(idx), b, self.n_classes,

@@ -113,6 +113,11 @@ def test_one_step_against_reference_fixture(name):
     idx = torch.arange(b, dtype=torch.int32, device=e.device)
     if "labels" in d.files:                 # supervised term: BCE + 100 * CE(sum) on head 0's softmax output
         e.set_labels(d["labels"], ks[0], 100.0)
+    # one_step_edge plants P rows at exactly 0 and 1: r == 0 / r == 1 entries divide by the 1e-12 floor (single gradient elements of
+    # 5e11, SURVEY.md section 7 "edge semantics").  dP is still compared at 2e-5 of its maximum; the gradients BEHIND dQ (MLP, V) sum
+    # such elements with others 12 orders of magnitude smaller, so their fp32 value depends on the summation order at the 1e-3
+    # level (the fp32 oracle itself is 1e-3 from its float64 run there): 3e-3.  After Adam those entries move by lr whatever the
+    # gradient's size, and an entry whose r sits on the rounding boundary of the clamp mask may or may not see the floor: P at 1e-4.
     edge = name.endswith("edge")
     gtol = 3e-3 if edge else 2e-5
     for s in range(3):
@@ -519,18 +524,20 @@ def test_trajectory_demo_c1_vs_reference(ep):
         assert abs(ll - float(d["hi_e5_loglik"])) / abs(float(d["hi_e5_loglik"])) < 1e-4
 
 
-@pytest.mark.parametrize("b,M,K", [(800, 500_000, 8),      # configs[3] / the bench workload
-                                   (800, 600_000, 7),      # configs[1]: 1000-Genomes scale, single head K=7
-                                   (104, 600_000, 7)])     # ... and its partial last batch (2504 = 3 * 800 + 104)
-def test_full_width_against_torch_fp32_on_device(b, M, K):
+@pytest.mark.parametrize("b,M,ks", [(800, 500_000, [8]),                    # configs[3] / the bench workload
+                                    (800, 600_000, [7]),                    # configs[1]: 1000-Genomes scale, single head K=7
+                                    (104, 600_000, [7]),                    # ... and its partial last batch (2504 = 3 * 800 + 104)
+                                    (64, 1_000_000, [16]),                  # configs[4] width: M = 1M, K = 16 (two k slots in pass 2)
+                                    (104, 600_000, list(range(2, 11)))])    # configs[2]: heads K = 2..10 over the 1000-Genomes width
+def test_full_width_against_torch_fp32_on_device(b, M, ks):
     """BASELINE-scale width: the three passes against a plain torch fp32 / fp64 computation on the same GPU from the
-    unpacked matrix (independent code path), plus linearity."""
+    unpacked matrix (independent code path: every configs[] width meets something other than itself), plus linearity."""
     dev = _dev()
     import neural_admixture_amd as na
     from neural_admixture_amd._lib import lib, check, ptr
     import ctypes as C
-    Cc, Hd = 8, 1024
-    e = na.Engine(M, Cc, Hd, [K], dev, b)
+    Cc, Hd, K = 8, 1024, max(ks)
+    e = na.Engine(M, Cc, Hd, ks, dev, b)
     g = torch.Generator(device="cpu").manual_seed(0)
     Qt = torch.distributions.Dirichlet(torch.full((K,), 0.2)).sample((b,)).float().to(dev)
     Fq = (0.5 * torch.rand(K, M, generator=g)).clamp(0.005, 0.5).to(dev)
@@ -542,25 +549,30 @@ def test_full_width_against_torch_fp32_on_device(b, M, K):
     cnt = torch.bincount(Gd.reshape(-1).to(torch.int64), minlength=4).cpu().numpy() / (b * M)
     assert 0.005 < cnt[3] < 0.02 and cnt[0] > 0.3 and cnt[1] > 0.05          # generator sanity
     X = torch.where(Gd == 3, torch.zeros((), device=dev), Gd.float() / 2)
+    del Gd
     V = (torch.randn(M, Cc, generator=g) / M ** 0.5).numpy()
-    P = torch.rand(K, M, generator=g).mul(0.9).add(0.05).numpy()
-    small = na.model.init_encoder_weights(42, Cc, Hd, [K])
+    P = torch.rand(sum(ks), M, generator=g).mul(0.9).add(0.05).numpy()
+    small = na.model.init_encoder_weights(42, Cc, Hd, ks)
     e.load_params(V, P, small)
     idx = torch.arange(b, dtype=torch.int32, device=dev)
     e.forward(idx, b)
     e.backward(idx, b, True)
     torch.cuda.synchronize()
-    Vd, Pd = e.V().contiguous(), e.P(0).contiguous()
+    Vd = e.V().contiguous()
     Z_ref = X.double() @ Vd.double()
     assert (e.Z[: b * Cc].view(b, Cc).double() - Z_ref).abs().max().item() < 1e-5 * Z_ref.abs().max().item() + 1e-6
-    Q = e.Q[: b * e.lay.SP].view(b, e.lay.SP)[:, :K].contiguous()
-    Rraw = Q @ Pd.T
-    R = Rraw.clamp(0, 1)
-    loss_ref = torch.nn.functional.binary_cross_entropy(R, X, reduction="sum").double().item()
+    loss_ref = 0.0
+    for h, k in enumerate(ks):
+        Pd = e.P(h).contiguous()
+        Q = e.Q[: b * e.lay.SP].view(b, e.lay.SP)[:, e.lay.qoff[h]: e.lay.qoff[h] + k].contiguous()
+        Rraw = Q @ Pd.T
+        R = Rraw.clamp(0, 1)
+        loss_ref += torch.nn.functional.binary_cross_entropy(R, X, reduction="sum").double().item()
+        dR = (R - X) / ((1 - R) * R).clamp_min(1e-12) * ((Rraw >= 0) & (Rraw <= 1))
+        dP_ref = (dR.double().T @ Q.double())
+        assert (e.gP(h).double() - dP_ref).abs().max().item() < 2e-5 * dP_ref.abs().max().item(), h
+        del Rraw, R, dR, dP_ref
     assert abs(e.read_loss()[1] - loss_ref) / loss_ref < 2e-5
-    dR = (R - X) / ((1 - R) * R).clamp_min(1e-12) * ((Rraw >= 0) & (Rraw <= 1))
-    dP_ref = (dR.double().T @ Q.double())
-    assert (e.gP(0).double() - dP_ref).abs().max().item() < 2e-5 * dP_ref.abs().max().item()
     dZ = e.dZ[: b * Cc].view(b, Cc)
     dV_ref = X.double().T @ dZ.double()
     assert (e.gV().double() - dV_ref).abs().max().item() < 2e-5 * dV_ref.abs().max().item()
@@ -638,9 +650,16 @@ def test_train_boundary_supervised_vs_reference():
     # the boundary call itself
     Ps, Qs, model = na.train(int(d["epochs"]), int(d["b"]), float(d["lr"]), K, int(d["seed"]), data, dev, 1, Hd, True,
                              d["Vt"], pops, None, None, 8)
-    selfQ = mx(d["med_Q"], d["hi_Q"])
+    # Tolerance of the end-of-run Q: the supervised start (class means of the RAW codes, values up to 3, train.py:82) saturates
+    # most of R at the clamp, where one rounding decides whether an element sees the 1e-12 floor (gradients of 1e3 .. 1e12 into
+    # Adam).  The reference's own fp32 and bf16 runs of this fixture therefore end 0.135 apart in Q (max; 0.058 mean) after its
+    # 9 steps although their step-0 losses agree to 4e-6 -- there is no tighter yardstick than that self-distance for any two
+    # fp32 summation orders.  Asserted: within twice the reference's distance from itself (max) and within it on average; the
+    # rounding-level pins are the step-0 loss above (5e-6) and one_step_supervised (gradients 2e-5, test_one_step_...).
+    selfQ, selfQ_mean = mx(d["med_Q"], d["hi_Q"]), float(np.abs(d["med_Q"] - d["hi_Q"]).mean())
     assert Ps[0].shape == (M, K) and Qs[0].shape == (N, K)
-    assert mx(Qs[0], d["hi_Q"]) < max(2 * selfQ, 0.05)
+    assert mx(Qs[0], d["hi_Q"]) < 2 * selfQ, (mx(Qs[0], d["hi_Q"]), selfQ)
+    assert float(np.abs(Qs[0] - d["hi_Q"]).mean()) < selfQ_mean, (float(np.abs(Qs[0] - d["hi_Q"]).mean()), selfQ_mean)
     assert float(Ps[0].min()) >= 0.0 and float(Ps[0].max()) <= 1.0
     with pytest.raises(AssertionError):                      # train.py:79
         na.train(1, 100, 2e-3, K + 1, 1, data, dev, 1, Hd, True, d["Vt"], pops, None, None, 8)
@@ -1105,8 +1124,8 @@ def test_pass2_gather_byproduct_and_pass3_on_the_compact_copy(K):
     assert torch.equal(dv[0], dv[1])
     # whole steps: engine with the by-product on (default on a GPU) vs off, two steps, bit-identical state
     e1, e2 = make_engine(Gm, p, b), make_engine(Gm, p, b)
-    assert e1.gather_batch
-    e2.gather_batch = False
+    assert e1.gather_batch is None and not e1._gather()          # a small resident matrix: no copy by default (GATHER_MIN_BYTES)
+    e1.gather_batch, e2.gather_batch = True, False
     for _ in range(2):
         e1.train_step(idx, b, 2e-3, True)
         e2.train_step(idx, b, 2e-3, True)
