@@ -686,11 +686,13 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast
 //              twice the term of a genotype is c*log d + (2-c)*log(1-d) = log(u*v), (u, v) = (1-d, 1-d), (d, 1-d), (d, d): the
 //              factors are picked with two 0/1 selectors s1 = [c >= 1], s2 = [c == 2] (two more v_cvt_scalef32_pk_f32_fp4 of the
 //              same code word, masked), u = o + s1*(d - o), and the four factors of a pair are multiplied before the one v_log.
-//              Every factor is either 0 or >= 6e-8 for 1-d and arbitrary for d; the product of four underflows or is 0 exactly
-//              when a clamp of the reference could be active (a zero factor) or d is tiny (< ~1e-10) -- then, and only then, the
-//              logarithm is -inf and the wave recomputes the loss of that tile pair with the exact form (cold branch in the
-//              loop, decode_bce_bf16_kernel).  Same value up to the rounding of three multiplications per pair (relative 2e-7
-//              on a term; the loss tolerance is 5e-6 on the sum).
+//              A factor 1-d is either 0 or >= 6e-8, a factor d is arbitrary; the product of four is 0 or underflows exactly when a
+//              clamp of the reference could be active (a zero factor) or d is tiny (two d < 1e-10 under genotype 2) -- then, and
+//              only then, the logarithm is -inf and the wave recomputes the loss of that tile pair with the exact form (cold
+//              branch in the loop, decode_bce_bf16_kernel).  Same value up to the rounding of three multiplications per pair
+//              (relative 2e-7 on a term; the loss tolerance is 5e-6 on the sum).  (Multiplying the products of the lane's two
+//              pairs of a tile as well -- one logarithm per four genotypes -- measured 250 us against 246: the longer dependent
+//              chain in front of the logarithm costs what the logarithm saves.)
 constexpr float LOSS_LOG_SHIFT = 20.f;                    // log2 of the scale of the exact form
 __device__ __forceinline__ f32x2_t two_max0(const f32x2_t v) {                 // 2 * max(v, 0), exact.  As asm: the compiler would pair
     f32x2_t r;                                                                 // the two adds into a v_pk_add_f32, which has no |abs|
@@ -730,7 +732,7 @@ __device__ __forceinline__ void bce_loss_prod2(const f32x2_t d, const f32x2_t om
     const f32x2_t v = __builtin_elementwise_fma(s2, e2, o2);                    // 2d if c == 2 else 2(1-r)
     const f32x2_t tt = u * v;
     acc += __builtin_amdgcn_logf(tt.x * tt.y);
-    asm volatile("" : "+v"(acc));
+    asm volatile("" : "+v"(acc));             // pin the accumulation here (see bce_loss_exact2)
 }
 
 // Two genotypes -> two floats in ONE instruction: a nibble 00cc read as FP4 (E2M1) is exactly cc/2 (0, .5, 1), so
@@ -1021,7 +1023,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                     qb1[s2] = s_qr[st][0][lane];
                     qb2[s2] = s_qr[st][1][lane];
                 }
-                float it_acc = 0.f;                                    // fast loss of this tile pair: sum of log2(16 * product of 4 factors)
+                float it_acc = 0.f;                                    // fast loss of this tile pair: sum of log2(16 * product of the 4 factors of a pair)
                 const uint4 qd1 = s_qd[p][0][lane];
                 uint4 qd2 = make_uint4(0, 0, 0, 0);
                 if constexpr (W) qd2 = s_qd[p][1][lane];
@@ -1386,10 +1388,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     {
         constexpr int ROW4 = CP / 4;
         const int64_t m0 = chunk * EB_CHUNK_SNPS;
-        // (a loop of load-update-store trips: four HBM round trips per block at the end of a single-round kernel.  Issuing the
-        // loads of all trips first, or one trip ahead, makes the register allocator spill the main loop's accumulators to
-        // scratch at this kernel's 128-VGPR budget; as a non-inlined helper the call made the kernel 15x slower; in pass 2,
-        // whose blocks overlap each other's epilogues, batching the loads changed nothing.  Left as a plain loop.)
+        // (a loop of load-update-store trips at the end of a single-round kernel: +11 us against the launch that only writes dV.
+        // r03 measured the loop with the loads of 1 / 2 / 4 trips issued together (no spills in that form): 63.7 / 63.1 / 65.4 us --
+        // it is not the round trips that cost, profiles/r03_ablations.txt.  Left as a plain loop.)
         for (int e = tid; e < EB_CHUNK_SNPS * ROW4; e += 256) {
             const int64_t m = m0 + e / ROW4;
             if (m < M) {
