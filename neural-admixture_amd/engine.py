@@ -77,10 +77,9 @@ class Engine:
         self.xp: Optional[torch.Tensor] = None          # packed genotypes [rows, ld]
         self.step_count = 0
         self.p_unit = True                              # every P entry in [0, 1] (see load_params)
-        # optional per-kernel timing (bench.py): name -> list of (start_event, end_event) on the launch stream
-        # pass 2 writes the batch's gathered rows back to back into xg and pass 3 reads them from there (include/nadm.h,
-        # nadm_decode_bce_gather): same bytes, same results, no scattered reads over the resident matrix in pass 3
-        # ... worth it only when the resident matrix is large: at 12.5 GB pass 3 missed the per-CU translation cache on 13 % of its
+        # pass 2 can write the batch's gathered rows back to back into xg for pass 3 to read from there (include/nadm.h,
+        # nadm_decode_bce_gather): same bytes, same results, no scattered reads over the resident matrix in pass 3 -- worth it
+        # only when the resident matrix is large: at 12.5 GB pass 3 missed the per-CU translation cache on 13 % of its
         # scattered requests (68 us instead of 52, profiles/r01_pmc_tlb.txt), at 2.5 GB it did not -- below GATHER_MIN_BYTES the
         # copy (b * ld bytes written per step) is skipped and pass 3 gathers the rows itself.  None = decide by the resident size.
         self.gather_batch: Optional[bool] = None
@@ -89,7 +88,7 @@ class Engine:
         self._xg_key = None
         self.side_weights = device.type == "cuda"            # MLP weight-gradient partials as extra blocks of pass 3's launch
         self.fused_adam = device.type == "cuda"               # Adam in the epilogues of passes 2 and 3, see train_step
-        self.timers: Optional[dict] = None                    # {name: [(start, end) HIP events]} when a dict (bench.py)
+        self.timers: Optional[dict] = None                    # per-kernel timing (bench.py): {name: [(start, end) HIP events on the launch stream]}
         self.timed_names = None                               # restrict the timers to these kernel names (None = all)
         self.head_streams = 2                                 # decode_all: concurrent pass-2 launches of a multi-head model
         self._head_streams, self._head_events = None, None
