@@ -161,7 +161,7 @@ struct SmallSide {
     const float* part;
     float *out, *p, *m, *v;
     int splits, n;
-    float step_size, bc2_sqrt, grad_scale;
+    float step_size, inv_bc2, grad_scale;
 };
 
 template <int CP>
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
         }
         ss.out[e] = a;
         if (ss.m != nullptr) {
-            ss.p[e] = adam_element(pq, a, mq, vq, ss.step_size, ss.bc2_sqrt, ss.grad_scale, false);
+            ss.p[e] = adam_element(pq, a, mq, vq, ss.step_size, ss.inv_bc2, ss.grad_scale, false);
             ss.m[e] = mq; ss.v[e] = vq;
         }
         return;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
                     float pp[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w}, gg[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
                     float mm[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w}, vv[4] = {s4[u].x, s4[u].y, s4[u].z, s4[u].w};
 #pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) pp[q4] = adam_element(pp[q4], gg[q4], mm[q4], vv[q4], adv.step_size, adv.bc2_sqrt, adv.grad_scale, false);
+                    for (int q4 = 0; q4 < 4; ++q4) pp[q4] = adam_element(pp[q4], gg[q4], mm[q4], vv[q4], adv.step_size, adv.inv_bc2, adv.grad_scale, false);
                     vst[j0 + u] = make_float4(pp[0], pp[1], pp[2], pp[3]);
                     const int e = 4 * (lane + 64 * (j0 + u));
                     if (slice0 + e / CP < M) {                // (a clamped row would be updated twice)
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
             if (m < M) {
                 const int64_t o = m * KP + 4 * (e % ROW4P);
                 if (ad.m != nullptr && ad.pre)
-                    adam_float4(P + o, *reinterpret_cast<const float4*>(dP + o), ad.m + o, ad.v + o, ad.step_size, ad.bc2_sqrt, ad.grad_scale, true);
+                    adam_float4(P + o, *reinterpret_cast<const float4*>(dP + o), ad.m + o, ad.v + o, ad.step_size, ad.inv_bc2, ad.grad_scale, true);
                 p4 = *reinterpret_cast<const float4*>(P + o);
             }
             reinterpret_cast<float4*>(s_p)[e] = p4;
@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
                 const int64_t o = m * KP + 4 * (e % ROW4);
                 // single-GPU step: the gradient of these rows is final here and nothing else in the step reads P again, so
                 // Adam + clamp is applied on the spot (no dP round trip through HBM, no separate launch for the P matrices)
-                if (ad.m != nullptr && !ad.pre) adam_float4(P + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.bc2_sqrt, ad.grad_scale, true);
+                if (ad.m != nullptr && !ad.pre) adam_float4(P + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.inv_bc2, ad.grad_scale, true);
                 else *reinterpret_cast<float4*>(dP + o) = g4;
             }
         }
@@ -1396,7 +1396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (m < M) {
                 const float4 g4 = *reinterpret_cast<const float4*>(s_dv + 4 * e);
                 const int64_t o = m * CP + 4 * (e % ROW4);
-                if (ad.m != nullptr) adam_float4(Vrw + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.bc2_sqrt, ad.grad_scale, false);
+                if (ad.m != nullptr) adam_float4(Vrw + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.inv_bc2, ad.grad_scale, false);
                 else *reinterpret_cast<float4*>(dV + o) = g4;
             }
         }
@@ -1410,7 +1410,7 @@ constexpr int dec_spl(int kp) { return kp <= 8 ? 8 : (kp <= 16 ? 4 : (kp <= 32 ?
 __global__ __launch_bounds__(256) void adam_range_kernel(float* __restrict__ p, const float* __restrict__ g, AdamFused ad, int64_t n, int clamp01) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
         float mq = ad.m[e], vq = ad.v[e];
-        p[e] = adam_element(p[e], g[e], mq, vq, ad.step_size, ad.bc2_sqrt, ad.grad_scale, clamp01 != 0);
+        p[e] = adam_element(p[e], g[e], mq, vq, ad.step_size, ad.inv_bc2, ad.grad_scale, clamp01 != 0);
         ad.m[e] = mq; ad.v[e] = vq;
     }
 }
@@ -1573,7 +1573,7 @@ static int adam_fused_args(const nadm_adam_t* adam, const char* who, AdamFused* 
     out->m = adam->m; out->v = adam->v; out->grad_scale = adam->grad_scale;
     out->pre = adam->when == 1 ? 1 : 0;
     if (adam->when != 0 && adam->when != 1) return fail("nadm_*_step: nadm_adam_t.when is 0 (epilogue) or 1 (prologue, pass 2 only)");
-    adam_scalars(adam->lr, adam->step, &out->step_size, &out->bc2_sqrt);
+    adam_scalars(adam->lr, adam->step, &out->step_size, &out->inv_bc2);
     return 0;
 }
 
@@ -1592,7 +1592,7 @@ extern "C" int nadm_encode_fwd_small(const uint8_t* xp, int64_t ld, const int32_
         if (!adam->m || !adam->v || !small) return fail("nadm_encode_fwd_small: Adam state / parameters are NULL");
         if (adam->step < 1 || adam->when != 0) return fail("nadm_encode_fwd_small: Adam step is 1-based, when must be 0");
         ss.m = adam->m; ss.v = adam->v; ss.grad_scale = adam->grad_scale;
-        adam_scalars(adam->lr, adam->step, &ss.step_size, &ss.bc2_sqrt);
+        adam_scalars(adam->lr, adam->step, &ss.step_size, &ss.inv_bc2);
     }
     return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0u, ss);
 }
@@ -1614,7 +1614,7 @@ extern "C" int nadm_encode_fwd_step(const uint8_t* xp, int64_t ld, const int32_t
             if (!adam_small->m || !adam_small->v || !small) return fail("nadm_encode_fwd_step: Adam state / parameters of the small update are NULL");
             if (adam_small->step < 1 || adam_small->when != 0) return fail("nadm_encode_fwd_step: small update: step is 1-based, when must be 0");
             ss.m = adam_small->m; ss.v = adam_small->v; ss.grad_scale = adam_small->grad_scale;
-            adam_scalars(adam_small->lr, adam_small->step, &ss.step_size, &ss.bc2_sqrt);
+            adam_scalars(adam_small->lr, adam_small->step, &ss.step_size, &ss.inv_bc2);
         }
     }
     return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0u, ss, V, dV, adv);

@@ -24,12 +24,12 @@ inline int check_launch(const char* what) {
     return 0;
 }
 
-// step-dependent scalars of the Adam update (bias corrections folded in), as nadm_adam has always computed them
-inline void adam_scalars(float lr, int step, float* step_size, float* bc2_sqrt) {
+// step-dependent scalars of the Adam update (bias corrections folded in): step_size = lr / (1 - b1^t), inv_bc2 = 1 / sqrt(1 - b2^t)
+inline void adam_scalars(float lr, int step, float* step_size, float* inv_bc2) {
     const double bc1 = 1.0 - pow(0.9, (double)step);
     const double bc2 = 1.0 - pow(0.95, (double)step);
     *step_size = (float)((double)lr / bc1);
-    *bc2_sqrt = (float)sqrt(bc2);
+    *inv_bc2 = (float)(1.0 / sqrt(bc2));
 }
 
 }  // namespace nadm

@@ -938,7 +938,7 @@ __global__ void small_reduce_kernel(const float* __restrict__ part, int splits, 
 // Adam + clamp (torch.optim.Adam fused kernel closed form; neural_admixture.py:187-204,411-412)
 // =================================================================================================
 __device__ __forceinline__ void adam_segment(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                             int64_t n, int64_t clamp_from, float step_size, float bc2_sqrt, float grad_scale,
+                                             int64_t n, int64_t clamp_from, float step_size, float inv_bc2, float grad_scale,
                                              int64_t first, int64_t stride) {
     for (int64_t e = first; e < n; e += stride) {
         if (e + 4 <= n) {
@@ -949,14 +949,14 @@ __device__ __forceinline__ void adam_segment(float* __restrict__ p, const float*
             float pp[4] = {P4.x, P4.y, P4.z, P4.w}, gg[4] = {G4.x, G4.y, G4.z, G4.w};
             float mm[4] = {M4.x, M4.y, M4.z, M4.w}, vv[4] = {V4.x, V4.y, V4.z, V4.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pp[q] = adam_element(pp[q], gg[q], mm[q], vv[q], step_size, bc2_sqrt, grad_scale, e + q >= clamp_from);
+            for (int q = 0; q < 4; ++q) pp[q] = adam_element(pp[q], gg[q], mm[q], vv[q], step_size, inv_bc2, grad_scale, e + q >= clamp_from);
             *reinterpret_cast<float4*>(p + e) = make_float4(pp[0], pp[1], pp[2], pp[3]);
             *reinterpret_cast<float4*>(m + e) = make_float4(mm[0], mm[1], mm[2], mm[3]);
             *reinterpret_cast<float4*>(v + e) = make_float4(vv[0], vv[1], vv[2], vv[3]);
         } else {
             for (int64_t q = e; q < n; ++q) {
                 float mq = m[q], vq = v[q];
-                p[q] = adam_element(p[q], g[q], mq, vq, step_size, bc2_sqrt, grad_scale, q >= clamp_from);
+                p[q] = adam_element(p[q], g[q], mq, vq, step_size, inv_bc2, grad_scale, q >= clamp_from);
                 m[q] = mq; v[q] = vq;
             }
         }
@@ -964,20 +964,20 @@ __device__ __forceinline__ void adam_segment(float* __restrict__ p, const float*
 }
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                   int64_t clamp_from, float step_size, float bc2_sqrt,
+                                                   int64_t clamp_from, float step_size, float inv_bc2,
                                                    float grad_scale) {
-    adam_segment(p, g, m, v, n, clamp_from, step_size, bc2_sqrt, grad_scale, ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4,
+    adam_segment(p, g, m, v, n, clamp_from, step_size, inv_bc2, grad_scale, ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4,
                  (int64_t)gridDim.x * blockDim.x * 4);
 }
 // two segments, one launch: blocks [0, blocks0) walk segment 0, the rest segment 1 (nadm_adam2)
 __global__ __launch_bounds__(256) void adam2_kernel(float* __restrict__ p0, const float* __restrict__ g0, float* __restrict__ m0, float* __restrict__ v0,
                                                     int64_t n0, int64_t clamp_from0, float* __restrict__ p1, const float* __restrict__ g1,
                                                     float* __restrict__ m1, float* __restrict__ v1, int64_t n1, int blocks0,
-                                                    float step_size, float bc2_sqrt, float grad_scale) {
+                                                    float step_size, float inv_bc2, float grad_scale) {
     if ((int)blockIdx.x < blocks0)
-        adam_segment(p0, g0, m0, v0, n0, clamp_from0, step_size, bc2_sqrt, grad_scale, ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4, (int64_t)blocks0 * 256 * 4);
+        adam_segment(p0, g0, m0, v0, n0, clamp_from0, step_size, inv_bc2, grad_scale, ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4, (int64_t)blocks0 * 256 * 4);
     else
-        adam_segment(p1, g1, m1, v1, n1, n1, step_size, bc2_sqrt, grad_scale, ((int64_t)(blockIdx.x - blocks0) * 256 + threadIdx.x) * 4,
+        adam_segment(p1, g1, m1, v1, n1, n1, step_size, inv_bc2, grad_scale, ((int64_t)(blockIdx.x - blocks0) * 256 + threadIdx.x) * 4,
                      (int64_t)(gridDim.x - blocks0) * 256 * 4);
 }
 
@@ -1442,7 +1442,7 @@ __global__ void small_reduce_adam_kernel(const float* __restrict__ part, int spl
     const float a = sum_splits(part, splits, n, e);
     out[e] = a;
     if (ad.m != nullptr) {
-        p[e] = adam_element(pq, a, mq, vq, ad.step_size, ad.bc2_sqrt, ad.grad_scale, false);
+        p[e] = adam_element(pq, a, mq, vq, ad.step_size, ad.inv_bc2, ad.grad_scale, false);
         ad.m[e] = mq; ad.v[e] = vq;
     }
 }
@@ -1456,7 +1456,7 @@ extern "C" int nadm_small_grads(const float* small_part, int32_t splits, int32_t
         if (!adam->m || !adam->v || !small) return fail("nadm_small_grads: Adam state / parameters are NULL");
         if (adam->step < 1) return fail("nadm_small_grads: Adam step is 1-based");
         ad.m = adam->m; ad.v = adam->v; ad.grad_scale = adam->grad_scale;
-        adam_scalars(adam->lr, adam->step, &ad.step_size, &ad.bc2_sqrt);
+        adam_scalars(adam->lr, adam->step, &ad.step_size, &ad.inv_bc2);
     }
     hipLaunchKernelGGL(small_reduce_adam_kernel, dim3((n_small + 255) / 256), dim3(256), 0, (hipStream_t)stream, small_part, splits, n_small,
                        grad_small, small, ad);
@@ -1606,13 +1606,13 @@ extern "C" int nadm_adam(float* param, const float* grad, float* m, float* v, in
     if (step < 1) return fail("nadm_adam: step is 1-based");
     if (n <= 0) return 0;
     if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) return fail("nadm_adam: buffers must be 16-byte aligned");
-    float step_size, bc2_sqrt;
-    adam_scalars(lr, step, &step_size, &bc2_sqrt);
+    float step_size, inv_bc2;
+    adam_scalars(lr, step, &step_size, &inv_bc2);
     int64_t blocks = (n / 4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, clamp_from, step_size,
-                       bc2_sqrt, grad_scale);
+                       inv_bc2, grad_scale);
     return check_launch("adam");
 }
 
@@ -1624,12 +1624,12 @@ extern "C" int nadm_adam2(float* param0, const float* grad0, float* m0, float* v
     if (n0 <= 0 || n1 <= 0) return fail("nadm_adam2: empty segment (use nadm_adam)");
     if (((uintptr_t)param0 | (uintptr_t)grad0 | (uintptr_t)m0 | (uintptr_t)v0 | (uintptr_t)param1 | (uintptr_t)grad1 | (uintptr_t)m1 | (uintptr_t)v1) & 15)
         return fail("nadm_adam2: buffers must be 16-byte aligned");
-    float step_size, bc2_sqrt;
-    adam_scalars(lr, step, &step_size, &bc2_sqrt);
+    float step_size, inv_bc2;
+    adam_scalars(lr, step, &step_size, &inv_bc2);
     auto nblk = [](int64_t n) { int64_t x = (n / 4 + 255) / 256; return (int)(x > 256 * 16 ? 256 * 16 : (x < 1 ? 1 : x)); };
     const int b0 = nblk(n0), b1 = nblk(n1);
     hipLaunchKernelGGL(adam2_kernel, dim3((unsigned)(b0 + b1)), dim3(256), 0, (hipStream_t)stream, param0, grad0, m0, v0, n0, clamp_from0,
-                       param1, grad1, m1, v1, n1, b0, step_size, bc2_sqrt, grad_scale);
+                       param1, grad1, m1, v1, n1, b0, step_size, inv_bc2, grad_scale);
     return check_launch("adam2");
 }
 
