@@ -14,6 +14,25 @@ __device__ __forceinline__ float decode_x(uint32_t code2) {
     return __uint_as_float(static_cast<uint32_t>(tab >> (code2 << 4)) << 16);
 }
 
+// ---- lane masks without compares -----------------------------------------------------------------
+// A select on a lane-dependent condition becomes v_cndmask_b32; hipcc prefers its VOP2 form with the mask in VCC, and THAT form
+// costs 23 cycles per wave64 instruction on gfx950 against 4.6 with the mask in an SGPR pair and 2.8 / 4.5 for v_and / v_bfi with a
+// mask register (profiles/r03_ubench_cndmask.txt).  Prologues made of dozens of such selects (operand blends by lane group, "row
+// past M -> 0") were 14 % of a pass-1 block's life.  Masks are therefore formed arithmetically -- from a wrapping subtraction, so that
+// LLVM cannot fold them back into a compare + select -- and applied with bit operations.
+__device__ __forceinline__ uint32_t lt_mask(int a, int b) {            // a < b ? 0xFFFFFFFF : 0   (|a - b| < 2^31)
+    uint32_t m = (uint32_t)((int)((uint32_t)a - (uint32_t)b) >> 31);
+    asm("" : "+v"(m));                  // opaque: with known operand ranges LLVM proves "m is sext(a < b)" and selects again
+    return m;
+}
+__device__ __forceinline__ uint32_t lt_mask64(int64_t a, int64_t b) {  // the same for 64-bit operands
+    uint32_t m = (uint32_t)((int64_t)((uint64_t)a - (uint64_t)b) >> 63);
+    asm("" : "+v"(m));
+    return m;
+}
+__device__ __forceinline__ float keepf(float x, uint32_t m) { return __uint_as_float(__float_as_uint(x) & m); }
+__device__ __forceinline__ uint32_t blend(uint32_t if_set, uint32_t if_clear, uint32_t m) { return (if_set & m) | (if_clear & ~m); }   // v_bfi_b32
+
 // ---- wave64 reductions with DPP (no LDS traffic) -------------------------------------------
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float dpp_f(float v) {

@@ -222,6 +222,9 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
     {
         float* const sv = &s_raw[wave * SV_WAVE];
         float4 vst[CP];
+        // rows past M are read from row M - 1 (clamped, unconditional) and zeroed at the LDS store; the clamp as ONE 32-bit minimum per
+        // load (a 64-bit "m < M ? m : M - 1" is a compare + two v_cndmask with the mask in VCC: 23 cycles each, nadm_common.h)
+        const int row_lim = (int)(M - 1 - slice0 < (int64_t)(EM_SLICE - 1) ? M - 1 - slice0 : (int64_t)(EM_SLICE - 1));
         if (adv.m != nullptr) {
             // Data-parallel step: the previous step's Adam update of V, from the all-reduced gradient lying in dV, applied to the
             // wave's rows on their way in (like pass 2 does for P, AdamFused.pre).  The launch then has ONE batch split, so a V row
@@ -234,8 +237,7 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int e = 4 * (lane + 64 * (j0 + u));
-                    const int64_t m = slice0 + e / CP;
-                    off[u] = (m < M ? m : M - 1) * CP + e % CP;
+                    off[u] = (slice0 + min(e / CP, row_lim)) * CP + e % CP;
                     v4[u] = *reinterpret_cast<const float4*>(Vrw + off[u]);
                     g4[u] = *reinterpret_cast<const float4*>(dV + off[u]);
                     m4[u] = *reinterpret_cast<const float4*>(adv.m + off[u]);
@@ -260,8 +262,7 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
 #pragma unroll
             for (int j = 0; j < CP; ++j) {                    // unconditional, clamped; masked at the LDS store
                 const int e = 4 * (lane + 64 * j);
-                const int64_t m = slice0 + e / CP;
-                vst[j] = *reinterpret_cast<const float4*>(V + (m < M ? m : M - 1) * CP + e % CP);
+                vst[j] = *reinterpret_cast<const float4*>(V + (slice0 + min(e / CP, row_lim)) * CP + e % CP);
             }
         }
 #pragma unroll
@@ -849,7 +850,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
         const uint4 Lo = make_uint4(lo[0], lo[1], lo[2], lo[3]);
         // lane-group dependent choice of the piece, written as mask blends: a ?: on whole uint4 values is turned into a
         // table in scratch memory indexed by the lane group (64 B of scratch stores + loads per tile and thread)
-        const uint32_t m01 = a < 2 ? 0xFFFFFFFFu : 0u, m0 = a == 0 ? 0xFFFFFFFFu : 0u, m1 = a == 1 ? 0xFFFFFFFFu : 0u;
+        const uint32_t m01 = lt_mask(a, 2), m0 = lt_mask(a, 1), m1 = m01 & ~m0;          // a < 2, a == 0, a == 1 (nadm_common.h: no selects)
         if constexpr (W) {
             pa_r1[t] = H;                                                                        // slots [Ph Ph' Ph Ph']
             pa_r2[t] = Md;                                                                       // slots [Pm Pm' Pm Pm']
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
             uint32_t h, md, lo;
             split3_pair(v0, v1, h, md, lo);
             if constexpr (W) { w1[e >> 1] = h; w2[e >> 1] = md; }
-            else { w1[e >> 1] = (n < 8) ? h : md; w2[e >> 1] = 0u; }
+            else { w1[e >> 1] = blend(h, md, lt_mask(n, 8)); w2[e >> 1] = 0u; }
         }
         pa_q1[tp] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
         if constexpr (W) pa_q2[tp] = make_uint4(w2[0], w2[1], w2[2], w2[3]);
@@ -896,6 +897,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     const int pr = has_piece ? tid / PPR : 0, pc16 = tid % PPR;
     const int64_t poff = byte0 + pc16 * 16;
     const bool pcol_ok = poff * 4 < M;             // not `< ld`: on an SNP sub-range launch the bytes past M belong to the next range
+    const uint32_t pcol_okm = lt_mask64(poff * 4, M);
     const int64_t poff_c = pcol_ok ? poff : 0;
     auto row_index = [&](int i0) -> int32_t { const int smp = i0 + pr; return idx[smp < b ? smp : b - 1]; };
     int32_t row_pref = row_index(0);
@@ -925,7 +927,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     };
     auto commit = [&](int i0) {
         const bool ok = pcol_ok && (i0 + pr < b);
-        if (has_piece) *reinterpret_cast<uint4*>(&s_x[pr * RS + pc16 * 16]) = ok ? stage : make_uint4(0, 0, 0, 0);
+        const uint32_t okm = pcol_okm & lt_mask(i0 + pr, b);           // (a select here is four 23-cycle v_cndmask per tile, nadm_common.h)
+        if (has_piece) *reinterpret_cast<uint4*>(&s_x[pr * RS + pc16 * 16]) = make_uint4(stage.x & okm, stage.y & okm, stage.z & okm, stage.w & okm);
         // by-product for pass 3: the gathered rows written back to back (row i of the batch -> row i of xg).  Pass 3 then
         // reads 100 MB in one place instead of 800 rows scattered over the resident matrix, which at 12.5 GB costs it 13 %
         // misses in the per-CU translation cache (UTCL1) and 16 us; here the store is one instruction per tile and thread.

@@ -368,12 +368,15 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    uint32_t cmask[8];                                               // column c < C (bit masks instead of selects: nadm_common.h lt_mask)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cmask[c] = lt_mask(c, C);
 #pragma unroll
     for (int j = 0; j < JH; ++j) {                                   // masks, after every load has been issued
-        const bool in = tid + 256 * j < Hd;
-        bb[j] = in ? bb[j] : 0.f;
+        const uint32_t in = lt_mask(tid + 256 * j, Hd);
+        bb[j] = keepf(bb[j], in);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) w1[j][c] = (in && c < C) ? w1[j][c] : 0.f;
+        for (int c = 0; c < 8; ++c) w1[j][c] = keepf(w1[j][c], in & cmask[c]);
     }
     // ---- Z = sum over chunks (same scheme as mlp_fwd_kernel) ----
     {
@@ -391,8 +394,10 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { const int64_t ch = ch0 + (int64_t)u * G; v[u] = src[(ch < n_chunks ? ch : n_chunks - 1) * stride4]; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (ch0 + (int64_t)u * G < n_chunks) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+                for (int u = 0; u < 8; ++u) {
+                    const uint32_t ok = lt_mask64(ch0 + (int64_t)u * G, n_chunks);
+                    a.x += keepf(v[u].x, ok); a.y += keepf(v[u].y, ok); a.z += keepf(v[u].z, ok); a.w += keepf(v[u].w, ok);
+                }
             }
         }
         reinterpret_cast<float4*>(s_grp)[tid] = a;
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
 #pragma unroll
             for (int c = 0; c < 8; ++c) a = fmaf(s_zn[s * CP + (c < CP ? c : 0)], w1[j][c], a);     // w1 = 0 beyond C
             a = fmaxf(a, 0.f);
-            hv[j][s] = h < Hd ? a : 0.f;
+            hv[j][s] = keepf(a, lt_mask(h, Hd));
             if (h < Hd && s < ns) H[(int64_t)(i0 + s) * Hd + h] = a;
         }
     }
@@ -453,9 +458,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
             }
             __builtin_amdgcn_sched_barrier(0);                                 // keep the loads above their first use
 #pragma unroll
-            for (int kk = 0; kk < MLP_KT; ++kk)
+            for (int kk = 0; kk < MLP_KT; ++kk) {
+                const uint32_t kin = lt_mask(k0 + kk, K);
 #pragma unroll
-                for (int j = 0; j < JH; ++j) wk[j][kk] = (tid + 256 * j < Hd && k0 + kk < K) ? wk[j][kk] : 0.f;
+                for (int j = 0; j < JH; ++j) wk[j][kk] = keepf(wk[j][kk], kin & lt_mask(tid + 256 * j, Hd));
+            }
             float acc[SB][MLP_KT];
 #pragma unroll
             for (int s = 0; s < SB; ++s)
@@ -572,13 +579,18 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    uint32_t cmask[8], smask[SB];                                    // column c < C, sample s < ns (bit masks instead of selects: lt_mask)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cmask[c] = lt_mask(c, C);
+#pragma unroll
+    for (int s = 0; s < SB; ++s) smask[s] = lt_mask(s, ns);
 #pragma unroll
     for (int j = 0; j < JH; ++j) {
-        const bool in = tid + 256 * j < Hd;
+        const uint32_t in = lt_mask(tid + 256 * j, Hd);
 #pragma unroll
-        for (int s = 0; s < SB; ++s) hact[j][s] = (in && s < ns) ? hact[j][s] : 0.f;
+        for (int s = 0; s < SB; ++s) hact[j][s] = keepf(hact[j][s], in & smask[s]);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) w1[j][c] = (in && c < C) ? w1[j][c] : 0.f;
+        for (int c = 0; c < 8; ++c) w1[j][c] = keepf(w1[j][c], in & cmask[c]);
     }
     // ---- dQ = sum over chunks, per head ----
     {
@@ -599,8 +611,10 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
 #pragma unroll
                     for (int u = 0; u < DQD; ++u) { const int64_t ch = ch0 + (int64_t)u * G; v[u] = src[(ch < nch ? ch : nch - 1) * stride4]; }
 #pragma unroll
-                    for (int u = 0; u < DQD; ++u)
-                        if (ch0 + (int64_t)u * G < nch) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
+                    for (int u = 0; u < DQD; ++u) {
+                        const uint32_t ok = lt_mask64(ch0 + (int64_t)u * G, nch);
+                        a.x += keepf(v[u].x, ok); a.y += keepf(v[u].y, ok); a.z += keepf(v[u].z, ok); a.w += keepf(v[u].w, ok);
+                    }
                 }
             }
             reinterpret_cast<float4*>(s_grp)[tid] = a;
@@ -653,9 +667,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
             }
             __builtin_amdgcn_sched_barrier(0);                                 // keep the loads above their first use
 #pragma unroll
-            for (int kk = 0; kk < MLP_KT; ++kk)
+            for (int kk = 0; kk < MLP_KT; ++kk) {
+                const uint32_t kin = lt_mask(k0 + kk, K);
 #pragma unroll
-                for (int j = 0; j < JH; ++j) wk[j][kk] = (tid + 256 * j < Hd && k0 + kk < K) ? wk[j][kk] : 0.f;
+                for (int j = 0; j < JH; ++j) wk[j][kk] = keepf(wk[j][kk], kin & lt_mask(tid + 256 * j, Hd));
+            }
 #pragma unroll
             for (int kk = 0; kk < MLP_KT; ++kk) {
                 float dls[SB];
@@ -678,7 +694,10 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
         const int h = tid + 256 * j;
 #pragma unroll
         for (int s = 0; s < SB; ++s) {
-            const float v = hact[j][s] > 0.f ? dh[j][s] : 0.f;
+            // relu mask: hact is a relu output (>= +0), so "> 0" is "bits != 0": -bits is negative exactly then
+            uint32_t pos = (uint32_t)((int)(0u - __float_as_uint(hact[j][s])) >> 31);
+            asm("" : "+v"(pos));
+            const float v = keepf(dh[j][s], pos);
             if (h < Hd && s < ns) dHpre[(int64_t)(i0 + s) * Hd + h] = v;
 #pragma unroll
             for (int c = 0; c < 8; ++c) part[s][c] = fmaf(v, w1[j][c], part[s][c]);
