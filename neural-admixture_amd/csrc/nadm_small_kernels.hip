@@ -36,6 +36,39 @@ __device__ __forceinline__ float block_sum(float v, float* s_red /*[NT/64]*/) {
     return t;
 }
 
+// -------------------------------------------------------------------------------------------------
+// Sums of NV per-thread values over the 256 threads of a block through LDS: every thread parks its NV partials ([value][thread],
+// row stride 264 floats), thread (value v = t >> 3, part p = t & 7) adds the 32 entries 8 i + p of row v in ascending i, and the
+// caller adds the 8 parts of a value in a fixed tree.  NV = 32 here (4 samples x 8 columns).  The DPP form this replaces -- 32
+// wave_sum_lane63 chains of six dependent cross-lane adds + a 4-wave combine -- was the longest single phase of the MLP forward:
+// 4774 of the 24 k cycles of a block (s_memtime probe, profiles/r03_mlp_probe.txt).  Fixed order, no atomics.
+// Two barriers inside; s_part must be free on entry (the caller's barrier).
+// -------------------------------------------------------------------------------------------------
+constexpr int BR_STRIDE = 264;
+template <int NV>
+__device__ __forceinline__ void block_reduce_lds(const float (&vals)[NV], float* __restrict__ s_part /*[NV * BR_STRIDE]*/, float* __restrict__ s_parts8 /*[NV * 8]*/) {
+    static_assert(NV * 8 == 256, "one (value, part) pair per thread");
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) s_part[v * BR_STRIDE + tid] = vals[v];
+    __syncthreads();
+    {
+        const int v = tid >> 3, p = tid & 7;
+        const float* row = s_part + v * BR_STRIDE + p;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};                  // four interleaved chains (fixed): i = 4 q + u
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] += row[8 * (4 * q + u)];
+        s_parts8[v * 8 + p] = (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ float block_reduce_result(const float* __restrict__ s_parts8, int v) {
+    const float* r = s_parts8 + v * 8;
+    return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+}
+
 // =================================================================================================
 // mlp_fwd: one block (256 threads) per SB consecutive samples (SB = 4: the partial-slab rows of
 // 4 samples are one 128 B line at CP = 8; weights are fetched once per block and reused SB times).
@@ -326,10 +359,12 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
                                                            float* __restrict__ Q, uint4* __restrict__ qimg, int64_t qimg_head_u4) {
     __shared__ __attribute__((aligned(16))) float s_grp[1024];
     __shared__ float s_zn[SB * 8];
-    __shared__ float s_red[4][SB * MLP_KT];
+    static_assert(SB * MLP_KT == 32, "block_reduce_lds<32>");
+    __shared__ float s_part[32 * BR_STRIDE];
+    __shared__ float s_parts8[32 * 8];
     extern __shared__ __attribute__((aligned(16))) float s_logit[];      // [SB][SP]
     const int C = hd.C, CP = hd.CP, Hd = hd.Hd, SP = hd.SP;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int i0 = blockIdx.x * SB;
     const int ns = min(SB, b - i0);
     const int row = SB * CP;
@@ -473,19 +508,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
                     for (int j = 0; j < JH; ++j) a = fmaf(hv[j][s], wk[j][kk], a);
                     acc[s][kk] = a;
                 }
-            __syncthreads();                                  // s_red free (previous pass consumed)
-#pragma unroll
-            for (int s = 0; s < SB; ++s)
-#pragma unroll
-                for (int kk = 0; kk < MLP_KT; ++kk) {
-                    const float t = wave_sum_lane63(acc[s][kk]);
-                    if (lane == 63) s_red[wave][s * MLP_KT + kk] = t;
-                }
-            __syncthreads();
+            __syncthreads();                                  // s_part / s_parts8 free (previous pass consumed)
+            block_reduce_lds<32>(reinterpret_cast<const float (&)[32]>(acc), s_part, s_parts8);      // value v = s * MLP_KT + kk
             if (tid < SB * MLP_KT) {
                 const int s = tid / MLP_KT, kk = tid % MLP_KT;
-                if (k0 + kk < K)
-                    s_logit[s * SP + hd.qoff[hh] + k0 + kk] = ((s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid])) + bk[k0 + kk];
+                if (k0 + kk < K) s_logit[s * SP + hd.qoff[hh] + k0 + kk] = block_reduce_result(s_parts8, tid) + bk[k0 + kk];
             }
         }
     }
@@ -521,10 +548,12 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
                                                              double* __restrict__ loss_acc) {
     __shared__ __attribute__((aligned(16))) float s_grp[1024];
     __shared__ float s_dzn[SB * 8];
-    __shared__ float s_red[4][SB * 8];
+    static_assert(SB * 8 == 32, "block_reduce_lds<32>");
+    __shared__ float s_part[32 * BR_STRIDE];
+    __shared__ float s_parts8[32 * 8];
     extern __shared__ __attribute__((aligned(16))) float s_dl[];         // [SB][SP]
     const int C = hd.C, CP = hd.CP, Hd = hd.Hd, SP = hd.SP;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     // ---- loss: one EXTRA block (the launch has one more block than sample groups when n_loss > 0).  Inside a working block
     // the sum -- an HBM round trip, a float64 wave reduction -- was a tail every other block had already left behind.
     if (n_loss > 0 && blockIdx.x == gridDim.x - 1) {
@@ -704,15 +733,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
         }
     }
     // ---- dZn[s][c] = sum_h dHpre[s][h] W1[h][c] ----
-#pragma unroll
-    for (int s = 0; s < SB; ++s)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float t = wave_sum_lane63(part[s][c]);
-            if (lane == 63) s_red[wave][s * 8 + c] = t;
-        }
-    __syncthreads();
-    if (tid < SB * 8) s_dzn[tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+    block_reduce_lds<32>(reinterpret_cast<const float (&)[32]>(part), s_part, s_parts8);                      // value v = s * 8 + c
+    if (tid < SB * 8) s_dzn[tid] = block_reduce_result(s_parts8, tid);
     __syncthreads();
     if (tid < ns) {
         const int64_t i = i0 + tid;
