@@ -517,9 +517,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
         }
     }
     __syncthreads();
-    // ---- softmax: one thread per (sample, column).  Every thread of a head walks the head's k logits itself -- maximum, then
-    // the exponentials in order -- so all of them arrive at the same sum bit for bit (as one thread per head did, with k
-    // dependent LDS round trips and k + kp stores in a row while 250 threads waited) ----
+    // ---- softmax: one thread per (sample, column).  Phase A: the thread's own exponential (every thread of a head finds the head's
+    // maximum itself) parked in LDS; phase B: every thread of a head adds the head's k exponentials in order, so all of them arrive
+    // at the same sum bit for bit.  (r02 had every thread recompute all k exponentials of its head: k - 1 expf too many per
+    // thread in the kernel's last dependent phase.) ----
+    float* const s_ex = s_part;                                      // [SB][SP], the reduction scratch is free now
     for (int e = tid; e < ns * SP; e += 256) {
         const int s = e / SP, c = e % SP;
         int hh = 0;
@@ -528,10 +530,19 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
         const float* lg = s_logit + s * SP + o;
         float mx = -INFINITY;
         for (int jj = 0; jj < k; ++jj) mx = fmaxf(mx, lg[jj]);
-        float sum = 0.f, mine = 0.f;
-        for (int jj = 0; jj < k; ++jj) { const float ex = expf(lg[jj] - mx); sum += ex; if (jj == j) mine = ex; }
+        s_ex[e] = (j < k) ? expf(lg[j] - mx) : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < ns * SP; e += 256) {
+        const int s = e / SP, c = e % SP;
+        int hh = 0;
+        while (hh + 1 < hd.n_heads && c >= hd.qoff[hh + 1]) ++hh;
+        const int k = hd.k[hh], o = hd.qoff[hh], j = c - o;
+        const float* ex = s_ex + s * SP + o;
+        float sum = 0.f;
+        for (int jj = 0; jj < k; ++jj) sum += ex[jj];
         const float inv = 1.0f / sum;
-        const float qv = (j < k) ? mine * inv : 0.f;
+        const float qv = (j < k) ? ex[j] * inv : 0.f;
         Q[(int64_t)(i0 + s) * SP + c] = qv;
         q_image_store(qimg, qimg_head_u4, hh, hd.kp[hh], i0 + s, j, qv, b, s == 0);
     }

@@ -1,4 +1,4 @@
-// r03: is v_cndmask_b32 really a 23-cycle instruction on gfx950 (profiles/r02_ubench_valu_asm.txt)?  Independent destination registers,
+// r03: is v_cndmask_b32 really a 23-cycle instruction on gfx950 -- and what do the integer multiplies of the row addressing cost (profiles/r02_ubench_valu_asm.txt)?  Independent destination registers,
 // mask in VCC / in an SGPR pair, against v_bfi_b32 and v_and_b32 doing the same selection with a full-width mask register.
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench_cndmask.hip -o /tmp/ubc && /tmp/ubc
 #include <hip/hip_runtime.h>
@@ -8,14 +8,14 @@
 #define REP32(X) REP8(X) REP8(X) REP8(X) REP8(X)
 #define KERNEL(NAME, BODY)                                                                                     \
     __global__ __launch_bounds__(256) void NAME(float* out, int iters) {                                       \
-        float a[8]; unsigned u[8];                                                                             \
-        for (int j = 0; j < 8; ++j) { a[j] = threadIdx.x * 0.001f + j + 1.5f; u[j] = threadIdx.x * 977u + j; } \
+        float a[8]; unsigned u[8]; unsigned long long w[8];                                                    \
+        for (int j = 0; j < 8; ++j) { a[j] = threadIdx.x * 0.001f + j + 1.5f; u[j] = threadIdx.x * 977u + j; w[j] = u[j]; } \
         float c1 = 1.0000001f; unsigned mk = (threadIdx.x & 1) ? 0xFFFFFFFFu : 0u;                             \
         asm volatile("" : "+v"(c1), "+v"(mk));                                                                 \
         asm volatile("v_cmp_gt_f32 vcc, %0, %1\n s_mov_b64 s[20:21], vcc" : : "v"(a[0]), "v"(c1) : "vcc", "s20", "s21");  \
         for (int i = 0; i < iters; ++i) { REP32(BODY) }                                                        \
         float acc = 0;                                                                                         \
-        for (int j = 0; j < 8; ++j) acc += a[j] + (float)u[j];                                                 \
+        for (int j = 0; j < 8; ++j) acc += a[j] + (float)u[j] + (float)w[j];                                   \
         out[blockIdx.x * 256 + threadIdx.x] = acc;                                                             \
     }
 #define B_CND_VCC(j) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[j]) : "v"(c1));
@@ -24,7 +24,12 @@
 #define B_BFI(j) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(u[j]) : "v"(mk), "v"(c1));
 #define B_AND(j) asm volatile("v_and_b32 %0, %1, %0" : "+v"(u[j]) : "v"(mk));
 #define B_FMA(j) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[j]) : "v"(c1));
-KERNEL(k_cnd_vcc, B_CND_VCC) KERNEL(k_cnd_sg, B_CND_SG) KERNEL(k_cnd_0, B_CND_0) KERNEL(k_bfi, B_BFI) KERNEL(k_and, B_AND) KERNEL(k_fma, B_FMA)
+#define B_MULLO(j) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[j]) : "v"(mk));
+#define B_MUL24(j) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[j]) : "v"(mk));
+#define B_MULHI24(j) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(u[j]) : "v"(mk));
+#define B_MAD64(j) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(w[j]) : "v"(u[j]), "v"(mk) : "s20", "s21");
+#define B_LSHLADD64(j) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(w[j]) : "v"(w[(j + 1) & 7]));
+KERNEL(k_cnd_vcc, B_CND_VCC) KERNEL(k_cnd_sg, B_CND_SG) KERNEL(k_cnd_0, B_CND_0) KERNEL(k_bfi, B_BFI) KERNEL(k_and, B_AND) KERNEL(k_fma, B_FMA) KERNEL(k_mullo, B_MULLO) KERNEL(k_mul24, B_MUL24) KERNEL(k_mulhi24, B_MULHI24) KERNEL(k_mad64, B_MAD64) KERNEL(k_lshladd64, B_LSHLADD64)
 typedef void (*kern_t)(float*, int);
 static void run(const char* name, kern_t fn, float* out, int wps) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -46,6 +51,8 @@ int main() {
         run("v_cndmask_b32 v, v, v, vcc", k_cnd_vcc, out, wps); run("v_cndmask_b32_e64 v, v, v, s[20:21]", k_cnd_sg, out, wps);
         run("v_cndmask_b32_e64 v, 0, v, s[20:21]", k_cnd_0, out, wps); run("v_bfi_b32 v, mask, v, v", k_bfi, out, wps);
         run("v_and_b32 v, mask, v", k_and, out, wps); run("v_fma_f32", k_fma, out, wps);
+        run("v_mul_lo_u32", k_mullo, out, wps); run("v_mul_u32_u24", k_mul24, out, wps); run("v_mul_hi_u32_u24", k_mulhi24, out, wps);
+        run("v_mad_u64_u32", k_mad64, out, wps); run("v_lshl_add_u64", k_lshladd64, out, wps);
     }
     return 0;
 }
