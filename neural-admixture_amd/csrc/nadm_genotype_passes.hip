@@ -625,8 +625,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define NADM_TW_SWZ 1        // rotate the chunks of the dR transposition buffer's rows (conflict-free, see the kernel)
 #endif
 #ifndef NADM_BF_WPE
-#define NADM_BF_WPE 3        // waves per SIMD the register allocator must leave room for
+#define NADM_BF_WPE 3        // waves per SIMD the register allocator must leave room for (K <= 8)
 #endif
+#ifndef NADM_BF_WPE_W
+#define NADM_BF_WPE_W 2      // ... for K 9..16: 7 MFMAs per tile and three more resident operands want 218 VGPRs; at 168 (3 waves) the
+#endif                       // kernel ran 721 us (K = 16, M = 1M), at 2 waves per SIMD 652, and 629 with the pair-product loss (r03)
+constexpr int bf_wpe(int kp) { return kp > 8 ? NADM_BF_WPE_W : NADM_BF_WPE; }
 constexpr int mf_waves(int kp) { return NADM_BF_WAVES; }   // waves per block
 constexpr int MF_RS_PAD = 16;       // LDS row stride of the X tile = row bytes + 16 (16 B aligned, de-phased banks)
 constexpr int mf_ntw(int kp) { return NADM_BF_NTW; }            // 16-SNP tiles per wave
@@ -754,7 +758,7 @@ constexpr int BF_TS = NADM_BF_TS;       // samples per LDS tile
 // QIMG: the Q operands come ready-made from `qimg` (this head's tile images written by the MLP forward, nadm_common.h) instead
 // of being split from the fp32 Q by every block: same bf16 pieces, same results.
 template <int KP, bool LOSS, bool UNIT_P = true, bool QIMG = false>
-__global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(NADM_BF_WPE, NADM_BF_WPE))) void decode_bce_bf16_kernel(
+__global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(bf_wpe(KP), bf_wpe(KP)))) void decode_bce_bf16_kernel(
     const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
     float* P, const float* __restrict__ Q, int SP,
     float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart, uint8_t* __restrict__ xg, AdamFused ad,
@@ -982,7 +986,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(N
     asm volatile("v_rcp_f32 %0, %0" : "+v"(kmax_v));
     const float kmax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, kmax_v)));
 #ifndef NADM_FAST_LOSS_MAXKP
-#define NADM_FAST_LOSS_MAXKP 8      // K 9..16 (7 MFMAs per tile, at the 168-VGPR ceiling): 769 us with the fast form against 694 without (K = 16, M = 1M)
+#define NADM_FAST_LOSS_MAXKP 16
 #endif
     constexpr bool FAST_LOSS = LOSS && UNIT_P && KP <= NADM_FAST_LOSS_MAXKP;   // one logarithm per pair of genotypes, exact form as the cold fallback
     // the lane's codes of one 16-sample tile: nibble = one 2-bit code, codes 0,2 / 1,3 of each byte (byte t = 4 SNPs of tile t)
