@@ -669,13 +669,17 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast
 // waves' VALU work (tools/ubench_issue.hip).  max, rcp, log and the conversions have no packed form.
 // Returns dR (gradient w.r.t. the pre-clamp reconstruction) and accumulates the BCE loss terms; x = genotype/2 with missing
 // already mapped to 0 (fp4_pair below).
-//   gradient   den = (1 - d) * d from the UNCLAMPED d: inside [0, 1] that is r(1 - r) bit for bit (r == d there), outside it
-//              is negative.  inv = med3(rcp(den), 0, KMAX) with KMAX = rcp(1e-12) as v_rcp_f32 computes it: rcp is monotonic, so
-//              for den >= 1e-12 this is rcp(den), for 0 <= den < 1e-12 (rcp >= KMAX, +inf at 0) it is KMAX = rcp(max(den, 1e-12)),
-//              and for den < 0 -- d out of range -- rcp is negative and the median is exactly 0: the reference's clamp_ backward
-//              masks on the PRE-clamp value, bounds inclusive.  The numerator can then use d itself: no clamp instruction on the
-//              gradient path at all.  (r02 formed max3(den, 1e-12, den * -inf) in front of the reciprocal: one packed multiply
-//              more per pair, 10 us of the kernel.)
+//   gradient   den = d - d^2 (one fma) from the UNCLAMPED d: inside [0, 1] that is r(1 - r) to an ulp (r == d there), 0 exactly at
+//              d = 0 / 1, negative outside.  The reference divides by max(den, 1e-12) and its clamp_ backward zeroes the gradient
+//              where the PRE-clamp value lies outside [0, 1] (bounds inclusive): inv = min(1/den, 1e12) for den >= 0, 0 for
+//              den < 0.  The tile loop forms inv * 1e-12 = sat(1e-12 * rcp(den)) -- a v_mul_f32 carrying the clamp bit
+//              (saturation to [0, 1]: +inf -> 1, negative and -inf -> 0; profiles/r03_ubench_clamp_mfma16.txt) -- and the factor
+//              KMAX = rcp(1e-12) goes onto the dQ / dP sums once per block (scale_back below): dR' = (d - x) * inv * 1e-12 is
+//              what the matrix pipe sees (bf16 / fp32 have the exponent range to spare: |dR'| >= 1e-19 for any d - x an fp32
+//              subtraction can produce).  rcp is monotonic, so the saturation sets in exactly at den <= 1e-12.  The numerator
+//              uses d itself: no clamp instruction on the gradient path at all.  (r02 formed max3(den, 1e-12, den * -inf) in
+//              front of the reciprocal, r03 first med3(rcp(den), 0, KMAX) per value: -10 us; then this form: a v_med3 becomes
+//              a v_mul of the cheap class, and 1 - d is no longer needed for den.)
 //   loss       x*max(log r, -100) + (1-x)*max(log(1-r), -100), x in {0, .5, 1}.
 //     exact    (bce_loss_exact2; the steps before the first restrict_P and the fallback below) needs the two clamps only for
 //              r == 0 / r == 1 (log = -inf; an fp32 r is never in (0, e^-100)).  log2(v * 2^20 + 2^(20 - 100/ln2)) - 20 equals
@@ -688,16 +692,22 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast
 //              UNIT_P = false clamps d from above for the step(s) before that -- the reference's supervised run starts
 //              from per-class means of the raw codes, which reach 2 (train.py:82).
 //     fast     (r03, bce_loss_prod2; UNIT_P only) ONE logarithm per PAIR of genotypes instead of four.  With c = 2x in {0, 1, 2}
-//              twice the term of a genotype is c*log d + (2-c)*log(1-d) = log(u*v), (u, v) = (1-d, 1-d), (d, 1-d), (d, d): the
-//              factors are picked with two 0/1 selectors s1 = [c >= 1], s2 = [c == 2] (two more v_cvt_scalef32_pk_f32_fp4 of the
-//              same code word, masked), u = o + s1*(d - o), and the four factors of a pair are multiplied before the one v_log.
-//              A factor 1-d is either 0 or >= 6e-8, a factor d is arbitrary; the product of four is 0 or underflows exactly when a
-//              clamp of the reference could be active (a zero factor) or d is tiny (two d < 1e-10 under genotype 2) -- then, and
-//              only then, the logarithm is -inf and the wave recomputes the loss of that tile pair with the exact form (cold
-//              branch in the loop, decode_bce_bf16_kernel).  Same value up to the rounding of three multiplications per pair
-//              (relative 2e-7 on a term; the loss tolerance is 5e-6 on the sum).  (Multiplying the products of the lane's two
-//              pairs of a tile as well -- one logarithm per four genotypes -- measured 250 us against 246: the longer dependent
-//              chain in front of the logarithm costs what the logarithm saves.)
+//              twice the term of a genotype is c*log d + (2-c)*log(1-d) = log f, f = (1-d)^2, d(1-d), d^2.  With o = sat(1 - d)
+//              (a v_sub with the clamp bit) and q = o - x:  q^2 = o^2 for x = 0 and d^2 for x = 1 (q = -d), and the heterozygous
+//              value is den = d(1-d), which the gradient has already formed:  f = qq + h * (den - qq),  qq = q^2,  h = [c == 1]
+//              (one more v_cvt_scalef32_pk_f32_fp4 of the masked code word) -- four packed instructions per pair, and the two
+//              f of a pair are multiplied before the one v_log.  o is clamped: with d > 1 by a rounding error a homozygous-
+//              reference genotype gives f = 0 like the reference's log(1 - clamp(d)), the heterozygous one f <= den < 0, the
+//              homozygous-alternative one f = 1 (log 1).  The product is 0, negative or underflows exactly when a clamp of
+//              the reference could be active or d is tiny -- then, and only then, the logarithm is -inf / NaN and the wave
+//              recomputes the loss of that tile pair with the exact form (cold branch in the loop, decode_bce_bf16_kernel).
+//              Accuracy: the factor under a non-zero genotype carries the ABSOLUTE rounding error of 1 - d (3e-8 for d < 1/2),
+//              i.e. 3e-8 / d relative -- against the fp32 accumulation of ~4e8 terms this is invisible in the sum (tests: 2e-6
+//              against the exact form, 5e-6 against the oracle), but a single term under d = 1e-6 is only good to 3 %; the
+//              exact form has no such error.  (First r03 version: u = o + s1 * (d - o) with two selectors and the product
+//              u * v: three instructions more per pair and twice that error.  Multiplying the products of the lane's two pairs
+//              of a tile as well -- one logarithm per four genotypes -- measured 250 us against 246: the longer dependent chain
+//              in front of the logarithm costs what the logarithm saves.)
 constexpr float LOSS_LOG_SHIFT = 20.f;                    // log2 of the scale of the exact form
 __device__ __forceinline__ f32x2_t two_max0(const f32x2_t v) {                 // 2 * max(v, 0), exact.  As asm: the compiler would pair
     f32x2_t r;                                                                 // the two adds into a v_pk_add_f32, which has no |abs|
@@ -705,11 +715,14 @@ __device__ __forceinline__ f32x2_t two_max0(const f32x2_t v) {                 /
     asm("v_add_f32_e64 %0, %1, |%1|" : "=v"(r.y) : "v"(v.y));
     return r;
 }
-// gradient w.r.t. the pre-clamp reconstruction for two genotypes; omd = 1 - d is handed back for the loss
-__device__ __forceinline__ f32x2_t bce_grad2(const f32x2_t d, const f32x2_t x, const float kmax, f32x2_t& omd) {
-    omd = (f32x2_t){1.f, 1.f} - d;
-    const f32x2_t den = omd * d;
-    const f32x2_t inv = {__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(den.x), 0.f, kmax), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(den.y), 0.f, kmax)};
+// gradient w.r.t. the pre-clamp reconstruction for two genotypes, TIMES 1e-12 (eps; the caller multiplies the sums by rcp(1e-12));
+// den = (1 - d) d is handed back for the loss
+__device__ __forceinline__ f32x2_t bce_grad2(const f32x2_t d, const f32x2_t x, const float eps, f32x2_t& den) {
+    den = __builtin_elementwise_fma(-d, d, d);                                 // d - d^2 in one rounding; < 0 exactly when d is outside [0, 1]
+    // sat(1e-12 / den): 1 at den <= 1e-12 (and +0), 0 for den < 0.  Written per element so that the clamp folds into the multiply
+    // (v_mul_f32_e64 ... clamp); as inline asm (v_pk_mul_f32 ... clamp) it would sit right behind the v_rcp without the wait state
+    // the hardware needs between a transcendental and its consumer -- the hazard recognizer does not look into asm statements
+    const f32x2_t inv = {__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(den.x) * eps, 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(den.y) * eps, 0.f, 1.f)};
     return (d - x) * inv;
 }
 // exact form: adds x*log2(r') + (1-x)*log2((1-r)') + 20 per genotype to lossacc (packed halves)
@@ -729,14 +742,14 @@ __device__ __forceinline__ void bce_loss_exact2(const f32x2_t d, const f32x2_t o
     asm volatile("" : "+v"(lossacc));     // pin the accumulation here: otherwise LLVM sinks all the logs of a tile pair
                                           // to the end of the loop body and keeps their 32 inputs alive (+60 VGPRs)
 }
-// fast form: adds log2(16 * u0 v0 u1 v1) = 2 * (the two genotypes' terms in log2 units) + 4 to acc; -inf (or NaN) flags the pair
-__device__ __forceinline__ void bce_loss_prod2(const f32x2_t d, const f32x2_t omd, const f32x2_t s1, const f32x2_t s2, float& acc) {
-    const f32x2_t o2 = two_max0(omd);                                           // 2 * (1 - r)
-    const f32x2_t e2 = __builtin_elementwise_fma(d, (f32x2_t){2.f, 2.f}, -o2);  // 2 * (d - (1 - r))
-    const f32x2_t u = __builtin_elementwise_fma(s1, e2, o2);                    // 2d if c >= 1 else 2(1-r)
-    const f32x2_t v = __builtin_elementwise_fma(s2, e2, o2);                    // 2d if c == 2 else 2(1-r)
-    const f32x2_t tt = u * v;
-    acc += __builtin_amdgcn_logf(tt.x * tt.y);
+// fast form: adds log2(f0 * f1) = 2 * (the two genotypes' terms in log2 units) to acc; -inf (or NaN) flags the pair.
+// h = [c == 1] per genotype
+__device__ __forceinline__ void bce_loss_prod2(const f32x2_t d, const f32x2_t den, const f32x2_t x, const f32x2_t h, float& acc) {
+    const f32x2_t o = {__builtin_amdgcn_fmed3f(1.f - d.x, 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - d.y, 0.f, 1.f)};   // 1 - r: v_sub_f32 ... clamp
+    const f32x2_t q = o - x;                                                             // 1-r | . | -d  for c = 0 | 1 | 2
+    const f32x2_t qq = q * q;                                                            // (1-r)^2 | . | d^2
+    const f32x2_t f = __builtin_elementwise_fma(h, den - qq, qq);                        // c == 1: qq + (den - qq)
+    acc += __builtin_amdgcn_logf(f.x * f.y);
     asm volatile("" : "+v"(acc));             // pin the accumulation here (see bce_loss_exact2)
 }
 
@@ -984,7 +997,10 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
 
     float kmax_v = 1e-12f;                                 // 1 / 1e-12 as v_rcp_f32 computes it (opaque to the constant folder)
     asm volatile("v_rcp_f32 %0, %0" : "+v"(kmax_v));
-    const float kmax = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, kmax_v)));
+    const float scale_back = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, kmax_v)));   // bce_grad2: dR is carried times 1e-12
+    float eps_v = 1e-12f;
+    asm volatile("" : "+s"(eps_v));                        // (opaque: the compiler would otherwise pair the two multiplies and clamp separately)
+    const float eps = eps_v;
 #ifndef NADM_FAST_LOSS_MAXKP
 #define NADM_FAST_LOSS_MAXKP 16
 #endif
@@ -1030,7 +1046,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                     qb1[s2] = s_qr[st][0][lane];
                     qb2[s2] = s_qr[st][1][lane];
                 }
-                float it_acc = 0.f;                                    // fast loss of this tile pair: sum of log2(16 * product of the 4 factors of a pair)
+                float it_acc = 0.f;                                    // fast loss of this tile pair: sum of log2(f0 * f1) over the lane's pairs
                 const uint4 qd1 = s_qd[p][0][lane];
                 uint4 qd2 = make_uint4(0, 0, 0, 0);
                 if constexpr (W) qd2 = s_qd[p][1][lane];
@@ -1050,12 +1066,12 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                             for (int h2 = 0; h2 < 2; ++h2) {
                                 const uint32_t cw = h2 ? odd[s2] : even[s2];
                                 const f32x2_t d = {D[2 * h2], D[2 * h2 + 1]}, x = fp4_pair(cw, t);
-                                f32x2_t omd;
-                                const f32x2_t dR = bce_grad2(d, x, kmax, omd);
-                                if constexpr (FAST_LOSS)      // selectors [c >= 1], [c == 2]: a nibble 0010 is 1.0 in FP4
-                                    bce_loss_prod2(d, omd, fp4_pair((cw | (cw << 1)) & 0x22222222u, t), fp4_pair(cw & 0x22222222u, t), it_acc);
+                                f32x2_t den;
+                                const f32x2_t dR = bce_grad2(d, x, eps, den);
+                                if constexpr (FAST_LOSS)      // selector [c == 1]: a nibble 0010 is 1.0 in FP4
+                                    bce_loss_prod2(d, den, x, fp4_pair(((cw & ~(cw >> 1)) & 0x11111111u) << 1, t), it_acc);
                                 else if constexpr (LOSS)
-                                    bce_loss_exact2<UNIT_P>(d, omd, x, lossacc);
+                                    bce_loss_exact2<UNIT_P>(d, (f32x2_t){1.f, 1.f} - d, x, lossacc);
                                 const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector(dR, bf16x2_t));
                                 hi[t2][h2] = hp;
                                 const f32x2_t rem = dR - (f32x2_t){__uint_as_float(hp << 16), __uint_as_float(hp & 0xFFFF0000u)};
@@ -1100,7 +1116,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                     }
                 }
                 if constexpr (FAST_LOSS) {
-                    // it_acc = sum over the lane's 4 * NTW pairs of 2 * (their terms in log2 units) + 4.  -inf (a zero or underflowed
+                    // it_acc = sum over the lane's 4 * NTW pairs of 2 * (their terms in log2 units).  -inf (a zero or underflowed
                     // product: a clamp of the reference may be active) or NaN anywhere in the wave: recompute the tile pair's
                     // loss in the exact form -- R^T again from the operands still in LDS / registers, loss algebra only
                     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(__builtin_fabsf(it_acc) < __builtin_inff())) != 0, 0)) {
@@ -1121,9 +1137,9 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                                 }
                             }
                         }
-                        it_acc = 2.f * ((ex.x + ex.y) - LOSS_LOG_SHIFT * NTW * 8) + 4.f * NTW * 4;
+                        it_acc = 2.f * ((ex.x + ex.y) - LOSS_LOG_SHIFT * NTW * 8);
                     }
-                    lossacc.x += 0.5f * (it_acc - 4.f * NTW * 4);     // "+ 4" per pair: the factor 16 = 2^4 in every product
+                    lossacc.x += 0.5f * it_acc;
                 } else if constexpr (LOSS) {   // the "- 20" of the shifted logs: 2 * NTW * 4 genotypes per lane and tile pair, half of them per packed half
                     lossacc -= (f32x2_t){LOSS_LOG_SHIFT * NTW * 4, LOSS_LOG_SHIFT * NTW * 4};
                 }
@@ -1149,7 +1165,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                     const float4 v = *reinterpret_cast<const float4*>(&s_dq[w][part][4 * e4]);
                     sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
                 }
-            *reinterpret_cast<float4*>(dqpart + (chunk * b + i0) * KP + 4 * e4) = sm;
+            *reinterpret_cast<float4*>(dqpart + (chunk * b + i0) * KP + 4 * e4) =
+                make_float4(sm.x * scale_back, sm.y * scale_back, sm.z * scale_back, sm.w * scale_back);
         }
         if (tl + 1 < ntiles) commit(i0 + MF_TS);
         __syncthreads();
@@ -1167,7 +1184,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
         for (int r = 0; r < 4; ++r) {
             float v = dpacc[t][r];
             if constexpr (!W) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /*row_ror:8*/, 0xf, 0xf, false));
-            if (n < KP) s_dp[(int)(snp_of(t, a, r) - snp_blk0) * KP + n] = v;
+            if (n < KP) s_dp[(int)(snp_of(t, a, r) - snp_blk0) * KP + n] = v * scale_back;
         }
     }
     __syncthreads();
