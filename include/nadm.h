@@ -40,7 +40,7 @@ extern "C" {
 
 #define NADM_MAX_HEADS 32
 #define NADM_MAX_K 64
-#define NADM_ABI_VERSION 7   /* 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
+#define NADM_ABI_VERSION 8   /* 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
@@ -118,9 +118,9 @@ int nadm_pca_project(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t 
                      const float* V, int32_t CP, float* zpart, void* stream);
 /* Transposed product with the same convention,  out [M,CP] = (G/2)^T . Y  for the rows idx[0..b), Y [b,CP]: the second
  * tall-skinny product of the randomized SVD (src/svd.py:60,77 -> utils_c/rsvd.pyx multiply_QT_A; A = raw codes = 2 * G/2).
- * Same kernel as nadm_encode_bwd; CP <= 8 only. */
+ * Same kernel as nadm_encode_bwd; CP <= 8 only; yimg = nadm_dz_image of Y. */
 int nadm_pca_project_t(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                       const float* Y, int32_t CP, float* out, void* stream);
+                       const float* Y, const void* yimg, int32_t CP, float* out, void* stream);
 
 /* ---- a6-a8: RMSNorm + Linear/ReLU + per-head Linear + softmax (neural_admixture.py:173-176) */
 int nadm_mlp_fwd(const nadm_heads_t* hd, const float* small, const float* zpart, int64_t n_chunks, int32_t b,
@@ -195,7 +195,7 @@ typedef struct {
     float* small_part;
 } nadm_mlp_weights_t;
 int nadm_encode_bwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                         const float* dZ, int32_t CP, float* V, float* dV, const nadm_adam_t* adam,
+                         const float* dZ, const void* dzimg, int32_t CP, float* V, float* dV, const nadm_adam_t* adam,
                          const nadm_mlp_weights_t* weights, void* stream);
 int nadm_small_grads(const float* small_part, int32_t splits, int32_t n_small, float* grad_small, float* small,
                      const nadm_adam_t* adam, void* stream);
@@ -252,9 +252,24 @@ int nadm_supervised_ce(const float* Q, int32_t SP, int32_t k, int32_t kp, const 
 int nadm_mlp_bwd_weights(const nadm_heads_t* hd, int32_t b, const float* Zn, const float* H, const float* dL,
                          const float* dHpre, const float* dgp, float* small_part, float* grad_small, void* stream);
 
-/* ---- a11: dV = X^T . dZ  (autograd of neural_admixture.py:172) --------------------------- */
+/* ---- a11: dV = X^T . dZ  (autograd of neural_admixture.py:172) ---------------------------
+ * C <= 8 (CP 4, 8) runs on gfx950's FP4 x FP6 block-scaled matrix instruction: the 2-bit codes enter it as FP4 numbers without a
+ * conversion, and dZ enters as an OPERAND IMAGE -- per 32 samples x column eight FP6 pieces (the hexadecimal digits of |dZ| in
+ * fixed point below the block's maximum) with their E8M0 scales, laid out per lane of the instruction.  The image is the same
+ * for every block of the launch, so it is built once: nadm_dz_image(dZ [b, CP] -> dzimg, nadm_dz_image_bytes(b) bytes, 16-byte
+ * aligned), on the stream, before the pass.  dZ itself is read by the CP > 8 variants only (dzimg may be NULL for them). */
+int64_t nadm_dz_image_bytes(int32_t b);
+int nadm_dz_image(const float* dZ, int32_t b, int32_t CP, void* dzimg, void* stream);
+/* nadm_mlp_bwd that also leaves dZ's operand image in dzimg: the block that completes a group of 32 samples last builds the group's
+ * part (no launch of its own, no launch gap).  dz_counters: (b + 31) / 32 int32 on the device, ZERO-FILLED ONCE by the caller (the
+ * launch returns them to zero).  A shorter batch than the previous one leaves the image parts of the samples past b as they were;
+ * pass 3 multiplies them by zeros. */
+int nadm_mlp_bwd_image(const nadm_heads_t* hd, const float* small, float* dqpart, int64_t M, int32_t b,
+                       const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
+                       float* dL, float* dHpre, float* dgp, float* small_part, float* dZ, float* grad_small,
+                       const float* losspart, int64_t n_loss, double* loss_acc, void* dzimg, int32_t* dz_counters, void* stream);
 int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                    const float* dZ, int32_t CP, float* dV, void* stream);
+                    const float* dZ, const void* dzimg, int32_t CP, float* dV, void* stream);
 
 /* ---- a12/a13: Adam(betas .9/.95, eps 1e-8) + restrict_P (neural_admixture.py:187-204,411-412)
  * Flat update of n floats; `step` is the 1-based step count; gradients are multiplied by

@@ -60,7 +60,7 @@ def _load():
         "nadm_bed_to_packed_dev": (C.c_int, [vp, i64, i64, vp, i64, vp, i32, vp, vp]),
         "nadm_encode_fwd": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp]),
         "nadm_pca_project": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp]),
-        "nadm_pca_project_t": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp]),
+        "nadm_pca_project_t": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, i32, vp, vp]),
         "nadm_loglik_blocks": (i64, [i64]),
         "nadm_loglik": (C.c_int, [vp, i64, i64, i64, vp, vp, i32, i32, C.c_double, vp, vp]),
         "nadm_savetxt_f32": (C.c_int, [C.c_char_p, vp, i64, i64, i64]),
@@ -73,13 +73,16 @@ def _load():
         "nadm_q_image_bytes": (C.c_int64, [i32]),
         "nadm_encode_fwd_small": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp]),
         "nadm_encode_fwd_step": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
-        "nadm_encode_bwd_step": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp, vp, vp, vp]),
+        "nadm_encode_bwd_step": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, i32, vp, vp, vp, vp, vp]),
         "nadm_small_grads": (C.c_int, [vp, i32, i32, vp, vp, vp, vp]),
         "nadm_mlp_bwd": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]),
+        "nadm_mlp_bwd_image": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
         "nadm_mlp_bwd_weights": (C.c_int, [HP, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         "nadm_sum_rows": (C.c_int, [vp, i64, i64, vp, vp]),
         "nadm_supervised_ce": (C.c_int, [vp, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp]),
-        "nadm_encode_bwd": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp]),
+        "nadm_encode_bwd": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, i32, vp, vp]),
+        "nadm_dz_image_bytes": (C.c_int64, [i32]),
+        "nadm_dz_image": (C.c_int, [vp, i32, i32, vp, vp]),
         "nadm_vcf_parse_gt": (C.c_int, [C.c_char_p, i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]),
         "nadm_adam": (C.c_int, [vp, vp, vp, vp, i64, i64, f32, i32, f32, vp]),
         "nadm_adam2": (C.c_int, [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, i64, f32, i32, f32, vp]),
@@ -89,7 +92,7 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.nadm_abi_version() != 7:
+    if lib.nadm_abi_version() != 8:
         raise RuntimeError("neural_admixture_amd: libnadm.so ABI version mismatch")
     return lib, tuple(sig)
 

@@ -114,6 +114,61 @@ __device__ __forceinline__ void split3(float v, uint32_t& h, uint32_t& m, uint32
     l = pk_bf16(r2, 0.f) & 0xFFFFu;
 }
 
+// ---- dZ as the operand image of pass 3 on the FP4 x FP6 matrix instruction (C <= 8; encode_bwd_fp4_kernel) --------------------------
+// Per tile of 128 samples (= K of v_mfma_scale_f32_16x16x128_f8f6f4) 7 x 64 uint4: uint4 k = 0..5 of lane l hold the lane's 24 operand
+// dwords (row group rg = 0..3: dwords 6 rg .. 6 rg + 5 = 32 FP6 codes), uint4 k = 6 holds in .x the four E8M0 scale bytes (byte rg).
+// Lane l = 16 q + 8 parity + c is row (parity, column c) and K-block q of the instruction; row group rg carries pieces 2 rg + parity.
+// A lane's 32 values (one column, 32 consecutive samples) are cut into eight pieces of four bits: |v| in fixed point below 2^(E0 + 4)
+// > the block's largest magnitude, n = |v| / 2^(E0 - 28) < 2^32, piece p = hexadecimal digit p of n with the sign of v.  Digit h is the
+// FP6 (E2M3) number h / 8 exactly, so piece p enters with the scale 2^(E0 - 4p + 3).  An element within 2^-8 of the block maximum is
+// carried exactly, a smaller one to an absolute error < 2^-31 of that maximum.
+constexpr int DZI_TS = 128;
+constexpr int DZI_TILE_U4 = 7 * 64;
+// sample (within its tile) of element e = 0..31 of K-block q: the order pass 3's bit transposition produces (see there)
+__host__ __device__ constexpr int dzi_sample(int q, int e) { return 32 * q + 8 * (e >> 3) + 4 * (e & 1) + ((e & 7) >> 1); }
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned u32x6_t __attribute__((ext_vector_type(6)));
+// one thread: piece p of column c of K-block q of tile T.  GROUP = false: dZ is the [b, CP] matrix in global memory; true: dZ points at
+// the K-block's 32 samples x 8 columns in LDS (rows past the batch and columns past CP zeroed by the caller)
+template <bool GROUP>
+__device__ __forceinline__ void dzi_build_piece(const float* dZ, int b, int CP, uint4* img, int T, int q, int c, int p) {
+    float v[32];
+    float mx = 0.f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        if constexpr (GROUP) {
+            v[e] = dZ[(dzi_sample(q, e) - 32 * q) * 8 + c];
+        } else {
+            const int s = T * DZI_TS + dzi_sample(q, e);
+            const float x = dZ[(int64_t)(s < b ? s : b - 1) * CP + (c < CP ? c : 0)];
+            v[e] = (s < b && c < CP) ? x : 0.f;
+        }
+        mx = __builtin_fmaxf(mx, __builtin_fabsf(v[e]));
+    }
+    // mx = m 2^ex, m in [1/2, 1): every |v| < 2^ex = 2^(E0 + 4)
+    const int E0 = __builtin_amdgcn_frexp_expf(mx) - 4;
+    int sb = 127 + E0 - 4 * p + 3;
+    const bool dead = !(mx > 0.f) || !(mx < __builtin_inff()) || sb < 1;   // (a piece below 2^-126 carries nothing an fp32 sum would see)
+    if (dead) sb = 127;
+    f32x16_t fa, fb;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        const uint32_t n = (uint32_t)__builtin_ldexpf(__builtin_fabsf(v[e]), 28 - E0);
+        const uint32_t h = dead ? 0u : ((n >> (28 - 4 * p)) & 15u);
+        const float f = __builtin_copysignf((float)h, v[e]);
+        if (e & 1) fb[e >> 1] = f; else fa[e >> 1] = f;      // the conversion interleaves its two sources: field 2i = a[i], 2i + 1 = b[i]
+    }
+    const u32x6_t r = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(fa, fb, 8.0f);      // h -> the code of h / 8, exact
+    const int l = 16 * q + 8 * (p & 1) + c, rg = p >> 1;
+    uint32_t* base = reinterpret_cast<uint32_t*>(img + (int64_t)T * DZI_TILE_U4);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int d = 6 * rg + i;
+        base[((d >> 2) * 64 + l) * 4 + (d & 3)] = r[i];
+    }
+    reinterpret_cast<uint8_t*>(base)[((6 * 64 + l) * 4) * 4 + rg] = (uint8_t)sb;
+}
+
 // ---- Q as the MFMA operand images of the bf16 pass 2 (K <= 16), one image per head and 64-sample tile --------------------------
 // Every block of pass 2 (1954 of them at M = 500k) needs the batch's Q as bf16 pieces laid out as its MFMA operands; built
 // from the fp32 Q inside pass 2 that is two split3 and 16 two-byte LDS stores per thread and tile, 3.5 % of the kernel without

@@ -18,6 +18,7 @@ extern "C" int nadm_mlp_bwd_weight_parts(const nadm_heads_t* hd, int32_t b, cons
                                          const float* dHpre, const float* dgp, float* small_part, void* stream);
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace nadm {
 
@@ -1427,6 +1428,249 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// =================================================================================================
+// pass 3 on the FP4 x FP6 matrix instruction (CP <= 8, r03): dV = X^T . dZ on v_mfma_scale_f32_16x16x128_f8f6f4.
+//   A nibble 00cc IS the FP4 (E2M1) number c/2, so the genotypes enter the matrix pipe WITHOUT a conversion: the B operand of
+//   one instruction is 32 samples x 1 SNP per lane (4 registers of nibbles), K = 128 samples per instruction.  What is left on
+//   the VALU is the bit transposition (the packed byte holds 4 SNPs of one sample, the operand wants 8 samples of one SNP per
+//   register): 40 instructions per 16 byte columns x 128 samples, where the bf16 kernel above spends 4 x 40 on shifts, masks
+//   and 64 v_cvt_scalef32_pk_bf16_fp4.  And K = 128 costs 22-25 issue cycles where four K = 32 bf16 instructions cost 71
+//   (profiles/r03_ubench_fp4_mfma.txt).
+//   dZ is the A operand, as FP6 (E2M3) pieces: the block of 32 samples x one column a lane holds is cut into EIGHT pieces of
+//   four bits -- the hexadecimal digits of |dZ| in fixed point below 16 x the block's largest magnitude, each with the sign
+//   of the value; digit h is the FP6 number h/8 exactly -- and the instruction's per-lane E8M0 scale carries the digit's
+//   weight 2^(E0 - 4p + 3).  Rows of the instruction = (piece parity, column), four instructions (row groups) per X operand
+//   accumulate all eight pieces into ONE accumulator; rows c and c + 8 are folded in the epilogue.  32 bits below the
+//   block maximum: an element within 2^-8 of it is carried exactly, a smaller one to an absolute error < 2^-31 of the block
+//   maximum (the bf16 kernel carried 24 bits below every element's own magnitude).  The image is the same for every block of
+//   the launch: it is built ONCE per step (dz_image_kernel; 7 KB per 128 samples) instead of once per block and tile.
+//   (layout and arithmetic of the image: nadm_common.h, dzi_build_piece; the MLP backward writes it, nadm_mlp_bwd_image.)
+//   Element order inside a lane (dzi_sample): what the bit transposition produces, see the tile loop.
+// =================================================================================================
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+
+// the image on its own (callers whose dZ does not come out of nadm_mlp_bwd_image): grid = tiles of 128 samples, 256 threads:
+// thread (piece p = tid & 7, column c = (tid >> 3) & 7, K-block q = tid >> 6)
+__global__ __launch_bounds__(256) void dz_image_kernel(const float* __restrict__ dZ, int b, int CP, uint4* __restrict__ img) {
+    const int tid = threadIdx.x;
+    dzi_build_piece<false>(dZ, b, CP, img, blockIdx.x, tid >> 6, (tid >> 3) & 7, tid & 7);
+}
+
+constexpr int EB4_XS = 132;               // bytes per byte column of the LDS tile: 128 samples + 4 (dword stride 33: the loader's 4-byte
+                                          // stores of 32 consecutive column quads and the 4-byte column reads spread over the banks)
+template <int CP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void encode_bwd_fp4_kernel(const uint8_t* __restrict__ xp, int64_t ld,
+                                                              const int32_t* __restrict__ idx, int b, int64_t M,
+                                                              const uint4* __restrict__ dzimg, float* __restrict__ dV,
+                                                              uint32_t missing_bf16, float* __restrict__ Vrw, AdamFused ad, MlpSide side) {
+    static_assert(CP <= 8, "rows of the instruction: piece parity x 8 columns");
+    {   // blocks past the SNP chunks: the MLP weight-gradient partials (independent of pass 3; see mlp_bwd_b_block)
+        const int64_t nchunks = (M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS;
+        if ((int64_t)blockIdx.x >= nchunks) {
+            const int e = (int)(blockIdx.x - nchunks);
+            mlp_bwd_b_block(side.hd, side.b, side.Zn, side.H, side.dL, side.dHpre, side.dgp, side.small_part, e % side.gx, e / side.gx);
+            return;
+        }
+    }
+    __shared__ __attribute__((aligned(16))) uint8_t s_xt[2][EB_COLS * EB4_XS];      // [byte column][128 samples]; the block's dV rows at the end
+    static_assert(sizeof(s_xt) >= (size_t)EB_CHUNK_SNPS * CP * sizeof(float), "the dV image fits the tile buffers");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int mcol = lane & 15, q = lane >> 4;
+    const int64_t chunk = blockIdx.x;
+    const int64_t byte0 = chunk * EB_COLS;
+    // a missing call (code 3) is 0 in the model and 1.5 in the init-time products: 1.5 is the FP4 value of the nibble 0011, for the
+    // model the loader clears both bits of every code 3 before the tile goes to LDS
+    const uint32_t kmiss = missing_bf16 == 0u ? 0x55555555u : 0u;
+    // ---- loader: thread -> 4 rows (row quad rq of the 128-sample tile) x 16 byte columns: four 16-byte loads per tile.  (With the bf16
+    // kernel's 4-byte loads -- 16 per thread and tile -- the X loads were not hidden behind the tile's arithmetic at all: 43.5 us
+    // against 25.5 us without them, profiles/r03_p3_fp4.txt.)  The 16 x 4 bytes go through four 4x4 byte transposes into the
+    // column-major LDS tile.  Column c sits in slot (c >> 4) * 8 + (c & 7) + 8 * (c & 8): with the dword stride 33 the 4-byte stores
+    // of a wave (8 column groups x 8 row quads) then fall on every bank twice -- in natural order 16 columns apart means 16 banks
+    // apart and they would pile up four deep.
+    const int cgrp = tid & 7, rq = tid >> 3;
+    const int64_t loff = byte0 + 16 * cgrp;
+    const bool lcol_ok = loff * 4 < M;             // not `< ld`: sub-range launches, see pass 2
+    const int64_t loff_c = lcol_ok ? loff : 0;
+    uint32_t lmask[4];                                        // 16 bytes = 64 SNPs, M need not be a multiple: per dword
+#pragma unroll
+    for (int t = 0; t < 4; ++t) lmask[t] = lt_mask64((loff + 4 * t) * 4, M);
+#ifdef NADM_P3_ABL_NOIDX
+    auto row_idx = [&](int i0, int k) -> int32_t { const int smp = i0 + 4 * rq + k; return smp < b ? smp : b - 1; };
+#else
+    auto row_idx = [&](int i0, int k) -> int32_t { const int smp = i0 + 4 * rq + k; return idx[smp < b ? smp : b - 1]; };
+#endif
+    int32_t rows[4];
+    uint4 xw[4];
+    const uint32_t ld32 = (uint32_t)ld;                       // (a row is < 4 GB)
+    const bool col_edge = (byte0 + EB_COLS) * 4 > M;          // block-uniform: only the last chunk has byte columns past M
+    auto fetch_rows = [&](int i0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rows[k] = row_idx(i0, k);
+    };
+    auto issue = [&]() {
+#ifdef NADM_P3_ABL_NOLOAD
+        return;
+#endif
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xw[k] = *reinterpret_cast<const uint4*>(xp + ((uint64_t)(uint32_t)rows[k] * ld32 + (uint64_t)loff_c));   // one v_mad_u64_u32
+    };
+    auto col_slot = [](int c) -> int { return ((c >> 4) << 3) | (c & 7) | ((c & 8) << 3); };
+    // dword t of the four rows -> byte columns 16 cgrp + 4t .. + 3, samples 4 rq .. 4 rq + 3 of tile buffer `buf`.  EDGE: the tile
+    // reaches past the batch or the chunk past M (tile- / block-uniform): only then are rows / columns masked
+    auto commit = [&](int buf, int i0, int t, auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        uint32_t d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t raw = t == 0 ? xw[k].x : (t == 1 ? xw[k].y : (t == 2 ? xw[k].z : xw[k].w));
+            uint32_t r = raw;
+            if constexpr (EDGE) r = raw & lmask[t] & lt_mask(i0 + 4 * rq + k, b);  // (no selects: nadm_common.h)
+            const uint32_t m3 = r & (r >> 1) & kmiss;
+            d[k] = r ^ (m3 | (m3 << 1));
+        }
+        // 4x4 byte transpose: e[c] = byte c of rows 0..3
+        const uint32_t t01l = __builtin_amdgcn_perm(d[1], d[0], 0x05010400u);   // d0.b0 d1.b0 d0.b1 d1.b1
+        const uint32_t t01h = __builtin_amdgcn_perm(d[1], d[0], 0x07030602u);   // d0.b2 d1.b2 d0.b3 d1.b3
+        const uint32_t t23l = __builtin_amdgcn_perm(d[3], d[2], 0x05010400u);
+        const uint32_t t23h = __builtin_amdgcn_perm(d[3], d[2], 0x07030602u);
+        const uint32_t e0 = __builtin_amdgcn_perm(t23l, t01l, 0x05040100u);     // t01l.b0 t01l.b1 t23l.b0 t23l.b1
+        const uint32_t e1 = __builtin_amdgcn_perm(t23l, t01l, 0x07060302u);
+        const uint32_t e2 = __builtin_amdgcn_perm(t23h, t01h, 0x05040100u);
+        const uint32_t e3 = __builtin_amdgcn_perm(t23h, t01h, 0x07060302u);
+        uint8_t* base = &s_xt[buf][col_slot(16 * cgrp + 4 * t) * EB4_XS + 4 * rq];     // (slots of columns 4t .. 4t + 3 are consecutive)
+        *reinterpret_cast<uint32_t*>(base) = e0;
+        *reinterpret_cast<uint32_t*>(base + EB4_XS) = e1;
+        *reinterpret_cast<uint32_t*>(base + 2 * EB4_XS) = e2;
+        *reinterpret_cast<uint32_t*>(base + 3 * EB4_XS) = e3;
+    };
+
+    f32x4 acc[EB_G][4];
+#pragma unroll
+    for (int g = 0; g < EB_G; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[g][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // prologue: tile 0 committed, tile 1 in flight, the row indices of tile 2 fetched.  A tile's loads are issued one tile phase
+    // (~1.5 k cycles of work per wave) before they are committed, its row indices one phase before that.
+    const int ntiles = (b + DZI_TS - 1) / DZI_TS;
+    fetch_rows(0);
+    issue();
+    fetch_rows(DZI_TS);
+    auto commit_tile = [&](int buf, int i0) {
+        if (col_edge || i0 + DZI_TS > b) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) commit(buf, i0, t, std::true_type{});
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) commit(buf, i0, t, std::false_type{});
+        }
+    };
+    commit_tile(0, 0);
+    issue();
+    fetch_rows(2 * DZI_TS);
+    __syncthreads();
+
+    for (int T = 0; T < ntiles; ++T) {
+        const int cur = T & 1;
+        // the tile's A operands: 7 x 16 B per lane of the image every block of the launch reads (L2)
+#ifdef NADM_P3_ABL_NOZ
+        const uint4* zi = dzimg + lane + (T > 100 ? 64 : 0);
+#else
+        const uint4* zi = dzimg + (int64_t)T * DZI_TILE_U4 + lane;
+#endif
+        uint4 z[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) z[k] = zi[64 * k];
+        const uint32_t zd[24] = {z[0].x, z[0].y, z[0].z, z[0].w, z[1].x, z[1].y, z[1].z, z[1].w, z[2].x, z[2].y, z[2].z, z[2].w,
+                                 z[3].x, z[3].y, z[3].z, z[3].w, z[4].x, z[4].y, z[4].z, z[4].w, z[5].x, z[5].y, z[5].z, z[5].w};
+        const int zscale = (int)z[6].x;
+#pragma unroll
+        for (int g = 0; g < EB_G; ++g) {
+            // the NEXT tile goes to the other buffer first thing, and the loads of the tile after that take its registers: they have
+            // the whole phase to arrive (issued half way through it they did not: 41 us against 25.5 without the loads)
+            if (g == 0) {
+                if (T + 1 < ntiles) commit_tile(cur ^ 1, (T + 1) * DZI_TS);
+                issue();                                                    // (clamped indices: issuing past the batch is harmless)
+                fetch_rows((T + 3) * DZI_TS);
+            }
+            // the lane's byte column, samples 32q .. 32q + 31: 8 words.  Bit transposition: words (2i, 2i + 1) hold samples 8i..8i+3 and
+            // 8i+4..8i+7, four 2-bit fields (SNPs) per byte.  u takes fields 0, 1 of both words into the low / high nibble of every
+            // byte, v fields 2, 3; masking with 0x33 then leaves one field per nibble: register i of field j's operand = nibbles
+            // (sample 8i + t, sample 8i + 4 + t), t = 0..3 -- the order dzi_sample() names
+            const uint32_t* colp = reinterpret_cast<const uint32_t*>(&s_xt[cur][col_slot(wave * (16 * EB_G) + g * 16 + mcol) * EB4_XS + 32 * q]);
+            i32x8_t bx[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bx[j] = (i32x8_t){0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t w0 = colp[2 * i], w1 = colp[2 * i + 1];
+                const uint32_t uu = (w0 & 0x0F0F0F0Fu) | ((w1 << 4) & 0xF0F0F0F0u);
+                const uint32_t vv = ((w0 >> 4) & 0x0F0F0F0Fu) | (w1 & 0xF0F0F0F0u);
+                bx[0][i] = (int)(uu & 0x33333333u);
+                bx[1][i] = (int)((uu >> 2) & 0x33333333u);
+                bx[2][i] = (int)(vv & 0x33333333u);
+                bx[3][i] = (int)((vv >> 2) & 0x33333333u);
+            }
+#ifndef NADM_P3_ABL_NOMFMA
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const i32x8_t az = {(int)zd[6 * rg], (int)zd[6 * rg + 1], (int)zd[6 * rg + 2], (int)zd[6 * rg + 3], (int)zd[6 * rg + 4], (int)zd[6 * rg + 5], 0, 0};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    switch (rg) {          // (the byte of the scale word is an immediate of the instruction)
+                        case 0: acc[g][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(az, bx[j], acc[g][j], 2, 4, 0, zscale, 0, 127); break;
+                        case 1: acc[g][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(az, bx[j], acc[g][j], 2, 4, 1, zscale, 0, 127); break;
+                        case 2: acc[g][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(az, bx[j], acc[g][j], 2, 4, 2, zscale, 0, 127); break;
+                        default: acc[g][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(az, bx[j], acc[g][j], 2, 4, 3, zscale, 0, 127); break;
+                    }
+                }
+            }
+#else
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[g][j][0] += __int_as_float(bx[j][0] ^ bx[j][1] ^ bx[j][2] ^ bx[j][3]) + __uint_as_float(zd[6 * g + j] ^ (uint32_t)zscale);
+#endif
+        }
+        __syncthreads();
+    }
+
+    // ---- fold the piece parities (rows c and c + 8 sit 32 lanes apart) into an LDS image of the block's dV rows [512 SNPs][CP], then
+    // every thread handles whole float4s of that contiguous region: full 16 B/lane lines for the gradient store, or -- single-GPU
+    // step -- for Adam on these V rows (3 reads + 3 writes per element: it has to be coalesced) ----
+    float* s_dv = reinterpret_cast<float*>(&s_xt[0][0]);       // (the barrier that ends the last tile has passed)
+#pragma unroll
+    for (int g = 0; g < EB_G; ++g) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u = acc[g][j][r];
+                o[r] = u + __shfl_xor(u, 32, 64);
+            }
+            const int ml = (wave * (16 * EB_G) + g * 16 + mcol) * 4 + j;          // SNP within the block's 512
+            if (q < 2 && 4 * q < CP) *reinterpret_cast<float4*>(s_dv + ml * CP + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int ROW4 = CP / 4;
+        const int64_t m0 = chunk * EB_CHUNK_SNPS;
+        for (int e = tid; e < EB_CHUNK_SNPS * ROW4; e += 256) {
+            const int64_t m = m0 + e / ROW4;
+            if (m < M) {
+                const float4 g4 = *reinterpret_cast<const float4*>(s_dv + 4 * e);
+                const int64_t o = m * CP + 4 * (e % ROW4);
+#ifdef NADM_P3_ABL_NOADAM
+                if (g4.x == 123.456f) *reinterpret_cast<float4*>(dV + o) = g4;
+                continue;
+#endif
+                if (ad.m != nullptr) adam_float4(Vrw + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.inv_bc2, ad.grad_scale, false);
+                else *reinterpret_cast<float4*>(dV + o) = g4;
+            }
+        }
+    }
+}
+
 // ---- SNPs per lane in pass 2 as a function of the padded head width (register budget ~128) ----
 constexpr int dec_spl(int kp) { return kp <= 8 ? 8 : (kp <= 16 ? 4 : (kp <= 32 ? 2 : 1)); }
 
@@ -1715,11 +1959,23 @@ extern "C" int nadm_decode_bce_images(const uint8_t* xp, int64_t ld, const int32
     return decode_bce_impl(xp, ld, idx, b, M, P, kp, Q, SP, dP, dqpart, losspart, with_loss, stream, xg, ad, static_cast<const uint4*>(qimg));
 }
 
+extern "C" int64_t nadm_dz_image_bytes(int32_t b) { return (int64_t)((b + nadm::DZI_TS - 1) / nadm::DZI_TS) * nadm::DZI_TILE_U4 * 16; }
+
+extern "C" int nadm_dz_image(const float* dZ, int32_t b, int32_t CP, void* dzimg, void* stream) {
+    if (!dZ || !dzimg) return fail("nadm_dz_image: null pointer");
+    if (b <= 0 || CP <= 0 || CP > 8) return fail("nadm_dz_image: b > 0 and 0 < CP <= 8 (the matrix-core pass 3)");
+    if ((uintptr_t)dzimg & 15) return fail("nadm_dz_image: the image must be 16-byte aligned");
+    hipLaunchKernelGGL(dz_image_kernel, dim3((unsigned)((b + DZI_TS - 1) / DZI_TS)), dim3(256), 0, (hipStream_t)stream, dZ, b, CP, (uint4*)dzimg);
+    return check_launch("dz_image");
+}
+
 static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                           const float* dZ, int32_t CP, float* dV, void* stream, uint32_t missing_bf16,
+                           const float* dZ, const void* dzimg, int32_t CP, float* dV, void* stream, uint32_t missing_bf16,
                            float* Vrw = nullptr, AdamFused ad = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0},
                            const nadm_mlp_weights_t* mw = nullptr) {
     if (!xp || !idx || !dZ || !dV) return fail("nadm_encode_bwd: null pointer");
+    if (CP <= 8 && (!dzimg || ((uintptr_t)dzimg & 15)))
+        return fail("nadm_encode_bwd: C <= 8 runs on the FP4 x FP6 matrix instruction and needs the operand image of dZ (nadm_dz_image), 16-byte aligned");
     if (b <= 0 || M <= 0) return fail("nadm_encode_bwd: empty batch or M");
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_encode_bwd: ld must be a multiple of 16 and >= ceil(M/4)");
     dim3 grid((unsigned)((M + 1023) / 1024)), block(256);
@@ -1734,9 +1990,15 @@ static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
             extra = (int64_t)side.gx * nadm_sample_splits(b);
         }
         dim3 g2((unsigned)((M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS + extra));
+#ifdef NADM_P3_BF16
         if (CP == 4) hipLaunchKernelGGL((encode_bwd_mfma_kernel<4>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV, missing_bf16, Vrw, ad, side);
         else hipLaunchKernelGGL((encode_bwd_mfma_kernel<8>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV, missing_bf16, Vrw, ad, side);
         return check_launch("encode_bwd_mfma");
+#else
+        if (CP == 4) hipLaunchKernelGGL((encode_bwd_fp4_kernel<4>), g2, block, 0, st, xp, ld, idx, b, M, (const uint4*)dzimg, dV, missing_bf16, Vrw, ad, side);
+        else hipLaunchKernelGGL((encode_bwd_fp4_kernel<8>), g2, block, 0, st, xp, ld, idx, b, M, (const uint4*)dzimg, dV, missing_bf16, Vrw, ad, side);
+        return check_launch("encode_bwd_fp4");
+#endif
     }
     switch (CP) {
         case 12: hipLaunchKernelGGL((encode_bwd_kernel<12>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
@@ -1751,23 +2013,23 @@ static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
 }
 
 extern "C" int nadm_encode_bwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                                    const float* dZ, int32_t CP, float* V, float* dV, const nadm_adam_t* adam,
+                                    const float* dZ, const void* dzimg, int32_t CP, float* V, float* dV, const nadm_adam_t* adam,
                                     const nadm_mlp_weights_t* weights, void* stream) {
     AdamFused ad;
     if (adam_fused_args(adam, "nadm_encode_bwd_step: Adam state is NULL", &ad)) return 1;
     if (ad.m && (!V || ((uintptr_t)V & 15))) return fail("nadm_encode_bwd_step: V must be non-NULL and 16-byte aligned");
     if (weights && (!weights->hd || !weights->Zn || !weights->H || !weights->dL || !weights->dHpre || !weights->dgp || !weights->small_part))
         return fail("nadm_encode_bwd_step: null pointer in the MLP weight-gradient arguments");
-    return encode_bwd_impl(xp, ld, idx, b, M, dZ, CP, dV, stream, 0u, V, ad, weights);
+    return encode_bwd_impl(xp, ld, idx, b, M, dZ, dzimg, CP, dV, stream, 0u, V, ad, weights);
 }
 
 extern "C" int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                               const float* dZ, int32_t CP, float* dV, void* stream) {
-    return encode_bwd_impl(xp, ld, idx, b, M, dZ, CP, dV, stream, 0u);
+                               const float* dZ, const void* dzimg, int32_t CP, float* dV, void* stream) {
+    return encode_bwd_impl(xp, ld, idx, b, M, dZ, dzimg, CP, dV, stream, 0u);
 }
 
 extern "C" int nadm_pca_project_t(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                                  const float* Y, int32_t CP, float* out, void* stream) {
+                                  const float* Y, const void* yimg, int32_t CP, float* out, void* stream) {
     if (CP > 8) return fail("nadm_pca_project_t: only the matrix-core pass (CP <= 8) has the missing = 1.5 variant");
-    return encode_bwd_impl(xp, ld, idx, b, M, Y, CP, out, stream, 0x3FC0u);
+    return encode_bwd_impl(xp, ld, idx, b, M, Y, yimg, CP, out, stream, 0x3FC0u);
 }

@@ -554,9 +554,9 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
                                                              const float* __restrict__ Z, const float* __restrict__ rinv,
                                                              const float* __restrict__ H, const float* __restrict__ Q,
                                                              float* __restrict__ dL, float* __restrict__ dHpre,
-                                                             float* __restrict__ dgp, float* __restrict__ dZ,
+                                                             float* __restrict__ dgp, float* dZ,
                                                              const float* __restrict__ losspart, int64_t n_loss,
-                                                             double* __restrict__ loss_acc) {
+                                                             double* __restrict__ loss_acc, uint4* dzimg, int* dzcnt) {
     __shared__ __attribute__((aligned(16))) float s_grp[1024];
     __shared__ float s_dzn[SB * 8];
     static_assert(SB * 8 == 32, "block_reduce_lds<32>");
@@ -764,8 +764,40 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
                 dz = ri * (dzn[c] * g[c]) - z * ri3 * mean_tz;
                 dgv = dzn[c] * z * ri;
             }
-            dZ[i * CP + c] = dz;
+            // (image path: written THROUGH to memory -- the group's last block, possibly on another XCD with its own L2, reads it back)
+            if (dzimg != nullptr) __hip_atomic_store(dZ + i * CP + c, dz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else dZ[i * CP + c] = dz;
             dgp[i * CP + c] = dgv;
+        }
+    }
+    // ---- dZ as the operand image of pass 3 (nadm_common.h, dzi_build_piece): a lane of the matrix instruction holds 32 consecutive
+    // samples of one column = the rows of 32 / SB blocks of this launch.  The block that finishes a group of 32 samples LAST builds
+    // the group's image (one wave: 8 columns x 8 pieces); the counters return to zero for the next launch.  (As a launch of its own
+    // the image cost 5 us + a launch gap per step, more than the matrix instruction saved in pass 3.)
+    // Ordering without a fence: the dZ stores above go through to memory (a __threadfence here is a write-back of the XCD's whole L2,
+    // which this kernel has just filled with dHpre: 200 of them took the kernel from 17 to 36-42 us), the wave waits for their
+    // acknowledgement, then the block is counted with a device-scope atomic; the last block reads with device-scope loads.
+    if (dzimg != nullptr) {
+        __shared__ int s_last;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): this wave's dZ stores have been acknowledged ...
+        __syncthreads();
+        const int grp = i0 / 32;
+        if (tid == 0) {
+            const int in_group = (min(b, 32 * grp + 32) - 32 * grp + SB - 1) / SB;
+            const int old = __hip_atomic_fetch_add(&dzcnt[grp], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... before the block is counted
+            s_last = old == in_group - 1;
+            if (s_last) __hip_atomic_store(&dzcnt[grp], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (s_last) {                                                 // block-uniform
+            // the group's 32 x 8 values: ONE load per thread, parked in LDS; 64 threads then cut a column's 32 values into a piece each
+            float* const s_grpz = s_part;                             // (free since the block reduction)
+            const int smp = 32 * grp + (tid >> 3), cc = tid & 7;
+            float x = 0.f;
+            if (smp < b && cc < CP) x = __hip_atomic_load(dZ + (int64_t)smp * CP + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_grpz[tid] = x;
+            __syncthreads();
+            if (tid < 64) dzi_build_piece<true>(s_grpz, b, CP, dzimg, grp >> 2, grp & 3, tid >> 3, tid & 7);
         }
     }
 }
@@ -1416,12 +1448,15 @@ extern "C" int nadm_sum_rows(const float* src, int64_t rows, int64_t n, float* o
     return check_launch("sum_rows");
 }
 
-extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, float* dqpart, int64_t M, int32_t b,
-                            const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
-                            float* dL, float* dHpre, float* dgp, float* small_part, float* dZ, float* grad_small,
-                            const float* losspart, int64_t n_loss, double* loss_acc, void* stream) {
+static int mlp_bwd_impl(const nadm_heads_t* hd, const float* small, float* dqpart, int64_t M, int32_t b,
+                        const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
+                        float* dL, float* dHpre, float* dgp, float* small_part, float* dZ, float* grad_small,
+                        const float* losspart, int64_t n_loss, double* loss_acc, void* dzimg, int32_t* dz_counters, void* stream) {
     if (!hd || !small || !dqpart || !Z || !rinv || !Zn || !H || !Q || !dL || !dHpre || !dgp || !small_part || !dZ)
         return fail("nadm_mlp_bwd: null pointer");
+    if (dzimg && (!dz_counters || hd->CP > 8 || ((uintptr_t)dzimg & 15)))
+        return fail("nadm_mlp_bwd_image: the image needs its group counters, C <= 8 and 16-byte alignment");
+    bool image_done = false;
     if (n_loss > 0 && (!losspart || !loss_acc)) return fail("nadm_mlp_bwd: n_loss > 0 needs losspart and loss_acc");
     if (b <= 0) return fail("nadm_mlp_bwd: empty batch");
     hipStream_t st = (hipStream_t)stream;
@@ -1446,7 +1481,8 @@ extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, float* d
         const size_t lds = (size_t)3 * MLP_SB * hd->SP * 4;                      // s_dl + the block's Q rows + dL
         const bool c8 = hd->C == 8 && ((reinterpret_cast<uintptr_t>(small) + 4 * (size_t)hd->w1_off) & 15) == 0;
 #define NADM_BWD_LAUNCH(JH, C8) hipLaunchKernelGGL((mlp_bwd_a_fast_kernel<MLP_SB, JH, C8>), grid, dim3(256), lds, st, *hd, small, dqpart, dqc, b, Z, rinv, H, Q, \
-                                                   dL, dHpre, dgp, dZ, losspart, n_loss, loss_acc)
+                                                   dL, dHpre, dgp, dZ, losspart, n_loss, loss_acc, (uint4*)dzimg, dz_counters)
+        image_done = dzimg != nullptr;
         if (hd->Hd <= 1024) { if (c8) NADM_BWD_LAUNCH(4, true); else NADM_BWD_LAUNCH(4, false); }
         else { if (c8) NADM_BWD_LAUNCH(8, true); else NADM_BWD_LAUNCH(8, false); }
 #undef NADM_BWD_LAUNCH
@@ -1460,8 +1496,26 @@ extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, float* d
                            dL, dHpre, dgp, dZ, losspart, n_loss, loss_acc);
     }
     if (check_launch("mlp_bwd")) return 1;
+    if (dzimg && !image_done && nadm_dz_image(dZ, b, hd->CP, dzimg, stream)) return 1;     // the generic kernels: the image as a launch of its own
     if (!grad_small) return 0;                       // the caller runs nadm_mlp_bwd_weights itself (possibly on another stream)
     return nadm_mlp_bwd_weights(hd, b, Zn, H, dL, dHpre, dgp, small_part, grad_small, stream);
+}
+
+extern "C" int nadm_mlp_bwd(const nadm_heads_t* hd, const float* small, float* dqpart, int64_t M, int32_t b,
+                            const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
+                            float* dL, float* dHpre, float* dgp, float* small_part, float* dZ, float* grad_small,
+                            const float* losspart, int64_t n_loss, double* loss_acc, void* stream) {
+    return mlp_bwd_impl(hd, small, dqpart, M, b, Z, rinv, Zn, H, Q, dL, dHpre, dgp, small_part, dZ, grad_small, losspart, n_loss, loss_acc,
+                        nullptr, nullptr, stream);
+}
+
+extern "C" int nadm_mlp_bwd_image(const nadm_heads_t* hd, const float* small, float* dqpart, int64_t M, int32_t b,
+                                  const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
+                                  float* dL, float* dHpre, float* dgp, float* small_part, float* dZ, float* grad_small,
+                                  const float* losspart, int64_t n_loss, double* loss_acc, void* dzimg, int32_t* dz_counters, void* stream) {
+    if (!dzimg || !dz_counters) return fail("nadm_mlp_bwd_image: null pointer");
+    return mlp_bwd_impl(hd, small, dqpart, M, b, Z, rinv, Zn, H, Q, dL, dHpre, dgp, small_part, dZ, grad_small, losspart, n_loss, loss_acc,
+                        dzimg, dz_counters, stream);
 }
 
 extern "C" int nadm_mlp_bwd_weights(const nadm_heads_t* hd, int32_t b, const float* Zn, const float* H, const float* dL,

@@ -73,6 +73,11 @@ class Engine:
         self._qimg_head = int(lib.nadm_q_image_bytes(b))
         self.qimg = torch.zeros(len(L.ks) * self._qimg_head, dtype=torch.uint8, device=device) if self.q_images else None
         self._qimg_b = -1
+        # dZ as the FP6 operand image of pass 3 (C <= 8; nadm_dz_image): built once per step from dZ
+        self._dzimg = (torch.zeros(int(lib.nadm_dz_image_bytes(b)), dtype=torch.uint8, device=device)
+                       if L.CP <= 8 and not self._CPU_TEST_DOUBLE else None)
+        self._dzcnt = torch.zeros((b + 31) // 32, dtype=torch.int32, device=device)      # group counters of nadm_mlp_bwd_image
+        self._dzimg_b = -1                               # batch size the image is valid for (-1: rebuild from dZ)
         self.loss_acc = torch.zeros(2, dtype=torch.float64, device=device)
         self.xp: Optional[torch.Tensor] = None          # packed genotypes [rows, ld]
         self.step_count = 0
@@ -380,11 +385,30 @@ class Engine:
         ``weights=False`` leaves the weight gradients to nadm_mlp_bwd_weights."""
         L, st = self.lay, _stream()
         self.flush_small()                                    # small_part is scratch of this call (no-op after a pass 1)
-        check(lib.nadm_mlp_bwd(C.byref(L.heads), ptr(self.small), ptr(self.dqpart if dq_src is None else dq_src),
-                               L.M if dq_M is None else dq_M, b, ptr(self.Z), ptr(self.rinv), ptr(self.Zn),
-                               ptr(self.H), ptr(self.Q), ptr(self.dL), ptr(self.dHpre), ptr(self.dgp), ptr(self.small_part),
-                               ptr(self.dZ), ptr(self.gsmall) if weights else None, ptr(self.losspart),
-                               n_loss, ptr(self.loss_acc), st), "mlp_bwd")
+        args = (C.byref(L.heads), ptr(self.small), ptr(self.dqpart if dq_src is None else dq_src),
+                L.M if dq_M is None else dq_M, b, ptr(self.Z), ptr(self.rinv), ptr(self.Zn),
+                ptr(self.H), ptr(self.Q), ptr(self.dL), ptr(self.dHpre), ptr(self.dgp), ptr(self.small_part),
+                ptr(self.dZ), ptr(self.gsmall) if weights else None, ptr(self.losspart), n_loss, ptr(self.loss_acc))
+        if self._dzimg is not None:     # C <= 8: dZ also as the operand image of pass 3, built by the blocks that finish a 32-sample group
+            check(lib.nadm_mlp_bwd_image(*args, ptr(self._dzimg), ptr(self._dzcnt), st), "mlp_bwd_image")
+            self._dzimg_b = b
+        else:
+            check(lib.nadm_mlp_bwd(*args, st), "mlp_bwd")
+
+    def _dz_image(self, b: int):
+        """dZ [b, CP] as the operand image pass 3's matrix instruction consumes (C <= 8; include/nadm.h, nadm_dz_image): built once
+        per step, read by every block of the pass."""
+        L = self.lay
+        if L.CP > 8:
+            return None
+        if self._dzimg_b != b:              # dZ did not come out of mlp_backward (tests that write dZ themselves call invalidate_dz)
+            check(lib.nadm_dz_image(ptr(self.dZ), b, L.CP, ptr(self._dzimg), _stream()), "dz_image")
+            self._dzimg_b = b
+        return ptr(self._dzimg)
+
+    def invalidate_dz(self) -> None:
+        """Call after writing ``dZ`` from outside: the next pass 3 rebuilds its operand image."""
+        self._dzimg_b = -1
 
     def encode_backward(self, idx: torch.Tensor, b: int, on_grad_ready=None, v_parts: int = 1, fused_adam=None,
                         side_weights: bool = False) -> None:
@@ -403,10 +427,11 @@ class Engine:
         else:
             src, rows = self.xp, idx
         self._xg_key = None
+        dzimg = self._dz_image(b)
         for i, (m0, m1) in enumerate(self._snp_ranges(v_parts, 1024)):
             side = mw if i == 0 else None
             if fused_adam is not None or side is not None:    # Adam on these V rows in the epilogue and / or the side blocks
-                check(lib.nadm_encode_bwd_step(C.c_void_p(src.data_ptr() + m0 // 4), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), L.CP,
+                check(lib.nadm_encode_bwd_step(C.c_void_p(src.data_ptr() + m0 // 4), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), dzimg, L.CP,
                                                C.c_void_p(self._big.data_ptr() + m0 * L.CP * fsz),
                                                C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz),
                                                C.byref(self._adam_args(m0 * L.CP, fused_adam)) if fused_adam is not None else None,
@@ -421,7 +446,7 @@ class Engine:
                     check(lib.nadm_small_grads(ptr(self.small_part), int(lib.nadm_sample_splits(b)), L.n_small, ptr(self.gsmall),
                                                ptr(self.small), sa, st), "small_grads")
             else:
-                check(lib.nadm_encode_bwd(C.c_void_p(src.data_ptr() + m0 // 4), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), L.CP,
+                check(lib.nadm_encode_bwd(C.c_void_p(src.data_ptr() + m0 // 4), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), dzimg, L.CP,
                                           C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz), st), "encode_bwd")
             if on_grad_ready is not None:                     # the first piece carries the small gradients in front of it
                 on_grad_ready(0 if i == 0 else self._ns_pad + m0 * L.CP, self._ns_pad + m1 * L.CP)

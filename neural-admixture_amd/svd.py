@@ -91,7 +91,9 @@ class _Rows:
             Y = torch.zeros((N, 8), dtype=torch.float32, device=dev)
             Y[:, :w] = Qd[:, g:g + w]
             o = torch.empty((M, 8), dtype=torch.float32, device=dev)
-            check(lib.nadm_pca_project_t(ptr(self.xp), self.ld, ptr(idx), N, M, ptr(Y), 8, ptr(o), st), "pca_project_t")
+            yimg = torch.empty(int(lib.nadm_dz_image_bytes(N)), dtype=torch.uint8, device=dev)     # operand image of Y (include/nadm.h)
+            check(lib.nadm_dz_image(ptr(Y), N, 8, ptr(yimg), st), "dz_image")
+            check(lib.nadm_pca_project_t(ptr(self.xp), self.ld, ptr(idx), N, M, ptr(Y), ptr(yimg), 8, ptr(o), st), "pca_project_t")
             out[:, g:g + w] = o[:, :w]
         out *= 2.0
         return out if keep_on_device else np.ascontiguousarray(out.t().cpu().numpy())

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in nadm.h but not exported"
     assert declared == set(_lib.EXPORTS)               # the Python binding covers the whole header
-    assert _lib.lib.nadm_abi_version() == 7
+    assert _lib.lib.nadm_abi_version() == 8
 
 
 def test_argument_validation_without_gpu():
@@ -63,7 +63,12 @@ def test_argument_validation_of_the_round1_additions(tmp_path):
     with pytest.raises(RuntimeError, match="CP <= 8"):
         check(lib.nadm_pca_project(p, 16, p, 4, 8, p, 12, p, None), "pca_project")
     with pytest.raises(RuntimeError, match="CP <= 8"):
-        check(lib.nadm_pca_project_t(p, 16, p, 4, 8, p, 12, p, None), "pca_project_t")
+        check(lib.nadm_pca_project_t(p, 16, p, 4, 8, p, p, 12, p, None), "pca_project_t")
+    with pytest.raises(RuntimeError, match="operand image of dZ"):
+        check(lib.nadm_encode_bwd(p, 16, p, 4, 8, p, None, 8, p, None), "encode_bwd")
+    with pytest.raises(RuntimeError, match="0 < CP <= 8"):
+        check(lib.nadm_dz_image(p, 4, 12, p, None), "dz_image")
+    assert lib.nadm_dz_image_bytes(800) == 7 * 7 * 64 * 16 and lib.nadm_dz_image_bytes(128) == 7 * 64 * 16
     with pytest.raises(RuntimeError, match="number of classes"):
         check(lib.nadm_supervised_ce(p, 8, 3, 4, p, None, 4, 5, 100.0, p, p, None), "supervised_ce")
     with pytest.raises(RuntimeError, match="k <= kp <= SP"):

@@ -100,6 +100,71 @@ def test_pack_unpack_bit_exact():
         assert np.array_equal(ud.cpu().numpy(), Gm & 3)
 
 
+def decode_dz_image(img_u8: np.ndarray, b: int, CP: int) -> np.ndarray:
+    """The operand image of dZ (include/nadm.h, nadm_dz_image; layout in csrc/nadm_common.h) back to [b, CP] values: per tile of 128
+    samples 7 x 64 uint4; lane l = 16 q + 8 parity + c holds, for row group rg, 32 FP6 (E2M3) codes in dwords 6 rg .. 6 rg + 5 (code e
+    at bits 6 e ..) and the E8M0 scale in byte rg of uint4 6's first dword; element e of K-block q is sample
+    32 q + 8 (e >> 3) + 4 (e & 1) + ((e & 7) >> 1); a value is the sum of its eight pieces."""
+    u32 = img_u8.view(np.uint32)
+    ntiles = (b + 127) // 128
+    out = np.zeros((ntiles * 128, 8), dtype=np.float64)
+    for T in range(ntiles):
+        tile = u32[T * 7 * 64 * 4:(T + 1) * 7 * 64 * 4].reshape(7, 64, 4)
+        for l in range(64):
+            q, c = l >> 4, l & 7
+            dw = tile[:6, l, :].reshape(24)
+            sc = int(tile[6, l, 0])
+            for rg in range(4):
+                bits = 0
+                for i in range(6):
+                    bits |= int(dw[6 * rg + i]) << (32 * i)
+                scale = 2.0 ** (((sc >> (8 * rg)) & 255) - 127)
+                for e in range(32):
+                    code = (bits >> (6 * e)) & 63
+                    ex, m = (code >> 3) & 3, code & 7
+                    val = m / 8.0 if ex == 0 else (1 + m / 8.0) * 2.0 ** (ex - 1)
+                    if code & 32:
+                        val = -val
+                    smp = 128 * T + 32 * q + 8 * (e >> 3) + 4 * (e & 1) + ((e & 7) >> 1)
+                    out[smp, c] += val * scale
+    return out[:b, :CP]
+
+
+@pytest.mark.parametrize("b", [800, 790, 37])
+def test_dz_operand_image_of_pass3(b):
+    """Pass 3 (C <= 8) consumes dZ as FP6 pieces with block scales.  The image nadm_mlp_bwd_image leaves behind -- built by whichever
+    block of the launch completes a 32-sample group last -- and the one nadm_dz_image builds from dZ must both decode to dZ: exactly for
+    elements within 2^-8 of their block's (32 samples x column) largest magnitude, to 2^-31 of that maximum otherwise."""
+    from neural_admixture_amd._lib import lib, check, ptr
+    rng = np.random.default_rng(b)
+    N, M, Hd, ks = 800, 4096, 64, [5]
+    Gm = O.synth_genotypes(N, M, 3, seed=5, missing=0.02)
+    V0 = (rng.standard_normal((M, 8)) / np.sqrt(M)).astype(np.float32)
+    P0 = rng.uniform(0.02, 0.98, size=(sum(ks), M)).astype(np.float32)
+    p = O.make_params(2, V0, P0, Hd, ks)
+    e = make_engine(Gm, p, N)
+    idx = torch.arange(b, dtype=torch.int32, device=e.device)
+    for _ in range(2):                                   # twice: the group counters must have returned to zero
+        e._dzimg.zero_()
+        e.forward(idx, b)
+        e.backward(idx, b, True)
+        torch.cuda.synchronize()
+        assert int(e._dzcnt.abs().sum().item()) == 0
+        CP = e.lay.CP
+        dZ = e.dZ.cpu().numpy()[: b * CP].reshape(b, CP).astype(np.float64)
+        fused = decode_dz_image(e._dzimg.cpu().numpy(), b, CP)
+        alone = torch.zeros_like(e._dzimg)
+        check(lib.nadm_dz_image(ptr(e.dZ), b, CP, ptr(alone), None))
+        torch.cuda.synchronize()
+        assert np.array_equal(fused, decode_dz_image(alone.cpu().numpy(), b, CP))
+        pad = np.zeros((((b + 31) // 32) * 32, CP))
+        pad[:b] = np.abs(dZ)
+        blockmax = np.repeat(pad.reshape(-1, 32, CP).max(axis=1), 32, axis=0)[:b]
+        assert np.all(np.abs(fused - dZ) <= blockmax * 2.0 ** -31)
+        near = np.abs(dZ) >= blockmax * 2.0 ** -8
+        assert np.array_equal(fused[near], dZ[near])
+
+
 @pytest.mark.parametrize("name", ["one_step_k3", "one_step_multihead", "one_step_k8_h1024", "one_step_edge",
                                   "one_step_supervised", "one_step_k7_h1024", "one_step_heads2to10"])
 def test_one_step_against_reference_fixture(name):
@@ -579,7 +644,8 @@ def test_full_width_against_torch_fp32_on_device(b, M, ks):
     # linearity of pass 3 in dZ: dV(2*dZ) == 2*dV(dZ) exactly (power-of-two scaling is exact in fp32)
     g1 = e.gV().clone()
     e.dZ.mul_(2.0)
-    check(lib.nadm_encode_bwd(ptr(e.xp), e.ld, ptr(idx), b, M, ptr(e.dZ), e.lay.CP, ptr(e.gbig), None))
+    e.invalidate_dz()
+    check(lib.nadm_encode_bwd(ptr(e.xp), e.ld, ptr(idx), b, M, ptr(e.dZ), e._dz_image(b), e.lay.CP, ptr(e.gbig), None))
     torch.cuda.synchronize()
     assert torch.equal(e.gV(), 2 * g1)
 
@@ -1116,9 +1182,11 @@ def test_pass2_gather_byproduct_and_pass3_on_the_compact_copy(K):
     dZ = torch.from_numpy(rng.standard_normal((b, L.CP)).astype(np.float32)).to(dev)
     iota = torch.arange(b, dtype=torch.int32, device=dev)
     dv = []
+    dzimg = torch.empty(int(lib.nadm_dz_image_bytes(b)), dtype=torch.uint8, device=dev)
+    check(lib.nadm_dz_image(ptr(dZ), b, L.CP, ptr(dzimg), None))
     for src, rows in ((e.xp, idx), (outs[1][3], iota)):
         o = torch.zeros(M * L.CP, dtype=torch.float32, device=dev)
-        check(lib.nadm_encode_bwd(ptr(src), e.ld, ptr(rows), b, M, ptr(dZ), L.CP, ptr(o), None))
+        check(lib.nadm_encode_bwd(ptr(src), e.ld, ptr(rows), b, M, ptr(dZ), ptr(dzimg), L.CP, ptr(o), None))
         dv.append(o)
     torch.cuda.synchronize()
     assert torch.equal(dv[0], dv[1])
