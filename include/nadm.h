@@ -146,8 +146,9 @@ int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b
                     float* dP, float* dqpart, float* losspart, int32_t with_loss, void* stream);
 
 /* The same pass with a by-product for pass 3: the batch's gathered rows written back to back into xg [b, ld] (row i of
- * the batch -> row i of xg, same byte columns, same row stride; an SNP sub-range launch passes xg + m0/4 like xp).  Pass 3
- * (nadm_encode_bwd) can then be given xg with idx = 0,1,..,b-1: it reads one compact 100 MB region instead of rows
+ * the batch -> row i of xg, same byte columns, same row stride; an SNP sub-range launch passes xg + m0/4 like xp), with every
+ * missing call (code 3) already replaced by 0 -- the model's input (neural_admixture.py:170).  Pass 3 (nadm_encode_bwd) can then
+ * be given xg with idx = 0,1,..,b-1 and flags = NADM_X_CLEAN: it reads one compact 100 MB region instead of rows
  * scattered over the resident matrix (at 12.5 GB resident the scattered reads cost it 13 % translation-cache misses and
  * 16 us of 68).  No reference counterpart: the reference re-gathers the unpacked batch per pass (utils.pyx:43-67). */
 int nadm_decode_bce_gather(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
@@ -196,7 +197,7 @@ typedef struct {
 } nadm_mlp_weights_t;
 int nadm_encode_bwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                          const float* dZ, const void* dzimg, int32_t CP, float* V, float* dV, const nadm_adam_t* adam,
-                         const nadm_mlp_weights_t* weights, void* stream);
+                         const nadm_mlp_weights_t* weights, int32_t flags, void* stream);
 int nadm_small_grads(const float* small_part, int32_t splits, int32_t n_small, float* grad_small, float* small,
                      const nadm_adam_t* adam, void* stream);
 /* nadm_encode_fwd of the NEXT step with nadm_small_grads of this one riding in the same launch as side blocks (pass 1 reads
@@ -268,8 +269,9 @@ int nadm_mlp_bwd_image(const nadm_heads_t* hd, const float* small, float* dqpart
                        const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
                        float* dL, float* dHpre, float* dgp, float* small_part, float* dZ, float* grad_small,
                        const float* losspart, int64_t n_loss, double* loss_acc, void* dzimg, int32_t* dz_counters, void* stream);
+#define NADM_X_CLEAN 1     /* flags: the rows handed over are nadm_decode_bce_gather's copy of the batch (missing calls already 0) */
 int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                    const float* dZ, const void* dzimg, int32_t CP, float* dV, void* stream);
+                    const float* dZ, const void* dzimg, int32_t CP, float* dV, int32_t flags, void* stream);
 
 /* ---- a12/a13: Adam(betas .9/.95, eps 1e-8) + restrict_P (neural_admixture.py:187-204,411-412)
  * Flat update of n floats; `step` is the 1-based step count; gradients are multiplied by

@@ -73,14 +73,14 @@ def _load():
         "nadm_q_image_bytes": (C.c_int64, [i32]),
         "nadm_encode_fwd_small": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp]),
         "nadm_encode_fwd_step": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
-        "nadm_encode_bwd_step": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, i32, vp, vp, vp, vp, vp]),
+        "nadm_encode_bwd_step": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, i32, vp, vp, vp, vp, i32, vp]),
         "nadm_small_grads": (C.c_int, [vp, i32, i32, vp, vp, vp, vp]),
         "nadm_mlp_bwd": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]),
         "nadm_mlp_bwd_image": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
         "nadm_mlp_bwd_weights": (C.c_int, [HP, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
         "nadm_sum_rows": (C.c_int, [vp, i64, i64, vp, vp]),
         "nadm_supervised_ce": (C.c_int, [vp, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp]),
-        "nadm_encode_bwd": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, i32, vp, vp]),
+        "nadm_encode_bwd": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, i32, vp, i32, vp]),
         "nadm_dz_image_bytes": (C.c_int64, [i32]),
         "nadm_dz_image": (C.c_int, [vp, i32, i32, vp, vp]),
         "nadm_vcf_parse_gt": (C.c_int, [C.c_char_p, i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]),

@@ -754,6 +754,9 @@ __device__ __forceinline__ void bce_loss_prod2(const f32x2_t d, const f32x2_t de
     asm volatile("" : "+v"(acc));             // pin the accumulation here (see bce_loss_exact2)
 }
 
+// missing calls (code 3) -> 0 in all 16 codes of a word: the model's input (neural_admixture.py:170)
+__device__ __forceinline__ uint32_t clean_codes(uint32_t w) { return w & ~((w & (w >> 1) & 0x55555555u) * 3u); }
+
 // Two genotypes -> two floats in ONE instruction: a nibble 00cc read as FP4 (E2M1) is exactly cc/2 (0, .5, 1), so
 // v_cvt_scalef32_pk_f32_fp4 on byte `sel` of a word whose nibbles hold one 2-bit code each yields x for both.
 __device__ __forceinline__ f32x2_t fp4_pair(const uint32_t w, const int sel) {
@@ -946,11 +949,15 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
     auto commit = [&](int i0) {
         const bool ok = pcol_ok && (i0 + pr < b);
         const uint32_t okm = pcol_okm & lt_mask(i0 + pr, b);           // (a select here is four 23-cycle v_cndmask per tile, nadm_common.h)
-        if (has_piece) *reinterpret_cast<uint4*>(&s_x[pr * RS + pc16 * 16]) = make_uint4(stage.x & okm, stage.y & okm, stage.z & okm, stage.w & okm);
-        // by-product for pass 3: the gathered rows written back to back (row i of the batch -> row i of xg).  Pass 3 then
-        // reads 100 MB in one place instead of 800 rows scattered over the resident matrix, which at 12.5 GB costs it 13 %
-        // misses in the per-CU translation cache (UTCL1) and 16 us; here the store is one instruction per tile and thread.
-        if (xg != nullptr && has_piece && ok) *reinterpret_cast<uint4*>(xg + (int64_t)(i0 + pr) * ld + poff) = stage;
+        // missing calls -> 0 HERE, once per loaded word (r03; until then every lane cleaned the word it took out of the tile): the tile
+        // and the copy for pass 3 both hold the model's input
+        const uint4 cl = make_uint4(clean_codes(stage.x & okm), clean_codes(stage.y & okm), clean_codes(stage.z & okm), clean_codes(stage.w & okm));
+        if (has_piece) *reinterpret_cast<uint4*>(&s_x[pr * RS + pc16 * 16]) = cl;
+        // by-product for pass 3: the gathered rows written back to back (row i of the batch -> row i of xg), missing calls already 0.
+        // Pass 3 then reads 100 MB in one place instead of 800 rows scattered over the resident matrix, which at 12.5 GB costs it
+        // 13 % misses in the per-CU translation cache (UTCL1) and 16 us, and skips its own cleaning; here the store is one
+        // instruction per tile and thread.
+        if (xg != nullptr && has_piece && ok) *reinterpret_cast<uint4*>(xg + (int64_t)(i0 + pr) * ld + poff) = cl;
         if constexpr (QIMG) {
             s_qimg[tid] = qi0;
             s_qimg[tid + NTHR] = qi1;
@@ -1011,8 +1018,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
         uint32_t w;
         if constexpr (NTW == 4) w = *reinterpret_cast<const uint32_t*>(&s_x[(16 * st + n) * RS + wave * 16 + 4 * a]);
         else w = *reinterpret_cast<const uint16_t*>(&s_x[(16 * st + n) * RS + wave * 8 + 2 * a]);
-        w &= ~((w & (w >> 1) & 0x55555555u) * 3u);         // missing (3) -> 0
-        ev = w & 0x33333333u;
+        ev = w & 0x33333333u;                              // (missing calls are 0 already: commit)
         od = (w >> 2) & 0x33333333u;
     };
     // R^T tile t (16 SNPs x 16 samples) from the resident P operands and one sample tile's Q operands
@@ -1458,7 +1464,8 @@ __global__ __launch_bounds__(256) void dz_image_kernel(const float* __restrict__
 
 constexpr int EB4_XS = 132;               // bytes per byte column of the LDS tile: 128 samples + 4 (dword stride 33: the loader's 4-byte
                                           // stores of 32 consecutive column quads and the 4-byte column reads spread over the banks)
-template <int CP>
+// CLEAN_SRC: the rows are pass 2's copy of the batch (xg), missing calls already 0
+template <int CP, bool CLEAN_SRC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void encode_bwd_fp4_kernel(const uint8_t* __restrict__ xp, int64_t ld,
                                                               const int32_t* __restrict__ idx, int b, int64_t M,
                                                               const uint4* __restrict__ dzimg, float* __restrict__ dV,
@@ -1494,11 +1501,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     uint32_t lmask[4];                                        // 16 bytes = 64 SNPs, M need not be a multiple: per dword
 #pragma unroll
     for (int t = 0; t < 4; ++t) lmask[t] = lt_mask64((loff + 4 * t) * 4, M);
-#ifdef NADM_P3_ABL_NOIDX
-    auto row_idx = [&](int i0, int k) -> int32_t { const int smp = i0 + 4 * rq + k; return smp < b ? smp : b - 1; };
-#else
     auto row_idx = [&](int i0, int k) -> int32_t { const int smp = i0 + 4 * rq + k; return idx[smp < b ? smp : b - 1]; };
-#endif
     int32_t rows[4];
     uint4 xw[4];
     const uint32_t ld32 = (uint32_t)ld;                       // (a row is < 4 GB)
@@ -1508,9 +1511,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int k = 0; k < 4; ++k) rows[k] = row_idx(i0, k);
     };
     auto issue = [&]() {
-#ifdef NADM_P3_ABL_NOLOAD
-        return;
-#endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) xw[k] = *reinterpret_cast<const uint4*>(xp + ((uint64_t)(uint32_t)rows[k] * ld32 + (uint64_t)loff_c));   // one v_mad_u64_u32
     };
@@ -1525,8 +1525,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const uint32_t raw = t == 0 ? xw[k].x : (t == 1 ? xw[k].y : (t == 2 ? xw[k].z : xw[k].w));
             uint32_t r = raw;
             if constexpr (EDGE) r = raw & lmask[t] & lt_mask(i0 + 4 * rq + k, b);  // (no selects: nadm_common.h)
-            const uint32_t m3 = r & (r >> 1) & kmiss;
-            d[k] = r ^ (m3 | (m3 << 1));
+            if constexpr (CLEAN_SRC) d[k] = r;
+            else { const uint32_t m3 = r & (r >> 1) & kmiss; d[k] = r ^ (m3 | (m3 << 1)); }
         }
         // 4x4 byte transpose: e[c] = byte c of rows 0..3
         const uint32_t t01l = __builtin_amdgcn_perm(d[1], d[0], 0x05010400u);   // d0.b0 d1.b0 d0.b1 d1.b1
@@ -1573,11 +1573,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int T = 0; T < ntiles; ++T) {
         const int cur = T & 1;
         // the tile's A operands: 7 x 16 B per lane of the image every block of the launch reads (L2)
-#ifdef NADM_P3_ABL_NOZ
-        const uint4* zi = dzimg + lane + (T > 100 ? 64 : 0);
-#else
         const uint4* zi = dzimg + (int64_t)T * DZI_TILE_U4 + lane;
-#endif
         uint4 z[7];
 #pragma unroll
         for (int k = 0; k < 7; ++k) z[k] = zi[64 * k];
@@ -1587,7 +1583,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int g = 0; g < EB_G; ++g) {
             // the NEXT tile goes to the other buffer first thing, and the loads of the tile after that take its registers: they have
-            // the whole phase to arrive (issued half way through it they did not: 41 us against 25.5 without the loads)
+            // the whole phase to arrive.  (TWO tiles in flight -- 128 registers, 88 bytes of scratch -- ran 67 us against 50.)
             if (g == 0) {
                 if (T + 1 < ntiles) commit_tile(cur ^ 1, (T + 1) * DZI_TS);
                 issue();                                                    // (clamped indices: issuing past the batch is harmless)
@@ -1611,7 +1607,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 bx[2][i] = (int)(vv & 0x33333333u);
                 bx[3][i] = (int)((vv >> 2) & 0x33333333u);
             }
-#ifndef NADM_P3_ABL_NOMFMA
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const i32x8_t az = {(int)zd[6 * rg], (int)zd[6 * rg + 1], (int)zd[6 * rg + 2], (int)zd[6 * rg + 3], (int)zd[6 * rg + 4], (int)zd[6 * rg + 5], 0, 0};
@@ -1625,10 +1620,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     }
                 }
             }
-#else
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[g][j][0] += __int_as_float(bx[j][0] ^ bx[j][1] ^ bx[j][2] ^ bx[j][3]) + __uint_as_float(zd[6 * g + j] ^ (uint32_t)zscale);
-#endif
         }
         __syncthreads();
     }
@@ -1660,10 +1651,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (m < M) {
                 const float4 g4 = *reinterpret_cast<const float4*>(s_dv + 4 * e);
                 const int64_t o = m * CP + 4 * (e % ROW4);
-#ifdef NADM_P3_ABL_NOADAM
-                if (g4.x == 123.456f) *reinterpret_cast<float4*>(dV + o) = g4;
-                continue;
-#endif
                 if (ad.m != nullptr) adam_float4(Vrw + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.inv_bc2, ad.grad_scale, false);
                 else *reinterpret_cast<float4*>(dV + o) = g4;
             }
@@ -1689,13 +1676,16 @@ static int launch_adam_range(float* p, const float* g, AdamFused ad, int64_t n, 
     return check_launch("adam_range");
 }
 
-// rows idx[0..b) of xp, the byte columns that hold SNPs [0, M) -> rows 0..b-1 of xg (same row stride): what the bf16 pass-2
-// kernel writes as a by-product, as a kernel of its own for the K > 16 / A-B-reference variants of pass 2
+// rows idx[0..b) of xp, the byte columns that hold SNPs [0, M) -> rows 0..b-1 of xg (same row stride), missing calls set to 0: what
+// the bf16 pass-2 kernel writes as a by-product, as a kernel of its own for the K > 16 / A-B-reference variants of pass 2
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx,
                                                           int b, int64_t pieces, uint8_t* __restrict__ xg) {
     const int64_t row = idx[blockIdx.y];
     for (int64_t p = blockIdx.x * 256 + threadIdx.x; p < pieces; p += (int64_t)gridDim.x * 256)
-        *reinterpret_cast<uint4*>(xg + (int64_t)blockIdx.y * ld + p * 16) = *reinterpret_cast<const uint4*>(xp + row * ld + p * 16);
+    {
+        const uint4 w = *reinterpret_cast<const uint4*>(xp + row * ld + p * 16);
+        *reinterpret_cast<uint4*>(xg + (int64_t)blockIdx.y * ld + p * 16) = make_uint4(clean_codes(w.x), clean_codes(w.y), clean_codes(w.z), clean_codes(w.w));
+    }
 }
 
 static int launch_gather_rows(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, uint8_t* xg, hipStream_t st) {
@@ -1970,7 +1960,7 @@ extern "C" int nadm_dz_image(const float* dZ, int32_t b, int32_t CP, void* dzimg
 }
 
 static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                           const float* dZ, const void* dzimg, int32_t CP, float* dV, void* stream, uint32_t missing_bf16,
+                           const float* dZ, const void* dzimg, int32_t CP, float* dV, void* stream, uint32_t missing_bf16, int32_t flags = 0,
                            float* Vrw = nullptr, AdamFused ad = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0},
                            const nadm_mlp_weights_t* mw = nullptr) {
     if (!xp || !idx || !dZ || !dV) return fail("nadm_encode_bwd: null pointer");
@@ -1995,8 +1985,11 @@ static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
         else hipLaunchKernelGGL((encode_bwd_mfma_kernel<8>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV, missing_bf16, Vrw, ad, side);
         return check_launch("encode_bwd_mfma");
 #else
-        if (CP == 4) hipLaunchKernelGGL((encode_bwd_fp4_kernel<4>), g2, block, 0, st, xp, ld, idx, b, M, (const uint4*)dzimg, dV, missing_bf16, Vrw, ad, side);
-        else hipLaunchKernelGGL((encode_bwd_fp4_kernel<8>), g2, block, 0, st, xp, ld, idx, b, M, (const uint4*)dzimg, dV, missing_bf16, Vrw, ad, side);
+#define NADM_P3_LAUNCH(CPV, CL) hipLaunchKernelGGL((encode_bwd_fp4_kernel<CPV, CL>), g2, block, 0, st, xp, ld, idx, b, M, (const uint4*)dzimg, dV, missing_bf16, Vrw, ad, side)
+        const bool clean = (flags & NADM_X_CLEAN) != 0 && missing_bf16 == 0u;
+        if (CP == 4) { if (clean) NADM_P3_LAUNCH(4, true); else NADM_P3_LAUNCH(4, false); }
+        else { if (clean) NADM_P3_LAUNCH(8, true); else NADM_P3_LAUNCH(8, false); }
+#undef NADM_P3_LAUNCH
         return check_launch("encode_bwd_fp4");
 #endif
     }
@@ -2014,18 +2007,18 @@ static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
 
 extern "C" int nadm_encode_bwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                                     const float* dZ, const void* dzimg, int32_t CP, float* V, float* dV, const nadm_adam_t* adam,
-                                    const nadm_mlp_weights_t* weights, void* stream) {
+                                    const nadm_mlp_weights_t* weights, int32_t flags, void* stream) {
     AdamFused ad;
     if (adam_fused_args(adam, "nadm_encode_bwd_step: Adam state is NULL", &ad)) return 1;
     if (ad.m && (!V || ((uintptr_t)V & 15))) return fail("nadm_encode_bwd_step: V must be non-NULL and 16-byte aligned");
     if (weights && (!weights->hd || !weights->Zn || !weights->H || !weights->dL || !weights->dHpre || !weights->dgp || !weights->small_part))
         return fail("nadm_encode_bwd_step: null pointer in the MLP weight-gradient arguments");
-    return encode_bwd_impl(xp, ld, idx, b, M, dZ, dzimg, CP, dV, stream, 0u, V, ad, weights);
+    return encode_bwd_impl(xp, ld, idx, b, M, dZ, dzimg, CP, dV, stream, 0u, flags, V, ad, weights);
 }
 
 extern "C" int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                               const float* dZ, const void* dzimg, int32_t CP, float* dV, void* stream) {
-    return encode_bwd_impl(xp, ld, idx, b, M, dZ, dzimg, CP, dV, stream, 0u);
+                               const float* dZ, const void* dzimg, int32_t CP, float* dV, int32_t flags, void* stream) {
+    return encode_bwd_impl(xp, ld, idx, b, M, dZ, dzimg, CP, dV, stream, 0u, flags);
 }
 
 extern "C" int nadm_pca_project_t(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,

@@ -423,9 +423,9 @@ class Engine:
         ev = self._timed("encode_bwd")
         # rows: the compact copy pass 2 of this step left in xg (rows 0..b-1 = the batch in order), else the resident matrix
         if self._xg_key == (idx.data_ptr(), b) and self._xg is not None:
-            src, rows = self._xg, self._iota
+            src, rows, xflags = self._xg, self._iota, 1       # NADM_X_CLEAN: pass 2's copy holds the model's input (missing = 0)
         else:
-            src, rows = self.xp, idx
+            src, rows, xflags = self.xp, idx, 0
         self._xg_key = None
         dzimg = self._dz_image(b)
         for i, (m0, m1) in enumerate(self._snp_ranges(v_parts, 1024)):
@@ -435,7 +435,7 @@ class Engine:
                                                C.c_void_p(self._big.data_ptr() + m0 * L.CP * fsz),
                                                C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz),
                                                C.byref(self._adam_args(m0 * L.CP, fused_adam)) if fused_adam is not None else None,
-                                               C.byref(side) if side is not None else None, st), "encode_bwd_step")
+                                               C.byref(side) if side is not None else None, xflags, st), "encode_bwd_step")
                 if side is not None and fused_adam is not None and self.defer_small:
                     # sum of the partials + Adam on the small parameters: owed to the next pass 1 (or to whoever looks first)
                     self._pending_small = (int(lib.nadm_sample_splits(b)), fused_adam[0], fused_adam[1], self.step_count)
@@ -447,7 +447,7 @@ class Engine:
                                                ptr(self.small), sa, st), "small_grads")
             else:
                 check(lib.nadm_encode_bwd(C.c_void_p(src.data_ptr() + m0 // 4), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), dzimg, L.CP,
-                                          C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz), st), "encode_bwd")
+                                          C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz), xflags, st), "encode_bwd")
             if on_grad_ready is not None:                     # the first piece carries the small gradients in front of it
                 on_grad_ready(0 if i == 0 else self._ns_pad + m0 * L.CP, self._ns_pad + m1 * L.CP)
         if ev: ev[1].record()

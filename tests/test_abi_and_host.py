@@ -65,7 +65,7 @@ def test_argument_validation_of_the_round1_additions(tmp_path):
     with pytest.raises(RuntimeError, match="CP <= 8"):
         check(lib.nadm_pca_project_t(p, 16, p, 4, 8, p, p, 12, p, None), "pca_project_t")
     with pytest.raises(RuntimeError, match="operand image of dZ"):
-        check(lib.nadm_encode_bwd(p, 16, p, 4, 8, p, None, 8, p, None), "encode_bwd")
+        check(lib.nadm_encode_bwd(p, 16, p, 4, 8, p, None, 8, p, 0, None), "encode_bwd")
     with pytest.raises(RuntimeError, match="0 < CP <= 8"):
         check(lib.nadm_dz_image(p, 4, 12, p, None), "dz_image")
     assert lib.nadm_dz_image_bytes(800) == 7 * 7 * 64 * 16 and lib.nadm_dz_image_bytes(128) == 7 * 64 * 16
