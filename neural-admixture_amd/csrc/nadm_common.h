@@ -128,23 +128,11 @@ constexpr int DZI_TILE_U4 = 7 * 64;
 __host__ __device__ constexpr int dzi_sample(int q, int e) { return 32 * q + 8 * (e >> 3) + 4 * (e & 1) + ((e & 7) >> 1); }
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 typedef unsigned u32x6_t __attribute__((ext_vector_type(6)));
-// one thread: piece p of column c of K-block q of tile T.  GROUP = false: dZ is the [b, CP] matrix in global memory; true: dZ points at
-// the K-block's 32 samples x 8 columns in LDS (rows past the batch and columns past CP zeroed by the caller)
-template <bool GROUP>
-__device__ __forceinline__ void dzi_build_piece(const float* dZ, int b, int CP, uint4* img, int T, int q, int c, int p) {
-    float v[32];
+// piece p (0..7) of 32 values that share one scale block: the 32 FP6 codes (6 dwords, element e at bits [6e, 6e + 6)) and the E8M0 scale
+__device__ __forceinline__ void fp6_piece(const float (&v)[32], int p, u32x6_t& codes, int& scale_byte) {
     float mx = 0.f;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) {
-        if constexpr (GROUP) {
-            v[e] = dZ[(dzi_sample(q, e) - 32 * q) * 8 + c];
-        } else {
-            const int s = T * DZI_TS + dzi_sample(q, e);
-            const float x = dZ[(int64_t)(s < b ? s : b - 1) * CP + (c < CP ? c : 0)];
-            v[e] = (s < b && c < CP) ? x : 0.f;
-        }
-        mx = __builtin_fmaxf(mx, __builtin_fabsf(v[e]));
-    }
+    for (int e = 0; e < 32; ++e) mx = __builtin_fmaxf(mx, __builtin_fabsf(v[e]));
     // mx = m 2^ex, m in [1/2, 1): every |v| < 2^ex = 2^(E0 + 4)
     const int E0 = __builtin_amdgcn_frexp_expf(mx) - 4;
     int sb = 127 + E0 - 4 * p + 3;
@@ -158,15 +146,39 @@ __device__ __forceinline__ void dzi_build_piece(const float* dZ, int b, int CP, 
         const float f = __builtin_copysignf((float)h, v[e]);
         if (e & 1) fb[e >> 1] = f; else fa[e >> 1] = f;      // the conversion interleaves its two sources: field 2i = a[i], 2i + 1 = b[i]
     }
-    const u32x6_t r = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(fa, fb, 8.0f);      // h -> the code of h / 8, exact
+    codes = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(fa, fb, 8.0f);      // h -> the code of h / 8, exact
+    scale_byte = sb;
+}
+// where piece p of (column c, K-block q) goes in a tile image: consumer lane 16 q + 8 parity + c, row group p >> 1
+__device__ __forceinline__ void fp6_piece_store(uint4* tile, int q, int c, int p, const u32x6_t& codes, int scale_byte) {
     const int l = 16 * q + 8 * (p & 1) + c, rg = p >> 1;
-    uint32_t* base = reinterpret_cast<uint32_t*>(img + (int64_t)T * DZI_TILE_U4);
+    uint32_t* base = reinterpret_cast<uint32_t*>(tile);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const int d = 6 * rg + i;
-        base[((d >> 2) * 64 + l) * 4 + (d & 3)] = r[i];
+        base[((d >> 2) * 64 + l) * 4 + (d & 3)] = codes[i];
     }
-    reinterpret_cast<uint8_t*>(base)[((6 * 64 + l) * 4) * 4 + rg] = (uint8_t)sb;
+    reinterpret_cast<uint8_t*>(base)[((6 * 64 + l) * 4) * 4 + rg] = (uint8_t)scale_byte;
+}
+// one thread: piece p of column c of K-block q of tile T.  GROUP = false: dZ is the [b, CP] matrix in global memory; true: dZ points at
+// the K-block's 32 samples x 8 columns in LDS (rows past the batch and columns past CP zeroed by the caller)
+template <bool GROUP>
+__device__ __forceinline__ void dzi_build_piece(const float* dZ, int b, int CP, uint4* img, int T, int q, int c, int p) {
+    float v[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        if constexpr (GROUP) {
+            v[e] = dZ[(dzi_sample(q, e) - 32 * q) * 8 + c];
+        } else {
+            const int s = T * DZI_TS + dzi_sample(q, e);
+            const float x = dZ[(int64_t)(s < b ? s : b - 1) * CP + (c < CP ? c : 0)];
+            v[e] = (s < b && c < CP) ? x : 0.f;
+        }
+    }
+    u32x6_t codes;
+    int sb;
+    fp6_piece(v, p, codes, sb);
+    fp6_piece_store(img + (int64_t)T * DZI_TILE_U4, q, c, p, codes, sb);
 }
 
 // ---- Q as the MFMA operand images of the bf16 pass 2 (K <= 16), one image per head and 64-sample tile --------------------------

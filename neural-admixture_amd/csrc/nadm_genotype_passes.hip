@@ -1222,225 +1222,24 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
     }
 }
 
-// =================================================================================================
-// pass 3, matrix-core version (CP <= 8): dV = X^T . dZ on v_mfma_f32_16x16x32_bf16.
-//   D[rows = dZ columns (hi 0-7 | mid 8-15), cols = 16 SNPs] += A[rows][32 samples] . B[32 samples][16 SNPs]
-//   with dZ split hi+mid+lo into bf16 (second accumulator holds lo|0), X exact in bf16.
-//   The reduction runs over SAMPLES, but a packed byte holds 4 SNPs of ONE sample, so the B operand
-//   (8 consecutive samples of one SNP per lane) needs a bit transpose.  It is done in two steps:
-//     1. the tile loader reads 4 rows x 4 bytes per thread, transposes the 4x4 bytes with v_perm and
-//        stores the tile SNP-byte-major in LDS, so a lane gets 4 consecutive samples of its byte
-//        column with one ds_read_b32;
-//     2. per 2-bit field j the codes of two consecutive samples are put into the two nibbles of a byte and
-//        v_cvt_scalef32_pk_bf16_fp4 turns that byte into a bf16 pair (nibble 00cc = c/2 in FP4): four such
-//        conversions per B operand, no lookup table.
-//   One byte column feeds 4 MFMA column sets (fields j = 0..3).  dZ operands are split once per
-//   32-sample tile by one wave and shared through LDS.  block = 4 waves x 128 SNPs; tiles are
-//   double-buffered, global loads for tile t+1 are issued before tile t is computed.
-// =================================================================================================
+// side work of pass 3's launch: the MLP weight-gradient partials as extra blocks (mlp_bwd_b_block)
 struct MlpSide {               // small_part == nullptr: no side work
     nadm_heads_t hd;
     int b, gx;
     const float *Zn, *H, *dL, *dHpre, *dgp;
     float* small_part;
 };
-constexpr int EB_TS = 32;                 // samples per k-step / tile
-constexpr int EB_G = 2;                   // 64-SNP groups per wave
+constexpr int EB_G = 2;                   // groups of 16 byte columns (64 SNPs) per wave
 constexpr int EB_COLS = 4 * EB_G * 16;    // packed byte columns per block (128)
-constexpr int EB_CS = 36;                 // LDS stride of one byte column (32 rows + pad: conflict-free)
 constexpr int EB_CHUNK_SNPS = EB_COLS * 4;
-#ifndef NADM_EB_D
-#define NADM_EB_D 4
-#endif
-constexpr int EB_D = NADM_EB_D;             // X tiles in flight per thread (global loads issued EB_D - 1 tiles ahead)
-
-template <int CP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void encode_bwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
-                                                              const int32_t* __restrict__ idx, int b, int64_t M,
-                                                              const float* __restrict__ dZ, float* __restrict__ dV,
-                                                              uint32_t missing_bf16, float* __restrict__ Vrw, AdamFused ad, MlpSide side) {
-    static_assert(CP <= 8, "hi|mid and lo|0 share the 16 MFMA rows");
-    {   // blocks past the SNP chunks: the MLP weight-gradient partials (independent of pass 3; see mlp_bwd_b_block)
-        const int64_t nchunks = (M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS;
-        if ((int64_t)blockIdx.x >= nchunks) {
-            const int e = (int)(blockIdx.x - nchunks);
-            mlp_bwd_b_block(side.hd, side.b, side.Zn, side.H, side.dL, side.dHpre, side.dgp, side.small_part, e % side.gx, e / side.gx);
-            return;
-        }
-    }
-    __shared__ __attribute__((aligned(16))) uint8_t s_xt[2][EB_COLS * EB_CS];
-    __shared__ __attribute__((aligned(16))) uint4 s_a[2][2][64];
-    __shared__ __attribute__((aligned(16))) float4 s_dvbuf[EB_CHUNK_SNPS * CP / 4];       // the block's dV rows (epilogue)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int mcol = lane & 15, q = lane >> 4;
-    const int64_t chunk = blockIdx.x;
-    const int64_t byte0 = chunk * EB_COLS;
-    // x = code/2; a missing call (code 3) is 0 in the model and 1.5 in the init-time products.  The codes become bf16
-    // through v_cvt_scalef32_pk_bf16_fp4 (nibble 00cc = c/2 in FP4, so 1.5 is the native value of code 3); for the model
-    // the loader clears both bits of every code 3 before the tile goes to LDS.
-    const uint32_t kmiss = missing_bf16 == 0u ? 0x55555555u : 0u;
-    // ---- loader mapping: thread -> 4 rows x 4 byte columns ----
-    const int cg = tid & 31, rg = tid >> 5;                   // byte columns 4cg..4cg+3, rows 4rg..4rg+3 of the tile
-    const int64_t loff = byte0 + 4 * cg;
-    const bool lcol_ok = loff * 4 < M;             // not `< ld`: sub-range launches, see pass 2
-    const int64_t loff_c = lcol_ok ? loff : 0;
-    auto row_idx = [&](int i0, int k) -> int32_t { const int smp = i0 + 4 * rg + k; return idx[smp < b ? smp : b - 1]; };
-    // Loads run EB_D - 1 tiles ahead of the compute: one 32-sample tile is only ~0.3 us of work per wave, far less than
-    // the latency of the dependent idx -> row loads, so a single tile of prefetch leaves every wave waiting on memory.
-    // Row indices are fetched a further EB_D - 1 tiles ahead of the X loads that use them: vector-memory loads retire in
-    // order, so waiting for an index loaded right before would also wait for every X tile in flight.
-    int32_t rows[EB_D][4];
-    uint32_t xw[EB_D][4];
-    float zst[EB_D];                                          // one dZ element of a coming tile per thread: sample tid>>3, column tid&7
-    const int zr = tid >> 3, zc = tid & 7;
-    auto fetch_rows = [&](int i0, int32_t (&rw)[4]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) rw[k] = row_idx(i0, k);
-    };
-    auto issue = [&](int i0, const int32_t (&rw)[4], uint32_t (&xs)[4], float& zs) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) xs[k] = *reinterpret_cast<const uint32_t*>(xp + (int64_t)rw[k] * ld + loff_c);
-        const int smp = i0 + zr;
-        zs = dZ[(int64_t)(smp < b ? smp : b - 1) * CP + (zc < CP ? zc : 0)];      // unconditional (no divergent branch around loads)
-    };
-    auto commit = [&](int buf, int i0, const uint32_t (&xs)[4], const float zs) {
-        uint32_t d[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t r = (lcol_ok && i0 + 4 * rg + k < b) ? xs[k] : 0u;
-            const uint32_t m3 = r & (r >> 1) & kmiss;
-            d[k] = r ^ (m3 | (m3 << 1));
-        }
-        // 4x4 byte transpose: e[c] = byte c of rows 0..3
-        const uint32_t t01l = __builtin_amdgcn_perm(d[1], d[0], 0x05010400u);   // d0.b0 d1.b0 d0.b1 d1.b1
-        const uint32_t t01h = __builtin_amdgcn_perm(d[1], d[0], 0x07030602u);   // d0.b2 d1.b2 d0.b3 d1.b3
-        const uint32_t t23l = __builtin_amdgcn_perm(d[3], d[2], 0x05010400u);
-        const uint32_t t23h = __builtin_amdgcn_perm(d[3], d[2], 0x07030602u);
-        const uint32_t e0 = __builtin_amdgcn_perm(t23l, t01l, 0x05040100u);     // t01l.b0 t01l.b1 t23l.b0 t23l.b1
-        const uint32_t e1 = __builtin_amdgcn_perm(t23l, t01l, 0x07060302u);
-        const uint32_t e2 = __builtin_amdgcn_perm(t23h, t01h, 0x05040100u);
-        const uint32_t e3 = __builtin_amdgcn_perm(t23h, t01h, 0x07060302u);
-        uint8_t* base = &s_xt[buf][(4 * cg) * EB_CS + 4 * rg];
-        *reinterpret_cast<uint32_t*>(base) = e0;
-        *reinterpret_cast<uint32_t*>(base + EB_CS) = e1;
-        *reinterpret_cast<uint32_t*>(base + 2 * EB_CS) = e2;
-        *reinterpret_cast<uint32_t*>(base + 3 * EB_CS) = e3;
-        // dZ element (sample zr, column zc) -> bf16 hi/mid/lo scattered into the A operand images:
-        // lane (mcol = zc [+8 for mid], q = zr>>3), element zr&7 of its 8 k-values
-        const float v = (i0 + zr < b && zc < CP) ? zs : 0.f;
-        const uint32_t hi = bf16_trunc_bits(v);
-        const float r1 = v - __uint_as_float(hi);
-        const uint32_t mid = bf16_trunc_bits(r1);
-        const float r2 = r1 - __uint_as_float(mid);
-        const uint32_t lo = bf16_trunc_bits(r2);
-        uint16_t* a1 = reinterpret_cast<uint16_t*>(&s_a[buf][0][0]) + (zr & 7);
-        uint16_t* a2 = reinterpret_cast<uint16_t*>(&s_a[buf][1][0]) + (zr & 7);
-        const int ln = 16 * (zr >> 3) + zc;
-        a1[ln * 8] = (uint16_t)(hi >> 16);
-        a1[(ln + 8) * 8] = (uint16_t)(mid >> 16);
-        a2[ln * 8] = (uint16_t)(lo >> 16);
-    };
-
-    f32x4 acc1[EB_G][4], acc2[EB_G][4];
-#pragma unroll
-    for (int g = 0; g < EB_G; ++g)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { acc1[g][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc2[g][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-
-    // prologue: tiles 0 .. EB_D-2 in flight (indices are clamped, so issuing past the batch is harmless), tile 0 committed
-    for (int e = tid; e < 2 * 2 * 64; e += 256) (&s_a[0][0][0])[e] = make_uint4(0, 0, 0, 0);     // rows 8..15 of the lo image stay zero
-    __syncthreads();
-#pragma unroll
-    for (int d = 0; d < EB_D - 1; ++d) fetch_rows(d * EB_TS, rows[d]);
-#pragma unroll
-    for (int d = 0; d < EB_D - 1; ++d) {
-        issue(d * EB_TS, rows[d], xw[d], zst[d]);
-        fetch_rows((d + EB_D - 1) * EB_TS, rows[(d + EB_D - 1) % EB_D]);        // tiles EB_D-1 .. 2*EB_D-3
-    }
-    commit(0, 0, xw[0], zst[0]);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-
-    const int ntiles = (b + EB_TS - 1) / EB_TS;
-    for (int tl0 = 0; tl0 < ntiles; tl0 += EB_D) {
-#pragma unroll
-        for (int u = 0; u < EB_D; ++u) {
-            const int tl = tl0 + u;
-            if (tl < ntiles) {                                    // block-uniform
-                const int cur = tl & 1;
-                const int i0 = tl * EB_TS;
-                // tile tl+EB_D-1: its indices were fetched EB_D-1 iterations ago; fetch those of tile tl+2*EB_D-2 now
-                issue(i0 + (EB_D - 1) * EB_TS, rows[(u + EB_D - 1) % EB_D], xw[(u + EB_D - 1) % EB_D], zst[(u + EB_D - 1) % EB_D]);
-                fetch_rows(i0 + (2 * EB_D - 2) * EB_TS, rows[(u + 2 * EB_D - 2) % EB_D]);
-                const bf16x8 a1 = __builtin_bit_cast(bf16x8, s_a[cur][0][lane]);
-                const bf16x8 a2 = __builtin_bit_cast(bf16x8, s_a[cur][1][lane]);
-#pragma unroll
-                for (int g = 0; g < EB_G; ++g) {
-                    const uint8_t* colp = &s_xt[cur][(wave * (16 * EB_G) + g * 16 + mcol) * EB_CS + 8 * q];
-                    const uint32_t w0 = *reinterpret_cast<const uint32_t*>(colp);        // samples 8q..8q+3 of this byte column
-                    const uint32_t w1 = *reinterpret_cast<const uint32_t*>(colp + 4);    // samples 8q+4..8q+7
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        // field j of samples (s, s+1) into the two nibbles of bytes 0 and 2, then one conversion per pair
-                        const uint32_t p0 = ((w0 >> (2 * j)) & 0x00030003u) | ((w0 >> (2 * j + 4)) & 0x00300030u);
-                        const uint32_t p1 = ((w1 >> (2 * j)) & 0x00030003u) | ((w1 >> (2 * j + 4)) & 0x00300030u);
-                        const bf16x8 bv = __builtin_bit_cast(bf16x8, make_uint4(fp4_bf16_pair(p0, 0), fp4_bf16_pair(p0, 2),
-                                                                                fp4_bf16_pair(p1, 0), fp4_bf16_pair(p1, 2)));
-                        acc1[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bv, acc1[g][j], 0, 0, 0);
-                        acc2[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bv, acc2[g][j], 0, 0, 0);
-                    }
-                }
-                if (tl + 1 < ntiles) commit(cur ^ 1, i0 + EB_TS, xw[(u + 1) % EB_D], zst[(u + 1) % EB_D]);
-                __syncthreads();
-            }
-        }
-    }
-
-    // ---- fold hi + mid + lo (rows c and c+8 sit 32 lanes apart) into an LDS image of the block's dV rows [512 SNPs][CP],
-    // then every thread handles whole float4s of that contiguous region: full 16 B/lane lines for the gradient store, or
-    // -- single-GPU step -- for Adam on these V rows (3 reads + 3 writes per element: it has to be coalesced) ----
-    __syncthreads();                                           // all waves are done with s_xt / s_a of the last tile
-    float* s_dv = reinterpret_cast<float*>(&s_dvbuf[0]);
-#pragma unroll
-    for (int g = 0; g < EB_G; ++g) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float o[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float u = acc1[g][j][r] + acc2[g][j][r];
-                o[r] = u + __shfl_xor(u, 32, 64);
-            }
-            const int ml = (wave * (16 * EB_G) + g * 16 + mcol) * 4 + j;          // SNP within the block's 512
-            if (q < 2 && 4 * q < CP) *reinterpret_cast<float4*>(s_dv + ml * CP + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-    }
-    __syncthreads();
-    {
-        constexpr int ROW4 = CP / 4;
-        const int64_t m0 = chunk * EB_CHUNK_SNPS;
-        // (a loop of load-update-store trips at the end of a single-round kernel: +11 us against the launch that only writes dV.
-        // r03 measured the loop with the loads of 1 / 2 / 4 trips issued together (no spills in that form): 63.7 / 63.1 / 65.4 us --
-        // it is not the round trips that cost, profiles/r03_ablations.txt.  Left as a plain loop.)
-        for (int e = tid; e < EB_CHUNK_SNPS * ROW4; e += 256) {
-            const int64_t m = m0 + e / ROW4;
-            if (m < M) {
-                const float4 g4 = *reinterpret_cast<const float4*>(s_dv + 4 * e);
-                const int64_t o = m * CP + 4 * (e % ROW4);
-                if (ad.m != nullptr) adam_float4(Vrw + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.inv_bc2, ad.grad_scale, false);
-                else *reinterpret_cast<float4*>(dV + o) = g4;
-            }
-        }
-    }
-}
 
 // =================================================================================================
 // pass 3 on the FP4 x FP6 matrix instruction (CP <= 8, r03): dV = X^T . dZ on v_mfma_scale_f32_16x16x128_f8f6f4.
 //   A nibble 00cc IS the FP4 (E2M1) number c/2, so the genotypes enter the matrix pipe WITHOUT a conversion: the B operand of
 //   one instruction is 32 samples x 1 SNP per lane (4 registers of nibbles), K = 128 samples per instruction.  What is left on
 //   the VALU is the bit transposition (the packed byte holds 4 SNPs of one sample, the operand wants 8 samples of one SNP per
-//   register): 40 instructions per 16 byte columns x 128 samples, where the bf16 kernel above spends 4 x 40 on shifts, masks
-//   and 64 v_cvt_scalef32_pk_bf16_fp4.  And K = 128 costs 22-25 issue cycles where four K = 32 bf16 instructions cost 71
+//   register): 40 instructions per 16 byte columns x 128 samples, where the bf16 kernel of rounds 1-2 (v_mfma_f32_16x16x32_bf16, dZ
+//   split hi + mid + lo, X converted with v_cvt_scalef32_pk_bf16_fp4) spent 4 x 40 on shifts and masks and 64 conversions.  And K = 128 costs 22-25 issue cycles where four K = 32 bf16 instructions cost 71
 //   (profiles/r03_ubench_fp4_mfma.txt).
 //   dZ is the A operand, as FP6 (E2M3) pieces: the block of 32 samples x one column a lane holds is cut into EIGHT pieces of
 //   four bits -- the hexadecimal digits of |dZ| in fixed point below 16 x the block's largest magnitude, each with the sign
@@ -1980,18 +1779,12 @@ static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
             extra = (int64_t)side.gx * nadm_sample_splits(b);
         }
         dim3 g2((unsigned)((M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS + extra));
-#ifdef NADM_P3_BF16
-        if (CP == 4) hipLaunchKernelGGL((encode_bwd_mfma_kernel<4>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV, missing_bf16, Vrw, ad, side);
-        else hipLaunchKernelGGL((encode_bwd_mfma_kernel<8>), g2, block, 0, st, xp, ld, idx, b, M, dZ, dV, missing_bf16, Vrw, ad, side);
-        return check_launch("encode_bwd_mfma");
-#else
 #define NADM_P3_LAUNCH(CPV, CL) hipLaunchKernelGGL((encode_bwd_fp4_kernel<CPV, CL>), g2, block, 0, st, xp, ld, idx, b, M, (const uint4*)dzimg, dV, missing_bf16, Vrw, ad, side)
         const bool clean = (flags & NADM_X_CLEAN) != 0 && missing_bf16 == 0u;
         if (CP == 4) { if (clean) NADM_P3_LAUNCH(4, true); else NADM_P3_LAUNCH(4, false); }
         else { if (clean) NADM_P3_LAUNCH(8, true); else NADM_P3_LAUNCH(8, false); }
 #undef NADM_P3_LAUNCH
         return check_launch("encode_bwd_fp4");
-#endif
     }
     switch (CP) {
         case 12: hipLaunchKernelGGL((encode_bwd_kernel<12>), grid, block, 0, st, xp, ld, idx, b, M, dZ, dV); break;
