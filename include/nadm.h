@@ -145,12 +145,13 @@ int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b
                     const float* P, int32_t kp, const float* Q, int32_t SP,
                     float* dP, float* dqpart, float* losspart, int32_t with_loss, void* stream);
 
-/* The same pass with a by-product for pass 3: the batch's gathered rows written back to back into xg [b, ld] (row i of
- * the batch -> row i of xg, same byte columns, same row stride; an SNP sub-range launch passes xg + m0/4 like xp), with every
- * missing call (code 3) already replaced by 0 -- the model's input (neural_admixture.py:170).  Pass 3 (nadm_encode_bwd) can then
- * be given xg with idx = 0,1,..,b-1 and flags = NADM_X_CLEAN: it reads one compact 100 MB region instead of rows
- * scattered over the resident matrix (at 12.5 GB resident the scattered reads cost it 13 % translation-cache misses and
- * 16 us of 68).  No reference counterpart: the reference re-gathers the unpacked batch per pass (utils.pyx:43-67). */
+/* The same pass with a by-product for pass 3: the batch as a copy of its own in xg -- rows in batch order, every missing call
+ * (code 3) already replaced by 0 (the model's input, neural_admixture.py:170), TILED by pass 3's chunks: byte column c of batch
+ * row i at  (c / 128) * b * 128 + i * 128 + c % 128  (nadm_batch_copy_bytes(b, M) bytes; an SNP sub-range launch starting at
+ * SNP m0 passes xg + (m0 / 4) * b).  Pass 3 (nadm_encode_bwd) is then given xg instead of xp with flags = NADM_X_CLEAN (idx is
+ * not read): each of its blocks streams one contiguous b x 128 byte region instead of gathering 128-byte row pieces 125 KB
+ * apart out of the resident matrix (those arrive at 2.6 TB/s, and at 12.5 GB resident 13 % of them miss the translation
+ * cache).  No reference counterpart: the reference re-gathers the unpacked batch per pass (utils.pyx:43-67). */
 int nadm_decode_bce_gather(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                            const float* P, int32_t kp, const float* Q, int32_t SP,
                            float* dP, float* dqpart, float* losspart, int32_t with_loss, uint8_t* xg, void* stream);
@@ -269,7 +270,8 @@ int nadm_mlp_bwd_image(const nadm_heads_t* hd, const float* small, float* dqpart
                        const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
                        float* dL, float* dHpre, float* dgp, float* small_part, float* dZ, float* grad_small,
                        const float* losspart, int64_t n_loss, double* loss_acc, void* dzimg, int32_t* dz_counters, void* stream);
-#define NADM_X_CLEAN 1     /* flags: the rows handed over are nadm_decode_bce_gather's copy of the batch (missing calls already 0) */
+#define NADM_X_CLEAN 1     /* flags: xp is nadm_decode_bce_gather's copy of the batch (tiled, rows in batch order, missing calls already 0) */
+int64_t nadm_batch_copy_bytes(int32_t b, int64_t M);
 int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                     const float* dZ, const void* dzimg, int32_t CP, float* dV, int32_t flags, void* stream);
 

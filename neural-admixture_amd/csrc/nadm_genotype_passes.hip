@@ -756,6 +756,12 @@ __device__ __forceinline__ void bce_loss_prod2(const f32x2_t d, const f32x2_t de
 
 // missing calls (code 3) -> 0 in all 16 codes of a word: the model's input (neural_admixture.py:170)
 __device__ __forceinline__ uint32_t clean_codes(uint32_t w) { return w & ~((w & (w >> 1) & 0x55555555u) * 3u); }
+// the batch copy pass 2 leaves for pass 3 (nadm_decode_bce_gather): byte `col` of batch row `row` lives in tile col / 128 of
+// [b rows][128 bytes]
+constexpr int XG_TILE_COLS = 128;
+__device__ __forceinline__ uint8_t* xg_piece(uint8_t* xg, int b, int row, int64_t col) {
+    return xg + (col / XG_TILE_COLS) * ((int64_t)b * XG_TILE_COLS) + (int64_t)row * XG_TILE_COLS + (col % XG_TILE_COLS);
+}
 
 // Two genotypes -> two floats in ONE instruction: a nibble 00cc read as FP4 (E2M1) is exactly cc/2 (0, .5, 1), so
 // v_cvt_scalef32_pk_f32_fp4 on byte `sel` of a word whose nibbles hold one 2-bit code each yields x for both.
@@ -953,11 +959,12 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
         // and the copy for pass 3 both hold the model's input
         const uint4 cl = make_uint4(clean_codes(stage.x & okm), clean_codes(stage.y & okm), clean_codes(stage.z & okm), clean_codes(stage.w & okm));
         if (has_piece) *reinterpret_cast<uint4*>(&s_x[pr * RS + pc16 * 16]) = cl;
-        // by-product for pass 3: the gathered rows written back to back (row i of the batch -> row i of xg), missing calls already 0.
-        // Pass 3 then reads 100 MB in one place instead of 800 rows scattered over the resident matrix, which at 12.5 GB costs it
-        // 13 % misses in the per-CU translation cache (UTCL1) and 16 us, and skips its own cleaning; here the store is one
-        // instruction per tile and thread.
-        if (xg != nullptr && has_piece && ok) *reinterpret_cast<uint4*>(xg + (int64_t)(i0 + pr) * ld + poff) = cl;
+        // by-product for pass 3: the batch as a copy of its own, missing calls already 0, TILED the way pass 3 walks it -- tile t = the
+        // 128 byte columns of pass 3's chunk t, [b rows][128 bytes] back to back (xg_piece).  A block of pass 3 then streams ONE
+        // contiguous b x 128 byte region instead of gathering 128-byte pieces 125 KB apart, which arrive at 2.6 TB/s (and, out of a
+        // 12.5 GB resident matrix, miss the per-CU translation cache on 13 % of the requests); here the store is one instruction
+        // per tile and thread.
+        if (xg != nullptr && has_piece && ok) *reinterpret_cast<uint4*>(xg_piece(xg, b, i0 + pr, poff)) = cl;
         if constexpr (QIMG) {
             s_qimg[tid] = qi0;
             s_qimg[tid + NTHR] = qi1;
@@ -1263,7 +1270,7 @@ __global__ __launch_bounds__(256) void dz_image_kernel(const float* __restrict__
 
 constexpr int EB4_XS = 132;               // bytes per byte column of the LDS tile: 128 samples + 4 (dword stride 33: the loader's 4-byte
                                           // stores of 32 consecutive column quads and the 4-byte column reads spread over the banks)
-// CLEAN_SRC: the rows are pass 2's copy of the batch (xg), missing calls already 0
+// CLEAN_SRC: xp is pass 2's copy of the batch (xg_piece: tiled by this kernel's chunks, rows in batch order, missing calls already 0)
 template <int CP, bool CLEAN_SRC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void encode_bwd_fp4_kernel(const uint8_t* __restrict__ xp, int64_t ld,
                                                               const int32_t* __restrict__ idx, int b, int64_t M,
@@ -1300,10 +1307,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     uint32_t lmask[4];                                        // 16 bytes = 64 SNPs, M need not be a multiple: per dword
 #pragma unroll
     for (int t = 0; t < 4; ++t) lmask[t] = lt_mask64((loff + 4 * t) * 4, M);
-    auto row_idx = [&](int i0, int k) -> int32_t { const int smp = i0 + 4 * rq + k; return idx[smp < b ? smp : b - 1]; };
+    auto row_idx = [&](int i0, int k) -> int32_t {
+        const int smp = i0 + 4 * rq + k, smc = smp < b ? smp : b - 1;
+        if constexpr (CLEAN_SRC) return smc;                  // the copy holds the batch in order
+        else return idx[smc];
+    };
     int32_t rows[4];
     uint4 xw[4];
     const uint32_t ld32 = (uint32_t)ld;                       // (a row is < 4 GB)
+    static_assert(XG_TILE_COLS == EB_COLS, "the batch copy is tiled by this kernel's chunks");
+    const uint8_t* const xtile = xp + chunk * ((int64_t)b * XG_TILE_COLS) + 16 * cgrp;
     const bool col_edge = (byte0 + EB_COLS) * 4 > M;          // block-uniform: only the last chunk has byte columns past M
     auto fetch_rows = [&](int i0) {
 #pragma unroll
@@ -1311,7 +1324,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     };
     auto issue = [&]() {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) xw[k] = *reinterpret_cast<const uint4*>(xp + ((uint64_t)(uint32_t)rows[k] * ld32 + (uint64_t)loff_c));   // one v_mad_u64_u32
+        for (int k = 0; k < 4; ++k) {
+            if constexpr (CLEAN_SRC) xw[k] = *reinterpret_cast<const uint4*>(xtile + rows[k] * XG_TILE_COLS);       // one contiguous b x 128 B region per block
+            else xw[k] = *reinterpret_cast<const uint4*>(xp + ((uint64_t)(uint32_t)rows[k] * ld32 + (uint64_t)loff_c));   // one v_mad_u64_u32
+        }
     };
     auto col_slot = [](int c) -> int { return ((c >> 4) << 3) | (c & 7) | ((c & 8) << 3); };
     // dword t of the four rows -> byte columns 16 cgrp + 4t .. + 3, samples 4 rq .. 4 rq + 3 of tile buffer `buf`.  EDGE: the tile
@@ -1475,7 +1491,7 @@ static int launch_adam_range(float* p, const float* g, AdamFused ad, int64_t n, 
     return check_launch("adam_range");
 }
 
-// rows idx[0..b) of xp, the byte columns that hold SNPs [0, M) -> rows 0..b-1 of xg (same row stride), missing calls set to 0: what
+// rows idx[0..b) of xp, the byte columns that hold SNPs [0, M) -> rows 0..b-1 of the tiled copy xg (xg_piece), missing calls set to 0: what
 // the bf16 pass-2 kernel writes as a by-product, as a kernel of its own for the K > 16 / A-B-reference variants of pass 2
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx,
                                                           int b, int64_t pieces, uint8_t* __restrict__ xg) {
@@ -1483,7 +1499,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restr
     for (int64_t p = blockIdx.x * 256 + threadIdx.x; p < pieces; p += (int64_t)gridDim.x * 256)
     {
         const uint4 w = *reinterpret_cast<const uint4*>(xp + row * ld + p * 16);
-        *reinterpret_cast<uint4*>(xg + (int64_t)blockIdx.y * ld + p * 16) = make_uint4(clean_codes(w.x), clean_codes(w.y), clean_codes(w.z), clean_codes(w.w));
+        *reinterpret_cast<uint4*>(xg_piece(xg, b, (int)blockIdx.y, p * 16)) = make_uint4(clean_codes(w.x), clean_codes(w.y), clean_codes(w.z), clean_codes(w.w));
     }
 }
 
@@ -1748,6 +1764,7 @@ extern "C" int nadm_decode_bce_images(const uint8_t* xp, int64_t ld, const int32
     return decode_bce_impl(xp, ld, idx, b, M, P, kp, Q, SP, dP, dqpart, losspart, with_loss, stream, xg, ad, static_cast<const uint4*>(qimg));
 }
 
+extern "C" int64_t nadm_batch_copy_bytes(int32_t b, int64_t M) { return ((M + 4 * nadm::XG_TILE_COLS - 1) / (4 * nadm::XG_TILE_COLS)) * (int64_t)b * nadm::XG_TILE_COLS; }
 extern "C" int64_t nadm_dz_image_bytes(int32_t b) { return (int64_t)((b + nadm::DZI_TS - 1) / nadm::DZI_TS) * nadm::DZI_TILE_U4 * 16; }
 
 extern "C" int nadm_dz_image(const float* dZ, int32_t b, int32_t CP, void* dzimg, void* stream) {

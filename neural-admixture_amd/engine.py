@@ -82,11 +82,12 @@ class Engine:
         self.xp: Optional[torch.Tensor] = None          # packed genotypes [rows, ld]
         self.step_count = 0
         self.p_unit = True                              # every P entry in [0, 1] (see load_params)
-        # pass 2 can write the batch's gathered rows back to back into xg for pass 3 to read from there (include/nadm.h,
-        # nadm_decode_bce_gather): same bytes, same results, no scattered reads over the resident matrix in pass 3 -- worth it
-        # only when the resident matrix is large: at 12.5 GB pass 3 missed the per-CU translation cache on 13 % of its
-        # scattered requests (68 us instead of 52, profiles/r01_pmc_tlb.txt), at 2.5 GB it did not -- below GATHER_MIN_BYTES the
-        # copy (b * ld bytes written per step) is skipped and pass 3 gathers the rows itself.  None = decide by the resident size.
+        # pass 2 writes the batch as a copy of its own into xg for pass 3 (include/nadm.h, nadm_decode_bce_gather): missing calls
+        # already 0 and tiled by pass 3's chunks, so that a block of pass 3 streams one contiguous region instead of gathering
+        # 128-byte row pieces out of the resident matrix -- those arrive at 2.6 TB/s whatever the size of the matrix (pass 3: 50 us
+        # against 40 at M = 500k; and at 12.5 GB resident 13 % of them miss the translation cache, profiles/r01_pmc_tlb.txt).  The
+        # copy costs pass 2 b * ld bytes of writes it has the bandwidth for.  None = on a GPU: always (r02 / early r03: only above
+        # 4 GB resident, when the copy was only known to cure the translation misses); False: pass 3 gathers the rows itself.
         self.gather_batch: Optional[bool] = None
         self._xg: Optional[torch.Tensor] = None
         self._iota: Optional[torch.Tensor] = None
@@ -100,16 +101,16 @@ class Engine:
         self._pending_ddp = None                              # (works, lr, grad_scale, step) of a deferred P update
         self._pending_vs = None                               # (lr, grad_scale, step) of a deferred update of V and the small parameters
 
-    GATHER_MIN_BYTES = 4 << 30
+    GATHER_MIN_BYTES = 0
 
     def _gather(self) -> bool:
         if self.gather_batch is not None:
             return bool(self.gather_batch)
-        return self.device.type == "cuda" and self.xp is not None and self.xp.numel() > self.GATHER_MIN_BYTES
+        return self.device.type == "cuda" and self.xp is not None and self.xp.numel() >= self.GATHER_MIN_BYTES
 
     def _xg_buf(self) -> torch.Tensor:
         if self._xg is None:
-            self._xg = torch.empty((self.bmax, self.ld), dtype=torch.uint8, device=self.device)
+            self._xg = torch.empty(int(lib.nadm_batch_copy_bytes(self.bmax, self.M)), dtype=torch.uint8, device=self.device)   # tiled by pass 3's chunks
             self._iota = torch.arange(self.bmax, dtype=torch.int32, device=self.device)
         return self._xg
 
@@ -351,7 +352,7 @@ class Engine:
                         C.c_void_p(self.gbig.data_ptr() + (L.p_off[h] + m0 * kp) * fsz),
                         C.c_void_p(self.dqpart.data_ptr() + (dq_offs[h] + c0 * b * kp) * fsz),
                         C.c_void_p(self.losspart.data_ptr() + (loss_offs[h] + c0) * fsz), (1 if self.p_unit else 3) if with_loss else 0)
-                xg = C.c_void_p(self._xg_buf().data_ptr() + m0 // 4) if (h == 0 and self._gather()) else None
+                xg = C.c_void_p(self._xg_buf().data_ptr() + (m0 // 4) * b) if (h == 0 and self._gather()) else None   # (tiles of [b][128 B])
                 if self.q_images and self._qimg_b == b and kp <= 16:      # Q operands ready-made by this step's MLP forward
                     check(lib.nadm_decode_bce_images(*args, xg, C.byref(self._adam_args(L.p_off[h] + m0 * kp, fused_adam)) if fused_adam is not None else None,
                                                      C.c_void_p(self.qimg.data_ptr() + h * self._qimg_head), st), "decode_bce_images")
@@ -423,15 +424,15 @@ class Engine:
         ev = self._timed("encode_bwd")
         # rows: the compact copy pass 2 of this step left in xg (rows 0..b-1 = the batch in order), else the resident matrix
         if self._xg_key == (idx.data_ptr(), b) and self._xg is not None:
-            src, rows, xflags = self._xg, self._iota, 1       # NADM_X_CLEAN: pass 2's copy holds the model's input (missing = 0)
+            src, rows, xflags, rstride = self._xg, self._iota, 1, b   # NADM_X_CLEAN: pass 2's tiled copy of the batch (missing = 0)
         else:
-            src, rows, xflags = self.xp, idx, 0
+            src, rows, xflags, rstride = self.xp, idx, 0, 1
         self._xg_key = None
         dzimg = self._dz_image(b)
         for i, (m0, m1) in enumerate(self._snp_ranges(v_parts, 1024)):
             side = mw if i == 0 else None
             if fused_adam is not None or side is not None:    # Adam on these V rows in the epilogue and / or the side blocks
-                check(lib.nadm_encode_bwd_step(C.c_void_p(src.data_ptr() + m0 // 4), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), dzimg, L.CP,
+                check(lib.nadm_encode_bwd_step(C.c_void_p(src.data_ptr() + (m0 // 4) * rstride), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), dzimg, L.CP,
                                                C.c_void_p(self._big.data_ptr() + m0 * L.CP * fsz),
                                                C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz),
                                                C.byref(self._adam_args(m0 * L.CP, fused_adam)) if fused_adam is not None else None,
@@ -446,7 +447,7 @@ class Engine:
                     check(lib.nadm_small_grads(ptr(self.small_part), int(lib.nadm_sample_splits(b)), L.n_small, ptr(self.gsmall),
                                                ptr(self.small), sa, st), "small_grads")
             else:
-                check(lib.nadm_encode_bwd(C.c_void_p(src.data_ptr() + m0 // 4), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), dzimg, L.CP,
+                check(lib.nadm_encode_bwd(C.c_void_p(src.data_ptr() + (m0 // 4) * rstride), self.ld, ptr(rows), b, m1 - m0, ptr(self.dZ), dzimg, L.CP,
                                           C.c_void_p(self.gbig.data_ptr() + m0 * L.CP * fsz), xflags, st), "encode_bwd")
             if on_grad_ready is not None:                     # the first piece carries the small gradients in front of it
                 on_grad_ready(0 if i == 0 else self._ns_pad + m0 * L.CP, self._ns_pad + m1 * L.CP)

@@ -1164,7 +1164,7 @@ def test_pass2_gather_byproduct_and_pass3_on_the_compact_copy(K):
         dP = torch.zeros(M * kp, dtype=torch.float32, device=dev)
         dq = torch.zeros(nch * b * kp, dtype=torch.float32, device=dev)
         ls = torch.zeros(nch, dtype=torch.float32, device=dev)
-        xg = torch.full((b, e.ld), 0xEE, dtype=torch.uint8, device=dev)
+        xg = torch.full((int(lib.nadm_batch_copy_bytes(b, M)),), 0xEE, dtype=torch.uint8, device=dev)
         args = (ptr(e.xp), e.ld, ptr(idx), b, M, C.c_void_p(e.big.data_ptr() + L.p_off[0] * 4), kp, ptr(e.Q), L.SP, ptr(dP), ptr(dq), ptr(ls), 1)
         if gather:
             check(lib.nadm_decode_bce_gather(*args, ptr(xg), None))
@@ -1178,7 +1178,9 @@ def test_pass2_gather_byproduct_and_pass3_on_the_compact_copy(K):
     want = e.xp[idx.long()]                                     # the copy holds the model's input: missing calls (code 3) are 0
     miss = want & (want >> 1) & 0x55
     want = want & ~(miss * 3)
-    assert torch.equal(outs[1][3][:, :nbytes], want[:, :nbytes])
+    # ... tiled by pass 3's chunks: byte column c of batch row i at (c // 128) * b * 128 + i * 128 + c % 128 (include/nadm.h)
+    got = outs[1][3].view(-1, b, 128).permute(1, 0, 2).reshape(b, -1)
+    assert torch.equal(got[:, :nbytes], want[:, :nbytes])
     assert bool((outs[0][3] == 0xEE).all())                      # the plain entry point leaves xg alone
     # pass 3: resident matrix + idx vs compact copy + iota
     dZ = torch.from_numpy(rng.standard_normal((b, L.CP)).astype(np.float32)).to(dev)
@@ -1186,15 +1188,15 @@ def test_pass2_gather_byproduct_and_pass3_on_the_compact_copy(K):
     dv = []
     dzimg = torch.empty(int(lib.nadm_dz_image_bytes(b)), dtype=torch.uint8, device=dev)
     check(lib.nadm_dz_image(ptr(dZ), b, L.CP, ptr(dzimg), None))
-    for src, rows, fl in ((e.xp, idx, 0), (outs[1][3], iota, 1), (outs[1][3], iota, 0)):
+    for src, rows, fl in ((e.xp, idx, 0), (outs[1][3], iota, 1)):
         o = torch.zeros(M * L.CP, dtype=torch.float32, device=dev)
         check(lib.nadm_encode_bwd(ptr(src), e.ld, ptr(rows), b, M, ptr(dZ), ptr(dzimg), L.CP, ptr(o), fl, None))
         dv.append(o)
     torch.cuda.synchronize()
-    assert torch.equal(dv[0], dv[1]) and torch.equal(dv[0], dv[2])
+    assert torch.equal(dv[0], dv[1])
     # whole steps: engine with the by-product on (default on a GPU) vs off, two steps, bit-identical state
     e1, e2 = make_engine(Gm, p, b), make_engine(Gm, p, b)
-    assert e1.gather_batch is None and not e1._gather()          # a small resident matrix: no copy by default (GATHER_MIN_BYTES)
+    assert e1.gather_batch is None and e1._gather()              # on a GPU the copy is on by default
     e1.gather_batch, e2.gather_batch = True, False
     for _ in range(2):
         e1.train_step(idx, b, 2e-3, True)
