@@ -1780,6 +1780,7 @@ static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
                            float* Vrw = nullptr, AdamFused ad = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0},
                            const nadm_mlp_weights_t* mw = nullptr) {
     if (!xp || !idx || !dZ || !dV) return fail("nadm_encode_bwd: null pointer");
+    if (CP > 8 && (flags & NADM_X_CLEAN)) return fail("nadm_encode_bwd: the batch copy (NADM_X_CLEAN) is tiled for the matrix-core pass, C <= 8");
     if (CP <= 8 && (!dzimg || ((uintptr_t)dzimg & 15)))
         return fail("nadm_encode_bwd: C <= 8 runs on the FP4 x FP6 matrix instruction and needs the operand image of dZ (nadm_dz_image), 16-byte aligned");
     if (b <= 0 || M <= 0) return fail("nadm_encode_bwd: empty batch or M");

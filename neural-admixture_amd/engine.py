@@ -105,8 +105,9 @@ class Engine:
 
     def _gather(self) -> bool:
         if self.gather_batch is not None:
-            return bool(self.gather_batch)
-        return self.device.type == "cuda" and self.xp is not None and self.xp.numel() >= self.GATHER_MIN_BYTES
+            return bool(self.gather_batch) and self.lay.CP <= 8
+        return (self.device.type == "cuda" and self.xp is not None and self.xp.numel() >= self.GATHER_MIN_BYTES
+                and self.lay.CP <= 8)                         # the copy is tiled for the matrix-core pass 3 (C <= 8)
 
     def _xg_buf(self) -> torch.Tensor:
         if self._xg is None:
