@@ -6,7 +6,8 @@
 //   rows64_read     pass 2's X loader: a block reads one 64-byte piece (4 lanes x 16 B) of each of `b` gathered rows, rows a
 //                   permutation of a `rows`-row matrix with row stride ld (the byte column of the block)
 //   stream_write    16 B / lane consecutive (P, m, v, dP rows)
-//   rows64_write    the by-product copy of the batch: 64-byte pieces at row stride ld
+//   rows64_write    the by-product copy of the batch, tiled by pass 3's chunks: 64-byte pieces at a stride of 128 bytes inside a
+//                   [b rows][128 bytes] tile (the block with the other half of the tile runs elsewhere, at another time)
 //   slab_write      the dQ slab: 2 KB contiguous per tile and block ([64 samples x 8] floats), blocks 25.6 KB apart
 // Every buffer is larger than the 256 MB Infinity Cache or touched once, sizes as in the bench workload (b = 800, M = 500k).
 //   hipcc --offload-arch=gfx950 -O3 tools/calib_fetch.hip -o /tmp/calib && /tmp/calib
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void rows64_write(uint8_t* __restrict__ xg, in
     const int tid = threadIdx.x, pr = tid >> 2, pc = tid & 3;
     const int64_t off = (int64_t)blockIdx.x * 64 + pc * 16;
     for (int i0 = 0; i0 < b; i0 += 64)
-        if (i0 + pr < b) *reinterpret_cast<uint4*>(xg + (int64_t)(i0 + pr) * ld + off) = make_uint4(tid, i0, 2, 3);
+        if (i0 + pr < b) *reinterpret_cast<uint4*>(xg + (off / 128) * ((int64_t)b * 128) + (int64_t)(i0 + pr) * 128 + off % 128) = make_uint4(tid, i0, 2, 3);
 }
 __global__ __launch_bounds__(256) void slab_write(float4* __restrict__ slab, int b) {      // [chunk][b][8] floats, 128 float4 per 64-sample tile
     for (int i0 = 0; i0 < b; i0 += 64) {
