@@ -69,6 +69,7 @@ def test_argument_validation_of_the_round1_additions(tmp_path):
     with pytest.raises(RuntimeError, match="0 < CP <= 8"):
         check(lib.nadm_dz_image(p, 4, 12, p, None), "dz_image")
     assert lib.nadm_dz_image_bytes(800) == 7 * 7 * 64 * 16 and lib.nadm_dz_image_bytes(128) == 7 * 64 * 16
+    assert lib.nadm_batch_copy_bytes(800, 500000) == 977 * 800 * 128 and lib.nadm_batch_copy_bytes(37, 2301) == 5 * 37 * 128
     with pytest.raises(RuntimeError, match="number of classes"):
         check(lib.nadm_supervised_ce(p, 8, 3, 4, p, None, 4, 5, 100.0, p, p, None), "supervised_ce")
     with pytest.raises(RuntimeError, match="k <= kp <= SP"):
