@@ -1246,17 +1246,20 @@ constexpr int EB_CHUNK_SNPS = EB_COLS * 4;
 //   one instruction is 32 samples x 1 SNP per lane (4 registers of nibbles), K = 128 samples per instruction.  What is left on
 //   the VALU is the bit transposition (the packed byte holds 4 SNPs of one sample, the operand wants 8 samples of one SNP per
 //   register): 40 instructions per 16 byte columns x 128 samples, where the bf16 kernel of rounds 1-2 (v_mfma_f32_16x16x32_bf16, dZ
-//   split hi + mid + lo, X converted with v_cvt_scalef32_pk_bf16_fp4) spent 4 x 40 on shifts and masks and 64 conversions.  And K = 128 costs 22-25 issue cycles where four K = 32 bf16 instructions cost 71
-//   (profiles/r03_ubench_fp4_mfma.txt).
+//   split hi + mid + lo, X converted with v_cvt_scalef32_pk_bf16_fp4) spent 4 x 40 on shifts and masks and 64 conversions.  And
+//   K = 128 costs 22-25 issue cycles where four K = 32 bf16 instructions cost 71 (profiles/r03_ubench_fp4_mfma.txt).
 //   dZ is the A operand, as FP6 (E2M3) pieces: the block of 32 samples x one column a lane holds is cut into EIGHT pieces of
 //   four bits -- the hexadecimal digits of |dZ| in fixed point below 16 x the block's largest magnitude, each with the sign
 //   of the value; digit h is the FP6 number h/8 exactly -- and the instruction's per-lane E8M0 scale carries the digit's
 //   weight 2^(E0 - 4p + 3).  Rows of the instruction = (piece parity, column), four instructions (row groups) per X operand
 //   accumulate all eight pieces into ONE accumulator; rows c and c + 8 are folded in the epilogue.  32 bits below the
 //   block maximum: an element within 2^-8 of it is carried exactly, a smaller one to an absolute error < 2^-31 of the block
-//   maximum (the bf16 kernel carried 24 bits below every element's own magnitude).  The image is the same for every block of
-//   the launch: it is built ONCE per step (dz_image_kernel; 7 KB per 128 samples) instead of once per block and tile.
-//   (layout and arithmetic of the image: nadm_common.h, dzi_build_piece; the MLP backward writes it, nadm_mlp_bwd_image.)
+//   maximum (the bf16 kernel carried 24 bits below every element's own magnitude; against a float64 product this pass is 3-4 x
+//   closer than an fp32 matmul, profiles/r03_p3_accuracy.json).  The image is the same for every block of the launch: it is built
+//   ONCE per step -- by the MLP backward (nadm_mlp_bwd_image), or by dz_image_kernel below -- instead of once per block and tile
+//   (7 KB per 128 samples; layout and arithmetic: nadm_common.h, fp6_piece / dzi_build_piece).
+//   The rows come as a stream when pass 2 has left its tiled copy of the batch (CLEAN_SRC, xg_piece): gathered out of a row-major
+//   matrix the 128-byte pieces arrive at 2.6 TB/s and the kernel takes 50 us instead of 40.
 //   Element order inside a lane (dzi_sample): what the bit transposition produces, see the tile loop.
 // =================================================================================================
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
