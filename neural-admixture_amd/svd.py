@@ -99,10 +99,27 @@ class _Rows:
         return out if keep_on_device else np.ascontiguousarray(out.t().cpu().numpy())
 
 
+def _preload_mixture_library(N: int) -> None:
+    """The decoder-init mixture fit that follows the SVD (train.gmm_p_init) calls scikit-learn for N <= 20000, and importing
+    scikit-learn takes 1.0 s on this image -- half of a default run on a 1000-Genomes-sized matrix.  Started here, on a thread,
+    the import runs underneath the SVD's GPU work (the main thread mostly waits for the device)."""
+    if N > 20_000:
+        return
+    import threading
+
+    def _imp():
+        try:
+            import sklearn.mixture  # noqa: F401
+        except Exception:                                        # the fit itself will report what is wrong
+            pass
+    threading.Thread(target=_imp, name="nadm-preload-sklearn", daemon=True).start()
+
+
 def RSVD(A_uint8, N: int, M: int, k: int = 8, seed: int = 42, oversampling: int = 10, power_iterations: int = 2,
          device: torch.device = None, rows: int = 2048) -> np.ndarray:
     if device is None:
         device = torch.device("cuda:0") if torch.cuda.is_available() else None
+    _preload_mixture_library(N)
     old_prec = torch.get_float32_matmul_precision()
     torch.set_float32_matmul_precision("highest")
     try:
