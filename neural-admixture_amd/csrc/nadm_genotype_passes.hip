@@ -1589,15 +1589,30 @@ static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
     const size_t lds = (size_t)rpb * ENC_LDW * 4;
     hipStream_t st = (hipStream_t)stream;
     if (CP <= 8) {
-        // Every block first splits its 2048 x CP slice of V into bf16 operands (about as much work as 12 sample tiles), so
-        // a block should see many tiles; but ~2 blocks per CU are needed to fill the chip.  grid.y = as few batch splits as
-        // give >= 480 blocks (never fewer than 4 tiles per block, at most EM_TILES_PER_BLOCK).  At M = 500k, b = 800:
-        // grid.y = 1 / 2 / 3 / 4 -> 45.1 / 40.7 / 44.5 / 46.1 us.
+        // Every block first splits its 2048 x CP slice of V into bf16 operands (about as much work as 11 sample tiles), so a block
+        // should see many tiles; but the 512 block slots of the chip (2 per CU) want to be filled, and a partly filled last round
+        // costs most of a full one.  grid.y = the number of batch splits (never fewer than 4 tiles per block) that minimises
+        //   rounds_eff(chunks * gy / 512) * (11.3 + tiles / gy)
+        // with rounds_eff() read off measured launches (profiles/r03_p1_batch_splits.txt: b = 800, M = 500k .. 1M, grid.y = 1..4; the
+        // model reproduces all twenty within 2 us except one): a block alone on its CU runs 1.5 x faster, a round that is a
+        // little over-full costs 1.4 rounds.  M = 500k: 2 splits (43.6 us; 1 / 3 / 4: 49.1 / 47.7 / 49.0), 600k: 3 (56.1; 60.0 with
+        // the 2 that r02's rule "as few splits as give 480 blocks" picked), 800k: 1 (70.9; 73.3 with 2), 1M: 1 (73.6).
         const int64_t chunks = nadm_encode_chunks(M);
         const int ntiles = (b + 15) / 16;
-        int64_t gy = (480 + chunks - 1) / chunks;
-        if (gy > (ntiles + 3) / 4) gy = (ntiles + 3) / 4;
-        if (gy < 1) gy = 1;
+        auto rounds_eff = [](double x) {
+            if (x <= 0.5) return 0.67;
+            if (x <= 1.0) return 0.92 + 0.16 * (x - 0.5);
+            if (x <= 1.5) return 1.40;
+            if (x <= 1.95) return 1.70;
+            if (x <= 2.0) return 2.00;
+            return 0.45 + 0.72 * x;
+        };
+        int64_t gy = 1;
+        double best = 1e30;
+        for (int64_t g = 1; g <= 64 && g <= (ntiles + 3) / 4; ++g) {
+            const double cost = rounds_eff((double)(chunks * g) / 512.0) * (11.3 + (double)((ntiles + g - 1) / g));
+            if (cost < best) { best = cost; gy = g; }
+        }
         if (adv.m && ntiles <= EM_TILES_PER_BLOCK) gy = 1;                    // prologue update of V: every row in exactly one block
         else if (adv.m) {                                                     // batch too tall for one split: the update as a launch of its own
             if (launch_adam_range(Vrw, dV, adv, M * CP, st, 0)) return 1;
