@@ -25,15 +25,16 @@ def main():
     torch.cuda.synchronize()
     data = PackedGenotypes(xp.cpu(), N, M)
     t0 = time.time()
+    seed = int(os.environ.get("NADM_RC_SEED", "42"))              # (the trainer's seed: epoch orders and small-parameter init)
     V = RSVD(data, N, M, 8, 42)
-    Ps, Qs, _ = na.train(epochs, 800, 2e-3, K, 42, data, dev, 1, 1024, True, V, None, None, None, 8)
+    Ps, Qs, _ = na.train(epochs, 800, 2e-3, K, seed, data, dev, 1, 1024, True, V, None, None, None, 8)
     dt = time.time() - t0
     Q, Qtrue, F = Qs[0].astype(np.float64), Qt.cpu().numpy().astype(np.float64), Fq.cpu().numpy().astype(np.float64)
     cost = ((Q[:, :, None] - Qtrue[:, None, :]) ** 2).sum(0)            # [est, true]
     r, c = linear_sum_assignment(cost)
     rmse_q = float(np.sqrt(((Q[:, r] - Qtrue[:, c]) ** 2).mean()))
     rmse_p = float(np.sqrt(((Ps[0].astype(np.float64)[:, r] - F.T[:, c]) ** 2).mean()))     # P = allele frequency of the coded allele / ... see note
-    print(json.dumps({"N": N, "M": M, "K": K, "epochs": epochs, "seconds": dt, "rmse_Q": rmse_q, "rmse_P_vs_F": rmse_p,
+    print(json.dumps({"N": N, "M": M, "K": K, "epochs": epochs, "seed": seed, "seconds": dt, "rmse_Q": rmse_q, "rmse_P_vs_F": rmse_p,
                       "Q_row_sums_min_max": [float(Q.sum(1).min()), float(Q.sum(1).max())]}))
 
 
