@@ -131,13 +131,17 @@ typedef unsigned u32x6_t __attribute__((ext_vector_type(6)));
 // piece p (0..7) of 32 values that share one scale block: the 32 FP6 codes (6 dwords, element e at bits [6e, 6e + 6)) and the E8M0 scale
 __device__ __forceinline__ void fp6_piece(const float (&v)[32], int p, u32x6_t& codes, int& scale_byte) {
     float mx = 0.f;
+    bool finite = true;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) mx = __builtin_fmaxf(mx, __builtin_fabsf(v[e]));
+    for (int e = 0; e < 32; ++e) {
+        mx = __builtin_fmaxf(mx, __builtin_fabsf(v[e]));
+        finite = finite && (__builtin_fabsf(v[e]) < __builtin_inff());       // (a NaN does not survive the maximum)
+    }
     // mx = m 2^ex, m in [1/2, 1): every |v| < 2^ex = 2^(E0 + 4)
     const int E0 = __builtin_amdgcn_frexp_expf(mx) - 4;
     int sb = 127 + E0 - 4 * p + 3;
-    const bool dead = !(mx > 0.f) || !(mx < __builtin_inff()) || sb < 1;   // (a piece below 2^-126 carries nothing an fp32 sum would see)
-    if (dead) sb = 127;
+    const bool dead = !(mx > 0.f) || !finite || sb < 1;     // (a piece below 2^-126 carries nothing an fp32 sum would see)
+    if (dead) sb = finite ? 127 : 255;                      // inf / NaN in the block: the E8M0 scale NaN, so that what multiplies it becomes NaN
     f32x16_t fa, fb;
 #pragma unroll
     for (int e = 0; e < 32; ++e) {

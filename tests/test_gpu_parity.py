@@ -130,6 +130,29 @@ def decode_dz_image(img_u8: np.ndarray, b: int, CP: int) -> np.ndarray:
     return out[:b, :CP]
 
 
+def test_pass3_propagates_a_nan_in_dz():
+    """A NaN (or inf) in dZ must not vanish inside the FP6 operand image: the block that holds it gets the NaN scale, and column c
+    of dV comes out NaN like the reference's X^T.dZ would -- a diverged run stays visible."""
+    from neural_admixture_amd._lib import lib, check, ptr
+    rng = np.random.default_rng(3)
+    N, M = 200, 4096
+    Gm = O.synth_genotypes(N, M, 3, seed=8, missing=0.02)
+    V0 = (rng.standard_normal((M, 8)) / np.sqrt(M)).astype(np.float32)
+    P0 = rng.uniform(0.02, 0.98, size=(5, M)).astype(np.float32)
+    e = make_engine(Gm, O.make_params(2, V0, P0, 64, [5]), N)
+    idx = torch.arange(N, dtype=torch.int32, device=e.device)
+    dZ = rng.standard_normal((N, 8)).astype(np.float32)
+    dZ[77, 3] = np.nan
+    dZ[150, 6] = np.inf
+    e.dZ[: N * 8] = torch.from_numpy(dZ.reshape(-1)).to(e.device)
+    e.invalidate_dz()
+    check(lib.nadm_encode_bwd(ptr(e.xp), e.ld, ptr(idx), N, M, ptr(e.dZ), e._dz_image(N), 8, ptr(e.gbig), 0, None))
+    torch.cuda.synchronize()
+    g = e.gV().cpu().numpy()
+    assert np.isnan(g[:, 3]).all() and not np.isfinite(g[:, 6]).any()
+    assert np.isfinite(g[:, [0, 1, 2, 4, 5, 7]]).all()
+
+
 @pytest.mark.parametrize("b", [800, 790, 37])
 def test_dz_operand_image_of_pass3(b):
     """Pass 3 (C <= 8) consumes dZ as FP6 pieces with block scales.  The image nadm_mlp_bwd_image leaves behind -- built by whichever
