@@ -774,6 +774,16 @@ __device__ __forceinline__ f32x2_t fp4_pair(const uint32_t w, const int sel) {
     }
 }
 
+// the same with the conversion's scale 2: a nibble 0001 (the subnormal 0.5) reads 1.0 -- a 0/1 selector without shifting the mask
+__device__ __forceinline__ f32x2_t fp4_pair_x2(const uint32_t w, const int sel) {
+    switch (sel) {
+        case 0: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 2.0f, 0);
+        case 1: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 2.0f, 1);
+        case 2: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 2.0f, 2);
+        default: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 2.0f, 3);
+    }
+}
+
 constexpr int BF_WAVES = NADM_BF_WAVES;
 constexpr int BF_NTW = NADM_BF_NTW;     // 16-SNP tiles per wave
 constexpr int BF_TS = NADM_BF_TS;       // samples per LDS tile
@@ -1082,8 +1092,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                                 const f32x2_t d = {D[2 * h2], D[2 * h2 + 1]}, x = fp4_pair(cw, t);
                                 f32x2_t den;
                                 const f32x2_t dR = bce_grad2(d, x, eps, den);
-                                if constexpr (FAST_LOSS)      // selector [c == 1]: a nibble 0010 is 1.0 in FP4
-                                    bce_loss_prod2(d, den, x, fp4_pair(((cw & ~(cw >> 1)) & 0x11111111u) << 1, t), it_acc);
+                                if constexpr (FAST_LOSS)      // selector [c == 1]: the nibble 0001 read with the scale 2
+                                    bce_loss_prod2(d, den, x, fp4_pair_x2((cw & ~(cw >> 1)) & 0x11111111u, t), it_acc);
                                 else if constexpr (LOSS)
                                     bce_loss_exact2<UNIT_P>(d, (f32x2_t){1.f, 1.f} - d, x, lossacc);
                                 const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector(dR, bf16x2_t));
