@@ -198,7 +198,7 @@ typedef struct {
 } nadm_mlp_weights_t;
 int nadm_encode_bwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                          const float* dZ, const void* dzimg, int32_t CP, float* V, float* dV, const nadm_adam_t* adam,
-                         const nadm_mlp_weights_t* weights, int32_t flags, void* stream);
+                         const nadm_mlp_weights_t* weights, int32_t flags /* NADM_X_CLEAN, see nadm_encode_bwd */, void* stream);
 int nadm_small_grads(const float* small_part, int32_t splits, int32_t n_small, float* grad_small, float* small,
                      const nadm_adam_t* adam, void* stream);
 /* nadm_encode_fwd of the NEXT step with nadm_small_grads of this one riding in the same launch as side blocks (pass 1 reads
