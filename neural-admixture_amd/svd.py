@@ -116,10 +116,11 @@ def _preload_mixture_library(N: int) -> None:
 
 
 def RSVD(A_uint8, N: int, M: int, k: int = 8, seed: int = 42, oversampling: int = 10, power_iterations: int = 2,
-         device: torch.device = None, rows: int = 2048) -> np.ndarray:
+         device: torch.device = None, rows: int = 2048, preload_mixture: bool = True) -> np.ndarray:
     if device is None:
         device = torch.device("cuda:0") if torch.cuda.is_available() else None
-    _preload_mixture_library(N)
+    if preload_mixture:               # (a caller that knows the fit will run in child processes -- more than two K -- passes False)
+        _preload_mixture_library(N)
     old_prec = torch.get_float32_matmul_precision()
     torch.set_float32_matmul_precision("highest")
     try:
