@@ -340,6 +340,41 @@ def case_supervised():
     np.savez_compressed(os.path.join(OUT, "supervised_k4.npz"), **out)
 
 
+def case_long_horizon():
+    """The horizon BASELINE's second metric is quoted on: a DEFAULT run is 250 epochs (entry.py:27, loop
+    model/neural_admixture.py:365-366).  (1) the bundled demo, K=3, 250 epochs, from the SAME V / P_init as demo_k3.npz (read
+    back from that fixture, so both fixtures describe one run); (2) the multibatch miniature (N=1000, M=2048, K=8, b=400) for 60
+    epochs = 180 steps with the sampler's own orders.  Both twice: "hi" (true fp32, the target) and "med" (the reference as it
+    ships: bf16 matmuls) -- the distance between the two is the yardstick the end-of-run tolerances are stated against."""
+    d = np.load(os.path.join(OUT, "demo_k3.npz"))
+    seed, K, Hd, lr = int(d["seed"]), int(d["K"]), int(d["Hd"]), float(d["lr"])
+    ref_utils.set_seed(seed)
+    data, _, N, M = ref_utils.read_data("/root/reference/demo/data/demo_data.bed")
+    V_MC = np.ascontiguousarray(d["Vt"].T.astype(np.float32))
+    P_SM = d["P_init"].astype(np.float32)
+    out = dict(epochs=250, seed=seed, K=K, Hd=Hd, lr=lr)
+    for mode in ("hi", "med"):
+        Qs, Ps, sd, sl = run_reference_training(data, V_MC, P_SM, K, None, None, Hd, 250, 800, lr, seed, mode)
+        out[f"{mode}_Q"], out[f"{mode}_P"], out[f"{mode}_V"], out[f"{mode}_losses"] = Qs[0], Ps[0], sd["V"], sl
+        out[f"{mode}_loglik"] = np.float64(ref_cy.loglikelihood(data, np.ascontiguousarray(Ps[0].astype(np.float64)),
+                                                                np.ascontiguousarray(Qs[0].astype(np.float64)), K))
+        print("demo e250", mode, sl[0], sl[-1], out[f"{mode}_loglik"])
+    np.savez_compressed(os.path.join(OUT, "demo_k3_e250.npz"), **out)
+
+    m = np.load(os.path.join(OUT, "multibatch_k8.npz"))
+    N, M, K, Hd, b, seed, lr, ep = int(m["N"]), int(m["M"]), int(m["K"]), int(m["Hd"]), int(m["b"]), int(m["seed"]), float(m["lr"]), 60
+    G = synth(N, M, K, seed=1234)
+    assert np.array_equal(pack_rule(G), m["G_packed"])             # the same matrix as multibatch_k8.npz (inputs live there)
+    out = dict(epochs=ep, N=N, M=M, K=K, Hd=Hd, b=b, seed=seed, lr=lr)
+    for mode in ("hi", "med"):
+        Qs, Ps, sd, sl = run_reference_training(G, m["V0"], m["P0"], K, None, None, Hd, ep, b, lr, seed, mode)
+        out[f"{mode}_Q"], out[f"{mode}_P"], out[f"{mode}_V"], out[f"{mode}_losses"] = Qs[0], Ps[0], sd["V"], sl
+        out[f"{mode}_loglik"] = np.float64(ref_cy.loglikelihood(G, np.ascontiguousarray(Ps[0].astype(np.float64)),
+                                                                np.ascontiguousarray(Qs[0].astype(np.float64)), K))
+        print("multibatch e60", mode, sl[:2], sl[-1], out[f"{mode}_loglik"])
+    np.savez_compressed(os.path.join(OUT, "multibatch_k8_e60.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     cases = {
@@ -358,6 +393,7 @@ if __name__ == "__main__":
         "one_step_supervised": lambda: one_step_case("one_step_supervised", 64, 509, [5], 64, 8, seed=8, sup=True),
         # BASELINE configs[1] / configs[2] model shapes (single head K=7; heads K=2..10) at fixture size
         "one_step_k7_h1024": lambda: one_step_case("one_step_k7_h1024", 56, 1021, [7], 1024, 8, seed=9),
+        "long_horizon": case_long_horizon,                 # r04: the default 250-epoch horizon (demo) and 60 epochs of the multibatch miniature
         "one_step_heads2to10": lambda: one_step_case("one_step_heads2to10", 40, 613, list(range(2, 11)), 256, 8, seed=10),
     }
     for name in (sys.argv[1:] or list(cases)):            # no arguments: every fixture; else only the named cases

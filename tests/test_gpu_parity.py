@@ -612,6 +612,36 @@ def test_trajectory_demo_c1_vs_reference(ep):
         assert abs(ll - float(d["hi_e5_loglik"])) / abs(float(d["hi_e5_loglik"])) < 1e-4
 
 
+def _end_of_run_vs_reference(Gm, p, d, batch, lr, seed):
+    """A run of the PRODUCTION path (NeuralAdmixture.launch_training on the HIP engine: fused epilogues, deferred small update,
+    prefetched epoch orders) of the fixture's length, held to SURVEY 8c's end-of-run bounds against the reference's fp32 run
+    (tests/test_oracle_golden.check_end_of_run: mean |dQ| <= 1e-2, max |dP| <= 1e-2, per-epoch loss <= 1e-3 rel, log-likelihood
+    <= 1e-4 rel, and closer to it than the reference's own bf16 run is)."""
+    from neural_admixture_amd.report import loglikelihood_packed
+    from test_oracle_golden import check_end_of_run
+    ep = int(d["epochs"])
+    Qs, Ps, model, tr = _run_trajectory(Gm, p, ep, batch, lr, seed)
+    ll = loglikelihood_packed(tr.engine, torch.from_numpy(Gm), Ps[0], Qs[0])
+    check_end_of_run(Qs[0], Ps[0], [tr.epoch_losses[e_] for e_ in range(ep)], ll, d)
+
+
+def test_default_horizon_demo_250_epochs_vs_reference():
+    """BASELINE's second metric is the wall-clock of a DEFAULT run = 250 epochs (entry.py:27, neural_admixture.py:365-366): the
+    bundled demo, K=3, from the reference's own RSVD V and GMM P_init, against the reference's 250-epoch fp32 run."""
+    dm, d = np.load(f"{G}/demo_k3.npz"), np.load(f"{G}/demo_k3_e250.npz")
+    Gm = O.unpack2bit(dm["G_packed"], int(dm["M"]))
+    p = O.make_params(int(dm["seed"]), dm["Vt"].T, dm["P_init"], int(dm["Hd"]), [3])
+    _end_of_run_vs_reference(Gm, p, d, 800, float(dm["lr"]), int(dm["seed"]))
+
+
+def test_long_horizon_multibatch_60_epochs_vs_reference():
+    """180 steps (60 epochs of 400 + 400 + 200 rows, the sampler's own orders) of the K=8 miniature."""
+    m, d = np.load(f"{G}/multibatch_k8.npz"), np.load(f"{G}/multibatch_k8_e60.npz")
+    Gm = O.unpack2bit(m["G_packed"], int(m["M"]))
+    p = O.make_params(int(m["seed"]), m["V0"], m["P0"], int(m["Hd"]), [int(m["K"])])
+    _end_of_run_vs_reference(Gm, p, d, int(m["b"]), float(m["lr"]), int(m["seed"]))
+
+
 @pytest.mark.parametrize("b,M,ks", [(800, 500_000, [8]),                    # configs[3] / the bench workload
                                     (800, 600_000, [7]),                    # configs[1]: 1000-Genomes scale, single head K=7
                                     (104, 600_000, [7]),                    # ... and its partial last batch (2504 = 3 * 800 + 104)

@@ -172,3 +172,39 @@ def test_supervised_run():
     assert abs(ls[0] - ref[0]) / ref[0] < 2e-6
     self_noise = np.abs(med - ref) / ref
     assert np.all(np.abs(ls - ref) / ref < np.maximum(3 * self_noise, 5e-3))
+
+
+# SURVEY 8c's end-of-run bounds at the horizon BASELINE's wall-clock metric is quoted on (a default run: 250 epochs, entry.py:27)
+END_OF_RUN = dict(mean_dq=1e-2, max_dp=1e-2, loglik_rel=1e-4, loss_rel=1e-3)
+
+
+def check_end_of_run(Q, P, losses, loglik, d):
+    """Q / P / per-epoch loss / log-likelihood of a run against the reference's fp32 ("hi") run of the same length, next to the
+    distance of the reference's own bf16 ("med") run from it -- the yardstick: two fp32 summation orders separate over
+    hundreds of steps like the reference separates from itself."""
+    dq, dp = np.abs(Q - d["hi_Q"]), np.abs(P - d["hi_P"])
+    ref_dq = np.abs(d["med_Q"] - d["hi_Q"])
+    assert dq.mean() <= END_OF_RUN["mean_dq"], dq.mean()
+    assert dp.max() <= END_OF_RUN["max_dp"], dp.max()
+    assert dq.mean() <= ref_dq.mean() and dq.max() <= ref_dq.max()        # closer to the fp32 run than the reference's own bf16 run
+    ref_l = np.asarray(d["hi_losses"], dtype=np.float64).reshape(len(losses), -1).sum(1)
+    assert np.max(np.abs(np.asarray(losses) - ref_l) / ref_l) <= END_OF_RUN["loss_rel"]
+    assert abs(loglik - float(d["hi_loglik"])) / abs(float(d["hi_loglik"])) <= END_OF_RUN["loglik_rel"]
+
+
+def test_default_horizon_demo_250_epochs():
+    """The bundled demo for the DEFAULT 250 epochs (entry.py:27; neural_admixture.py:365-366) from the reference's own init."""
+    dm, d = np.load(f"{G}/demo_k3.npz"), np.load(f"{G}/demo_k3_e250.npz")
+    Gm = O.unpack2bit(dm["G_packed"], int(dm["M"]))
+    p = O.make_params(int(dm["seed"]), dm["Vt"].T, dm["P_init"], int(dm["Hd"]), [3])
+    p, Qs, losses = O.train_run(Gm, p, int(d["epochs"]), 800, float(dm["lr"]), int(dm["seed"]))
+    check_end_of_run(Qs[0], p.P[0], losses, O.loglikelihood(Gm, p.P[0], Qs[0]), d)
+
+
+def test_long_horizon_multibatch_60_epochs():
+    """180 steps of the multibatch miniature (N=1000, M=2048, K=8, b=400) with the sampler's own epoch orders."""
+    m, d = np.load(f"{G}/multibatch_k8.npz"), np.load(f"{G}/multibatch_k8_e60.npz")
+    Gm = O.unpack2bit(m["G_packed"], int(m["M"]))
+    p = O.make_params(int(m["seed"]), m["V0"], m["P0"], int(m["Hd"]), [int(m["K"])])
+    p, Qs, losses = O.train_run(Gm, p, int(d["epochs"]), int(m["b"]), float(m["lr"]), int(m["seed"]))
+    check_end_of_run(Qs[0], p.P[0], losses, O.loglikelihood(Gm, p.P[0], Qs[0]), d)
