@@ -7,7 +7,8 @@ included), MLP backward, dV = X^T.dZ, gradient all-reduce (N>1), Adam on every p
 Workload (BASELINE.json configs[3]): synthetic 100k samples x 500k SNPs, K=8, resident 2-bit packed
 in HBM (12.5 GB; sharded by samples over ranks).
 
-Two multi-GPU modes, both sample-sharded with an RCCL all-reduce of the gradients every step:
+Two multi-GPU modes, both sample-sharded: gradients reduce-scattered over RCCL, Adam on each rank's 1/N slice of the parameters,
+all-gather of the result (csrc/nadm_step.hip, NADM_MODE_DP) -- every step is ONE C call:
   default            batch 800 PER GPU ("weak": the work per GPU is fixed, --batch_size 800*N in reference terms)
   --global-batch B   the reference's own semantics (neural_admixture.py:287: batch_size // num_gpus rows per GPU, i.e.
                      100 rows/GPU at N=8 for the default B=800; "strong": the work per step is fixed)
@@ -35,7 +36,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak (same guide); the three GEMM-shaped products run as bf16 pieces
 N_SIMD = 256 * 4          # 256 CUs x 4 SIMDs
 VALU_CYCLES_PER_INST = 4  # one wave64 VALU instruction occupies its SIMD for 4 cycles (tools/ubench_valu.hip; packed f32 alike)
-PROFILE_ROUND = "r03"     # profiles/<round>_pmc_*.json hold the counter passes of the kernels of THIS build (tools/pmc_profile.py)
+PROFILE_ROUND = "r04"     # profiles/<round>_pmc_*.json hold the counter passes of the kernels of THIS build (tools/pmc_profile.py)
 
 
 def parse():
@@ -60,16 +61,16 @@ def parse():
     ap.add_argument("--parallelism", choices=("dp", "snp"), default="dp",
                     help="dp (default, the reference's scheme): samples sharded, gradient all-reduce; snp: SNPs sharded, every rank "
                          "processes the global batch of batch*N rows on its M/N SNPs, two small all-reduces per step")
-    ap.add_argument("--force-ddp", action="store_true", help="single GPU: run the data-parallel step (sub-range launches + RCCL all-reduce on a 1-rank group)")
+    ap.add_argument("--force-ddp", action="store_true", help="single GPU: run the sample-sharded step (NADM_MODE_DP) on a 1-rank RCCL communicator")
+    ap.add_argument("--emulate-world", type=int, default=None, metavar="W",
+                    help="single GPU, with --force-ddp: the step of rank 0 of W ranks with no-op collectives (nadm_comm_emulated) -- Adam on 1/W of "
+                         "the parameters, the rest treated as gathered.  The per-rank GPU and host cost of a W-rank step; NOT a scaling measurement")
     ap.add_argument("--time-kernels", choices=("dominant", "all"), default="dominant",
                     help="HIP events inside the timed region around the dominant kernel only (default: two event records per step) "
                          "or around every kernel of the step (kernel_ms table; the records cost ~4 %% of the step)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="functional check of the N>1 flow on a ONE-GPU box: all ranks use cuda:0 and gloo carries the tensors "
                          "(RCCL refuses two ranks per device); not a measurement")
-    ap.add_argument("--head-streams", type=int, default=None, help="multi-head models: concurrent pass-2 launches (Engine.head_streams)")
-    ap.add_argument("--no-defer-small", action="store_true", help="A/B: the small-parameter update as a launch of its own after pass 3 (Engine.defer_small = False)")
-    ap.add_argument("--no-q-images", action="store_true", help="A/B: every pass-2 block splits Q into bf16 operands itself (Engine.q_images = False)")
     ap.add_argument("--cpu-rows", type=int, default=2400, help="rows of the same workload used for the bounded CPU baseline")
     ap.add_argument("--cpu-steps", type=int, default=12, help="timed steps of the CPU baseline (min / median / max reported)")
     return ap.parse_args()
@@ -184,7 +185,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or args.force_ddp or args.parallelism == "snp"
+    use_dist = world > 1
+    if args.emulate_world is not None and (world > 1 or not args.force_ddp):
+        raise SystemExit("--emulate-world needs --force-ddp on ONE GPU")
     rccl_ranks = 0
     if use_dist:
         import torch.distributed as dist
@@ -229,6 +232,28 @@ def main():
     else:
         b = args.batch
     snp = args.parallelism == "snp"
+    ddp = not snp and (world > 1 or args.force_ddp)
+    from neural_admixture_amd import comm as nacomm
+    comm = None
+    if args.emulate_world is not None:
+        comm = nacomm.emulated_comm(args.emulate_world)
+    elif snp or ddp:
+        # a communicator of the library's own (ncclCommInitRank; torch.distributed only carries the 128-byte id): RCCL prints a
+        # banner through C stdio on stdout -- keep stdout for the one JSON line
+        import ctypes
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            comm = nacomm.torch_comm(rank, world) if args.share_gpu else nacomm.rccl_comm(rank, world)
+            if comm.kind == "rccl":
+                rccl_ranks = comm.count_ranks(dev)                      # every rank contributes 1: the ranks the library's communicator connected
+                if rccl_ranks != world:
+                    raise RuntimeError(f"all-reduce over {world} ranks summed to {rccl_ranks}")
+        finally:
+            ctypes.CDLL(None).fflush(None)
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     rng = np.random.default_rng(42)                                     # identical parameters on every rank
     V0 = (0.01 * rng.standard_normal((M, 8))).astype(np.float32)
     P0 = rng.uniform(5e-6, 1 - 5e-6, size=(S, M)).astype(np.float32)
@@ -236,36 +261,24 @@ def main():
         # every rank: ALL rows of its SNP slice (same bytes in HBM per rank as the sample-sharded layout), global batch b*world
         from neural_admixture_amd.snp_parallel import SnpShardedEngine
         rows_local, gb = args.rows, b * world
-        eng = SnpShardedEngine(M, 8, args.hidden, ks, dev, gb, rank, world)
+        eng = SnpShardedEngine(M, 8, args.hidden, ks, dev, gb, comm=comm)
         eng.set_packed(make_dataset(eng, rows_local, 0, K, dev, seed=1234 + 7 * rank))
         gperm = torch.Generator(device="cpu").manual_seed(1000)         # the same global batches on every rank
     else:
         rows_local, gb = args.rows // world, b
-        eng = na.Engine(M, 8, args.hidden, ks, dev, b)
+        eng = na.Engine(M, 8, args.hidden, ks, dev, b, mode="dp" if ddp else "single", comm=comm if ddp else None)
         eng.set_packed(make_dataset(eng, rows_local, rank * rows_local, K, dev))
         gperm = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    if args.head_streams is not None:
-        eng.head_streams = args.head_streams
-    if args.no_q_images:
-        eng.q_images = False
-    if args.no_defer_small:
-        eng.defer_small = False
     eng.load_params(V0, P0, init_encoder_weights(42, 8, args.hidden, ks))
     del V0, P0
     perm = torch.randperm(rows_local, generator=gperm).to(torch.int32).to(dev)
     nb = max(1, rows_local // gb)
     with_loss = not args.no_loss
     lr = 2e-3
-    ddp = not snp and (world > 1 or args.force_ddp)
 
-    def step(s):
+    def step(s):                                                        # ONE C call: launches and collectives of the step
         o = (s % nb) * gb
-        if snp:
-            eng.train_step(perm[o:o + gb], gb, lr, with_loss)
-        elif ddp:
-            eng.train_step_ddp(perm[o:o + b], b, lr, world, with_loss, defer_tail=True)
-        else:
-            eng.train_step(perm[o:o + b], b, lr, with_loss)
+        eng.train_step(perm[o:o + gb], gb, lr, with_loss)
 
     # untimed clock-ramp phase: the same steps until --ramp-ms of wall-clock have passed (the sustained clock is reached
     # after ~25 launches; `--warmup 5 --steps 20` straight after start-up would time the ramp, not the step)
@@ -284,16 +297,16 @@ def main():
                 break
     for s in range(args.warmup):
         step(n_ramp + s)
-    eng.timers = {}
-    eng.timed_names = None if args.time_kernels == "all" else {"decode_bce"}
+    from neural_admixture_amd._lib import T_NAMES
+    eng.time_kernels(T_NAMES if args.time_kernels == "all" else ("decode_bce",))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(n_ramp + args.warmup + s)
-    if ddp:
-        eng.finish_ddp()                                   # the last step's deferred P piece belongs to the timed work
+    eng.sync()                                             # what the last step left to "the next one" belongs to the timed work
+    t_queued = time.perf_counter() - t0                    # the host has queued everything (the GPU is still running)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -303,24 +316,27 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    timers, eng.timers = eng.timers, None
+    kms = eng.kernel_ms()
     loss_sum, loss_last = eng.read_loss()
     assert np.isfinite(loss_last) or not with_loss
-
-    kms = {name: float(np.mean([a.elapsed_time(c) for a, c in evs])) for name, evs in timers.items()}
     if args.time_kernels == "dominant":
         # the other kernels of the step, for the kernel_ms table only: a short pass AFTER the timed region with events around
         # every kernel (those records cost ~4 % of the step, which is why the timed region carries only the dominant kernel's)
-        eng.timers, eng.timed_names = {}, None
+        eng.time_kernels(T_NAMES)
         for s in range(min(args.steps, 20)):
             step(n_ramp + args.warmup + args.steps + s)
-        if ddp:
-            eng.finish_ddp()
-        torch.cuda.synchronize()
-        extra, eng.timers = eng.timers, None
-        for name, evs in extra.items():
+        eng.sync()
+        for name, v in eng.kernel_ms().items():
             if name != "decode_bce":
-                kms[name] = float(np.mean([a.elapsed_time(c) for a, c in evs]))
+                kms[name] = v
+    eng.time_kernels(None)
+    # the host's cost of queueing a step, measured where the GPU cannot hide it: steps queued back to back onto an idle device
+    torch.cuda.synchronize()
+    t_h = time.perf_counter()
+    for s in range(20):
+        step(s)
+    host_queue_ms = (time.perf_counter() - t_h) / 20 * 1e3
+    torch.cuda.synchronize()
     # ---- roofline of the dominant kernel = pass 2 (decode_bce: all heads of the step) ----
     # Algorithmic bytes in the accounting of SURVEY.md 8d (whole step = 0.75 B/genotype of packed X + 36 B per parameter of
     # parameter/optimizer traffic): one 2-bit pass over the batch + the pass's share of the per-parameter traffic.
@@ -329,7 +345,7 @@ def main():
     #            8 B (read P, write dP) when Adam is a launch of its own behind the all-reduce (data-parallel step)
     #   alg_min: the bytes the launch must really move: fused = read P, m, v + write P, m, v = 24 B per parameter; unfused = 8 B
     dom = "decode_bce"
-    fused = (snp or not ddp) and getattr(eng, "fused_adam", False)
+    fused = snp or not ddp                                                # Adam + restrict_P in the pass's epilogue
     rows_b, m_loc = (gb, eng.M) if snp else (b, M)                       # snp: global batch x own SNP slice
     # X is priced ONCE whatever the number of heads (0.25 B per genotype and pass); the launches of a multi-head model
     # walk X once per head, which is real traffic but not algorithmic -- reported separately as x_walks / bytes_incl_x_rewalks
@@ -340,7 +356,7 @@ def main():
     composition = {                                                      # known bytes of the pass-2 launch(es) per access pattern (tools/pmc_profile.py)
         "x_pieces_read": x_walks * rows_b * m_loc / 4.0,
         "param_stream_read": (12 if fused else 4) * m_loc * kp_sum * 1.0 + (0 if fused else 0),
-        "batch_copy_write": rows_b * m_loc / 4.0 if eng._gather() else 0.0,
+        "batch_copy_write": rows_b * m_loc / 4.0 if eng._xg is not None else 0.0,
         "dq_slab_write": sum(int(c_) * rows_b * int(k_) * 4.0 for c_, k_ in zip(eng.lay.dec_chunks, eng.lay.kp)),
         "param_stream_write": (12 if fused else 4) * m_loc * kp_sum * 1.0}
     t_dom = kms[dom] * 1e-3
@@ -381,8 +397,14 @@ def main():
                                f"{'SNP' if snp else 'sample'}-sharded over {world} GPU(s), batch {b}/GPU, hidden {args.hidden}, n_components 8, "
                                f"loss value {'every step' if with_loss else 'skipped'}",
                    "global_batch": gb if snp else b * world, "parallelism": f"{args.parallelism}{world}", "mode": mode,
-                   "clock_ramp_steps_untimed": n_ramp},
-        "roofline": {"bound": "hbm", "limiter": "valu_issue", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "clock_ramp_steps_untimed": n_ramp, "transport": comm.kind if comm is not None else None,
+                   "emulated_world": args.emulate_world},
+        # one C call per step (nadm_step): host time to queue a step onto an idle device; the timed region's own loop took
+        # t_queued to queue (GPU-bound: the launch queue stays ahead)
+        "host_queue_ms_per_step": host_queue_ms, "host_loop_ms_per_step_in_timed_region": t_queued / args.steps * 1e3,
+        # bound: what binds the kernel (VALU + matrix instruction issue: issue_frac of all SIMD-cycles); roof_8d: the roof SURVEY 8d prices
+        # it against (achieved / peak / frac are in that accounting)
+        "roofline": {"bound": "valu_issue", "roof_8d": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_8d": achieved / HBM_PEAK_GBS, "frac_min": alg_min / t_dom / 1e9 / HBM_PEAK_GBS,
                      # what the counters say the launch is bound by: the fraction of all SIMD-cycles of the launch spent issuing VALU and
                      # matrix instructions (they do not overlap on a SIMD), and the VALU instruction rate against 1024 SIMDs x clk / 4
@@ -414,7 +436,7 @@ def main():
     if args.share_gpu:
         out["config"]["share_gpu"] = "all ranks on cuda:0 over gloo: functional check, not a measurement"
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and len(ks) == 1:
+        if world == 1 and not args.no_cpu_baseline and len(ks) == 1 and args.emulate_world is None:
             out["cpu_baseline"] = cpu_baseline(eng, args, dev)
         print(json.dumps(out))
         sys.stdout.flush()

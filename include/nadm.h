@@ -40,7 +40,7 @@ extern "C" {
 
 #define NADM_MAX_HEADS 32
 #define NADM_MAX_K 64
-#define NADM_ABI_VERSION 8   /* 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
+#define NADM_ABI_VERSION 9   /* 9: nadm_step / nadm_plan_* / nadm_comm_* / nadm_flat_layout (the step as one call, sharded optimizer), nadm_test_force_generic_mlp; 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
@@ -288,6 +288,115 @@ int nadm_adam(float* param, const float* grad, float* m, float* v, int64_t n, in
 int nadm_adam2(float* param0, const float* grad0, float* m0, float* v0, int64_t n0, int64_t clamp_from0,
                float* param1, const float* grad1, float* m1, float* v1, int64_t n1,
                float lr, int32_t step, float grad_scale, void* stream);
+
+/* ======================================================================================================================
+ * The training step as ONE call  (replaces NeuralAdmixture._run_step + the DDP hooks + optimizer.step + restrict_P,
+ * neural_admixture.py:315-319,403-414, as one host call per step; the entry points above remain the pieces it is made of)
+ * ======================================================================================================================
+ * Flat parameter layout.  Parameters, gradients and (single / SNP-sharded mode) Adam moments live in ONE flat float buffer each:
+ *     [ small | pad to 64 | V [M,CP] | gap | P_0 [M,KP_0] | P_1 ... | gap ]
+ * cut into the two MESSAGES of the sample-sharded step: B = [0, world * slice_b) holds the small parameters and V, A =
+ * [msg_a_off, msg_a_off + world * slice_a) holds every head's P; the gaps (zeros, < 4 * world floats) make both a multiple of
+ * `world` slices.  world = 1: no gaps. */
+typedef struct nadm_flat_layout {
+    int64_t n_flat;                       /* floats in a flat buffer                                  */
+    int64_t off_v;                        /* V starts here (= n_small rounded up to 64)               */
+    int64_t off_p[NADM_MAX_HEADS];        /* head h's P starts here                                   */
+    int64_t slice_b, slice_a;             /* floats per rank of message B / A                         */
+    int64_t msg_a_off;                    /* = world * slice_b                                        */
+} nadm_flat_layout_t;
+int nadm_flat_layout(const nadm_heads_t* hd, int64_t M, int32_t world, nadm_flat_layout_t* out);
+
+/* Transport of the step's collectives.  The step issues them on hipStreams it names; an implementation must order its work on
+ * that stream (RCCL does; a host transport synchronises the stream).  All three operate IN PLACE on float buffers:
+ *   reduce_scatter(buf, slice): buf holds world * slice floats; afterwards THIS rank's slice [rank*slice, (rank+1)*slice) holds the
+ *                               sum over ranks of that slice (the other slices are scratch)                    (ncclReduceScatter)
+ *   all_gather(buf, slice):     every rank contributes its own slice; afterwards buf is complete everywhere    (ncclAllGather)
+ *   all_reduce(buf, n):         sum over ranks                                                                 (ncclAllReduce)
+ * nadm_comm_rccl: a communicator of its own over RCCL / xGMI (ncclCommInitRank with `unique_id`, 128 bytes from
+ * nadm_comm_rccl_unique_id on rank 0, distributed by the caller -- the reference gets its communicator from
+ * init_process_group("nccl"), src/utils.py:88-93).  librccl_path: the librccl.so to dlopen (NULL: "librccl.so"); pass the path of
+ * the copy already mapped into the process.  nadm_comm_emulated: rank 0 of `world` ranks with no-op collectives -- the per-rank
+ * cost of a world-rank step measured on ONE GPU (bench.py --emulate-world; the run's results are meaningless). */
+typedef struct nadm_comm {
+    int32_t rank, world;
+    void* ctx;
+    int (*reduce_scatter)(void* ctx, float* buf, int64_t slice, void* stream);
+    int (*all_gather)(void* ctx, float* buf, int64_t slice, void* stream);
+    int (*all_reduce)(void* ctx, float* buf, int64_t n, void* stream);
+    void (*destroy)(void* ctx);           /* may be NULL */
+} nadm_comm_t;
+int  nadm_comm_rccl_unique_id(const char* librccl_path, void* id128);
+int  nadm_comm_rccl(const char* librccl_path, const void* id128, int32_t rank, int32_t world, nadm_comm_t** out);
+int  nadm_comm_emulated(int32_t world, nadm_comm_t** out);
+void nadm_comm_free(nadm_comm_t* comm);
+
+/* How the work of a step is spread over ranks */
+#define NADM_MODE_SINGLE 0   /* one GPU: Adam + restrict_P in the epilogues of passes 2 and 3                                        */
+#define NADM_MODE_DP     1   /* samples sharded (the reference's scheme, neural_admixture.py:287,315-319): gradients summed over ranks,
+                              * optimizer SHARDED -- reduce-scatter -> Adam (grad_scale 1/world = DDP's mean) + restrict_P on this rank's
+                              * 1/world slice of the parameters and ITS moments only -> all-gather of the updated parameters.  Same wire
+                              * bytes as the all-reduce, optimizer traffic and Adam-moment memory / world.  Message A (all P) travels on a
+                              * side stream underneath the MLP backward, pass 3 and the next step's pass 1; message B (small | V) on the
+                              * compute stream behind pass 3 */
+#define NADM_MODE_SNP    2   /* SNPs sharded (8(f)-4): every rank owns M/world SNPs of X, V, P and their Adam state and processes the
+                              * GLOBAL batch; two small all-reduces per step (partial Z, partial dQ), Adam in the epilogues with 1/world */
+
+/* Everything the step touches; every pointer is caller-owned device memory (sizes: the entry points above) */
+typedef struct nadm_plan_desc {
+    int32_t mode, bmax;
+    int64_t M, ld;
+    nadm_heads_t heads;
+    const uint8_t* xp;                    /* resident packed rows (nadm_plan_set_rows replaces it)                             */
+    float *params, *grads;                /* flat buffers, nadm_flat_layout(heads, M, comm world in DP mode, else 1)            */
+    float *m, *v;                         /* Adam moments: flat like params (single, SNP); DP: [slice_b | slice_a] of THIS rank */
+    float *zpart, *Z, *rinv, *Zn, *H, *Q, *dL, *dHpre, *dgp, *dZ, *dqpart, *losspart, *small_part;
+    float *zsum, *dqsum;                  /* SNP mode: [bmax*CP], [bmax*SP]                                                     */
+    void* qimg; int64_t qimg_head_bytes;  /* nadm_mlp_fwd_images (zero-filled once)                                            */
+    void* dzimg; int32_t* dzcnt;          /* nadm_mlp_bwd_image  (C <= 8; counters zero-filled once)                            */
+    uint8_t* xg;                          /* nadm_batch_copy_bytes(bmax, M) (C <= 8)                                            */
+    double* loss_acc;                     /* [2]: running sum, last step                                                        */
+    const nadm_comm_t* comm;              /* NULL: one rank.  Must outlive the plan                                             */
+} nadm_plan_desc_t;
+typedef struct nadm_plan nadm_plan_t;
+int  nadm_plan_create(const nadm_plan_desc_t* desc, nadm_plan_t** out);
+void nadm_plan_destroy(nadm_plan_t* plan);
+int  nadm_plan_set_rows(nadm_plan_t* plan, const uint8_t* xp);
+/* supervised mode (neural_admixture.py:460-474): class per resident row, NULL switches it off */
+int  nadm_plan_set_labels(nadm_plan_t* plan, const int32_t* labels, int32_t n_classes, float weight);
+/* Adam step count (1-based count of completed steps; 0 after loading parameters) and whether every P entry lies in [0, 1] (true
+ * after any step -- restrict_P -- and for the GMM initialisation; while false the loss path clamps the reconstruction before the
+ * logarithm, nadm_decode_bce with_loss bit 1).  Callers that run optimizer steps of their own (nadm_adam) keep the count in step. */
+int  nadm_plan_set_state(nadm_plan_t* plan, int32_t step_count, int32_t p_in_unit_range);
+int32_t nadm_plan_p_in_unit_range(const nadm_plan_t* plan);
+int32_t nadm_plan_step_count(const nadm_plan_t* plan);
+
+/* ONE training step on the batch rows idx[0..b) -- gather/decode, forward, loss, backward, gradient exchange, Adam, restrict_P --
+ * queued on `stream` (and, in DP mode, on the plan's side stream), asynchronous.  with_loss: also add the step's loss value to
+ * loss_acc.  The step may leave work to the NEXT step's launches (single / SNP: the small-parameter update rides in the next
+ * pass 1; DP: message A completes underneath the next pass 1): nadm_plan_flush makes `stream` see every parameter final. */
+int  nadm_step(nadm_plan_t* plan, const int32_t* idx, int32_t b, float lr, int32_t with_loss, void* stream);
+int  nadm_plan_flush(nadm_plan_t* plan, void* stream);
+/* Encoder only (final Q, neural_admixture.py:369-383; inference.py:71-77): pass 1 + MLP forward -> Q [b, SP] */
+int  nadm_plan_infer(nadm_plan_t* plan, const int32_t* idx, int32_t b, void* stream);
+
+/* Measurement: HIP events around the launches of a step on the stream they run on.  mask bit i = NADM_T_* below; the records cost
+ * ~1 % of a step per bit, hence a mask.  nadm_plan_kernel_ms synchronises, writes the mean duration [ms] of every timed group since
+ * the last call (0 where nothing was timed) and clears the records. */
+#define NADM_T_ENCODE_FWD 0
+#define NADM_T_MLP_FWD    1
+#define NADM_T_DECODE_BCE 2
+#define NADM_T_MLP_BWD    3
+#define NADM_T_ENCODE_BWD 4
+#define NADM_T_SYNC_A     5   /* DP: message A on the side stream (reduce-scatter, Adam, all-gather) */
+#define NADM_T_SYNC_B     6   /* DP: small-gradient sum + message B on the compute stream            */
+#define NADM_T_COUNT      7
+int  nadm_plan_timing(nadm_plan_t* plan, uint32_t mask);
+int  nadm_plan_kernel_ms(nadm_plan_t* plan, float* ms /* [NADM_T_COUNT] */, int32_t* counts /* [NADM_T_COUNT], may be NULL */);
+
+/* ---- test hook: route nadm_mlp_fwd / nadm_mlp_bwd to the generic (any hidden width) kernels even where the register-resident
+ * ones apply, so that tests can compare the two.  Process-wide; not for production use. */
+void nadm_test_force_generic_mlp(int32_t on);
 
 /* ---- 8(f)-3: log-likelihood report from the packed matrix (src/utils_c/utils.pyx:15-40, called train.py:134-146) -----
  * partial[b] (b < nadm_loglik_blocks(M), double, device) = sum over the block's 1024 SNPs and all `rows` rows of

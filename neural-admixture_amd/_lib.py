@@ -30,6 +30,35 @@ class AdamArgs(C.Structure):
                 ("when", C.c_int32)]
 
 
+class FlatLayout(C.Structure):
+    """nadm_flat_layout_t (include/nadm.h)."""
+    _fields_ = [("n_flat", C.c_int64), ("off_v", C.c_int64), ("off_p", C.c_int64 * MAX_HEADS), ("slice_b", C.c_int64),
+                ("slice_a", C.c_int64), ("msg_a_off", C.c_int64)]
+
+
+COMM_SLICES_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)      # (ctx, buf, slice | n, stream)
+COMM_DESTROY_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class CommStruct(C.Structure):
+    """nadm_comm_t (include/nadm.h)."""
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("ctx", C.c_void_p), ("reduce_scatter", COMM_SLICES_FN),
+                ("all_gather", COMM_SLICES_FN), ("all_reduce", COMM_SLICES_FN), ("destroy", COMM_DESTROY_FN)]
+
+
+class PlanDesc(C.Structure):
+    """nadm_plan_desc_t (include/nadm.h)."""
+    _fields_ = ([("mode", C.c_int32), ("bmax", C.c_int32), ("M", C.c_int64), ("ld", C.c_int64), ("heads", Heads), ("xp", C.c_void_p)]
+                + [(n, C.c_void_p) for n in ("params", "grads", "m", "v", "zpart", "Z", "rinv", "Zn", "H", "Q", "dL", "dHpre", "dgp", "dZ",
+                                             "dqpart", "losspart", "small_part", "zsum", "dqsum", "qimg")]
+                + [("qimg_head_bytes", C.c_int64), ("dzimg", C.c_void_p), ("dzcnt", C.c_void_p), ("xg", C.c_void_p), ("loss_acc", C.c_void_p),
+                   ("comm", C.POINTER(CommStruct))])
+
+
+MODE_SINGLE, MODE_DP, MODE_SNP = 0, 1, 2
+T_NAMES = ("encode_fwd", "mlp_fwd", "decode_bce", "mlp_bwd", "encode_bwd", "sync_a", "sync_b")     # NADM_T_* slots
+
+
 class MlpWeights(C.Structure):
     """nadm_mlp_weights_t (include/nadm.h)."""
     _fields_ = [("hd", C.POINTER(Heads)), ("Zn", C.c_void_p), ("H", C.c_void_p), ("dL", C.c_void_p), ("dHpre", C.c_void_p),
@@ -88,12 +117,30 @@ def _load():
         "nadm_adam": (C.c_int, [vp, vp, vp, vp, i64, i64, f32, i32, f32, vp]),
         "nadm_adam2": (C.c_int, [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, i64, f32, i32, f32, vp]),
         "nadm_synth_packed": (C.c_int, [vp, i64, i64, i64, i64, vp, vp, i32, f32, u64, vp]),
+        "nadm_flat_layout": (C.c_int, [HP, i64, i32, C.POINTER(FlatLayout)]),
+        "nadm_comm_rccl_unique_id": (C.c_int, [C.c_char_p, vp]),
+        "nadm_comm_rccl": (C.c_int, [C.c_char_p, vp, i32, i32, C.POINTER(C.POINTER(CommStruct))]),
+        "nadm_comm_emulated": (C.c_int, [i32, C.POINTER(C.POINTER(CommStruct))]),
+        "nadm_comm_free": (None, [C.POINTER(CommStruct)]),
+        "nadm_plan_create": (C.c_int, [C.POINTER(PlanDesc), C.POINTER(vp)]),
+        "nadm_plan_destroy": (None, [vp]),
+        "nadm_plan_set_rows": (C.c_int, [vp, vp]),
+        "nadm_plan_set_labels": (C.c_int, [vp, vp, i32, f32]),
+        "nadm_plan_set_state": (C.c_int, [vp, i32, i32]),
+        "nadm_plan_step_count": (i32, [vp]),
+        "nadm_plan_p_in_unit_range": (i32, [vp]),
+        "nadm_step": (C.c_int, [vp, vp, i32, f32, i32, vp]),
+        "nadm_plan_flush": (C.c_int, [vp, vp]),
+        "nadm_plan_infer": (C.c_int, [vp, vp, i32, vp]),
+        "nadm_plan_timing": (C.c_int, [vp, C.c_uint32]),
+        "nadm_plan_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(i32)]),
+        "nadm_test_force_generic_mlp": (None, [i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.nadm_abi_version() != 8:
+    if lib.nadm_abi_version() != 9:
         raise RuntimeError("neural_admixture_amd: libnadm.so ABI version mismatch")
     return lib, tuple(sig)
 

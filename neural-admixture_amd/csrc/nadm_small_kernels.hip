@@ -1344,11 +1344,15 @@ extern "C" int nadm_unpack2bit(const uint8_t* in_dev, uint8_t* out_dev, int64_t 
     return check_launch("unpack2bit");
 }
 
+// test hook (nadm_test_force_generic_mlp): the generic kernels also where the register-resident ones apply
+static int g_force_generic_mlp = 0;
+extern "C" void nadm_test_force_generic_mlp(int32_t on) { g_force_generic_mlp = on != 0; }
+
 static int mlp_fwd_impl(const nadm_heads_t* hd, const float* small, const float* zpart, int64_t n_chunks, int32_t b,
                         float* Z, float* rinv, float* Zn, float* H, float* Q, uint4* qimg, int64_t qimg_head_u4, void* stream) {
     if (!hd || !small || !zpart || !Z || !rinv || !Zn || !H || !Q) return fail("nadm_mlp_fwd: null pointer");
     if (b <= 0) return fail("nadm_mlp_fwd: empty batch");
-    if (hd->Hd <= 256 * MLP_JMAX && hd->C <= 8 && !getenv("NADM_MLP_GENERIC")) {
+    if (hd->Hd <= 256 * MLP_JMAX && hd->C <= 8 && !g_force_generic_mlp) {
         const dim3 grid((b + MLP_SB - 1) / MLP_SB);
         const size_t lds = (size_t)(MLP_SB + 1) * hd->SP * 4;                    // s_logit + the head biases
         const bool c8 = hd->C == 8 && ((reinterpret_cast<uintptr_t>(small) + 4 * (size_t)hd->w1_off) & 15) == 0;
@@ -1476,7 +1480,7 @@ static int mlp_bwd_impl(const nadm_heads_t* hd, const float* small, float* dqpar
                 if (dqc.n[h] > DQ_R) dqc.n[h] = DQ_R;
         }
     }
-    if (hd->Hd <= 256 * MLP_JMAX && hd->C <= 8 && !getenv("NADM_MLP_GENERIC")) {
+    if (hd->Hd <= 256 * MLP_JMAX && hd->C <= 8 && !g_force_generic_mlp) {
         const dim3 grid((b + MLP_SB - 1) / MLP_SB + (n_loss > 0 ? 1 : 0));          // + the loss block
         const size_t lds = (size_t)3 * MLP_SB * hd->SP * 4;                      // s_dl + the block's Q rows + dL
         const bool c8 = hd->C == 8 && ((reinterpret_cast<uintptr_t>(small) + 4 * (size_t)hd->w1_off) & 15) == 0;

@@ -1,21 +1,24 @@
-"""Parameter layout in HBM (mirrors include/nadm.h).
+"""Parameter layout in HBM (mirrors include/nadm.h, nadm_flat_layout).
 
-big   = V [M,CP] | P_0 [M,KP_0] | P_1 [M,KP_1] ...      (flat float32)
+flat  = small | pad | V [M,CP] | gap | P_0 [M,KP_0] | P_1 [M,KP_1] ... | gap          (float32; one buffer each for parameters,
+                                                                                       gradients and Adam moments)
 small = g[C] | W1[Hd,C] | b1[Hd] | Wk_0[k_0,Hd] | bk_0[k_0] | ...
+big   = flat[off_v:]  (V and every P; ``p_off`` / ``clamp_from`` below are offsets into it)
 
-The reference keeps the same tensors as separate nn.Parameters (Q_P, neural_admixture.py:100-150);
-flat buffers make the gradient all-reduce one message per buffer and Adam one launch per buffer.
+The reference keeps the same tensors as separate nn.Parameters (Q_P, neural_admixture.py:100-150); one flat buffer makes the
+sample-sharded step's gradient exchange two messages -- B = [small | V], A = [all P] -- each cut into ``world`` equal slices
+(reduce-scatter -> optimizer on the own slice -> all-gather); the gaps (zeros, world = 1: none) make the cuts come out even.
 """
 import ctypes as C
 from typing import List, Sequence
 
-from ._lib import lib, Heads, check
+from ._lib import lib, Heads, FlatLayout, check
 
 
 class ModelLayout:
-    def __init__(self, M: int, C_: int, Hd: int, ks: Sequence[int]):
+    def __init__(self, M: int, C_: int, Hd: int, ks: Sequence[int], world: int = 1):
         ks = sorted(int(k) for k in ks)
-        self.M, self.C, self.Hd, self.ks = int(M), int(C_), int(Hd), ks
+        self.M, self.C, self.Hd, self.ks, self.world = int(M), int(C_), int(Hd), ks, int(world)
         self.heads = Heads()
         arr = (C.c_int32 * len(ks))(*ks)
         check(lib.nadm_heads_init(C.byref(self.heads), self.C, self.Hd, arr, len(ks)), "heads_init")
@@ -23,14 +26,14 @@ class ModelLayout:
         self.CP, self.SP, self.n_small = h.CP, h.SP, h.n_small
         self.kp: List[int] = [h.kp[i] for i in range(len(ks))]
         self.qoff: List[int] = [h.qoff[i] for i in range(len(ks))]
+        fl = FlatLayout()
+        check(lib.nadm_flat_layout(C.byref(self.heads), self.M, self.world, C.byref(fl)), "flat_layout")
+        self.n_flat, self.off_v = int(fl.n_flat), int(fl.off_v)
+        self.slice_b, self.slice_a, self.msg_a_off = int(fl.slice_b), int(fl.slice_a), int(fl.msg_a_off)
         self.v_off = 0
-        self.p_off: List[int] = []
-        off = self.M * self.CP
-        for kp in self.kp:
-            self.p_off.append(off)
-            off += self.M * kp
-        self.n_big = off
-        self.clamp_from = self.M * self.CP                 # restrict_P applies to the P part only
+        self.p_off: List[int] = [int(fl.off_p[i]) - self.off_v for i in range(len(ks))]     # into big = flat[off_v:]
+        self.n_big = self.n_flat - self.off_v
+        self.clamp_from = self.p_off[0]                     # restrict_P applies to the P part only
         self.enc_chunks = int(lib.nadm_encode_chunks(self.M))
         self.dec_chunks = [int(lib.nadm_decode_chunks(self.M, kp)) for kp in self.kp]
         self.n_loss = sum(self.dec_chunks)

@@ -185,7 +185,7 @@ class _EpochOrders:
 
 class NeuralAdmixture:
     """Trainer mirror (constructor signature of neural_admixture.py:248-249)."""
-    engine_cls = Engine          # tests swap in an oracle-backed double to run the DDP orchestration on gloo
+    engine_cls = Engine          # tests swap in an oracle-backed double to run the multi-rank logic on gloo / CPU
     engine_snp_cls = None        # set below (import cycle): snp_parallel.SnpShardedEngine
 
     def __init__(self, k, epochs, batch_size, learning_rate, device, seed, num_gpus, master, pack2bit=None,
@@ -222,7 +222,13 @@ class NeuralAdmixture:
         infer_b = min(N, 1024)
         if self.parallelism == "snp" and world > 1:
             return self._launch_training_snp(P, data, hidden_size, C, V, M, N, pops, world, rank)
-        eng = self.engine_cls(M, C, hidden_size, self.ks_list, dev, max(self.batch_size, infer_b))
+        if world > 1:
+            # the step's collectives: RCCL over xGMI behind an nccl process group, torch.distributed callbacks otherwise (comm.py)
+            from .comm import make_comm
+            eng = self.engine_cls(M, C, hidden_size, self.ks_list, dev, max(self.batch_size, infer_b), mode="dp",
+                                  comm=make_comm(dev, rank, world))
+        else:
+            eng = self.engine_cls(M, C, hidden_size, self.ks_list, dev, max(self.batch_size, infer_b))
         self.engine = eng
         small = init_encoder_weights(self.seed, C, hidden_size, self.ks_list)
         eng.load_params(V.detach().cpu().numpy(), P.detach().cpu().numpy(), small)
@@ -261,10 +267,7 @@ class NeuralAdmixture:
                     order = orders.take(epoch, prefetch=epoch + 1 < self.epochs)
                 for s in range(0, n_local, b):
                     bb = min(b, n_local - s)
-                    if world > 1:
-                        eng.train_step_ddp(order[s:s + bb], bb, self.lr, world, with_loss, defer_tail=True)
-                    else:
-                        eng.train_step(order[s:s + bb], bb, self.lr, with_loss)
+                    eng.train_step(order[s:s + bb], bb, self.lr, with_loss)     # ONE C call, collectives included
                 if orders is not None:
                     orders.epoch_queued()                      # next epoch's order: drawn and copied underneath this epoch's steps
                 if with_loss:
@@ -274,8 +277,7 @@ class NeuralAdmixture:
                         log.info(f"            Loss in epoch {epoch:3d} on device {dev} is {loss_acc:,.0f}")
         finally:
             torch.set_num_threads(host_threads)
-        if world > 1:
-            eng.finish_ddp()                               # the last step's deferred P piece
+        eng.sync()                                         # what the last step left to "the next step" (engine.Engine.sync)
         # ---- final Q: sequential batches of <=1024, encoder only (:369-383) ----
         Qloc = [[] for _ in self.ks_list]
         for s in range(0, n_local, infer_b):
@@ -320,7 +322,8 @@ class NeuralAdmixture:
         dev = self.device
         infer_b = min(N, 1024)
         b_local = self.batch_size                                  # batch_size // num_gpus (:287)
-        eng = self.engine_snp_cls(M, C, hidden_size, self.ks_list, dev, max(b_local * world, infer_b), rank, world)
+        from .comm import make_comm
+        eng = self.engine_snp_cls(M, C, hidden_size, self.ks_list, dev, max(b_local * world, infer_b), comm=make_comm(dev, rank, world))
         self.engine = eng
         small = init_encoder_weights(self.seed, C, hidden_size, self.ks_list)
         eng.load_params(V.detach().cpu().numpy(), P.detach().cpu().numpy(), small)

@@ -49,11 +49,11 @@ def split_small(L, v):
     return out
 
 
-def make_engine(Gm, p: O.Params, bmax):
+def make_engine(Gm, p: O.Params, bmax, **kw):
     import neural_admixture_amd as na
     dev = _dev()
     M, C = p.V.shape
-    e = na.Engine(M, C, p.W1.shape[0], p.ks, dev, bmax)
+    e = na.Engine(M, C, p.W1.shape[0], p.ks, dev, bmax, **kw)
     P_SM = np.concatenate([P.T for P in p.P], axis=0)
     e.load_params(p.V, P_SM, small_vec(p))
     e.pack_from_host(torch.from_numpy(np.ascontiguousarray(Gm)))
@@ -145,8 +145,7 @@ def test_pass3_propagates_a_nan_in_dz():
     dZ[77, 3] = np.nan
     dZ[150, 6] = np.inf
     e.dZ[: N * 8] = torch.from_numpy(dZ.reshape(-1)).to(e.device)
-    e.invalidate_dz()
-    check(lib.nadm_encode_bwd(ptr(e.xp), e.ld, ptr(idx), N, M, ptr(e.dZ), e._dz_image(N), 8, ptr(e.gbig), 0, None))
+    e.encode_backward(idx, N)                              # (dZ was written from outside: the pass rebuilds its operand image)
     torch.cuda.synchronize()
     g = e.gV().cpu().numpy()
     assert np.isnan(g[:, 3]).all() and not np.isfinite(g[:, 6]).any()
@@ -318,9 +317,10 @@ def test_step_with_mostly_missing_genotypes_and_an_all_missing_sample():
     assert mx(e.Z.cpu().numpy()[: N * 8].reshape(N, 8)[5], 0 * aux["Z"][5]) == 0          # the all-missing sample projects to exactly 0
 
 
-def test_fast_and_generic_mlp_kernels_agree(monkeypatch):
+def test_fast_and_generic_mlp_kernels_agree():
     """nadm_mlp_fwd / nadm_mlp_bwd pick register-resident kernels for Hd <= 2048, C <= 8 and the generic ones otherwise
-    (NADM_MLP_GENERIC forces the latter): same outputs up to the summation order over the hidden dimension."""
+    (the test hook nadm_test_force_generic_mlp forces the latter): same outputs up to the summation order over the hidden dimension."""
+    from neural_admixture_amd._lib import lib
     rng = np.random.default_rng(21)
     for Hd, ks in ((1024, [8]), (1536, [2, 3, 4, 5]), (96, [11])):
         N, M, C = 37, 900, 8
@@ -330,18 +330,17 @@ def test_fast_and_generic_mlp_kernels_agree(monkeypatch):
         p = O.make_params(3, V0, P0, Hd, ks)
         outs = []
         for generic in (False, True):
-            if generic:
-                monkeypatch.setenv("NADM_MLP_GENERIC", "1")
-            else:
-                monkeypatch.delenv("NADM_MLP_GENERIC", raising=False)
-            e = make_engine(Gm, p, N)
-            idx = torch.arange(N, dtype=torch.int32, device=e.device)
-            e.forward(idx, N)
-            e.backward(idx, N, True)
-            torch.cuda.synchronize()
+            lib.nadm_test_force_generic_mlp(1 if generic else 0)
+            try:
+                e = make_engine(Gm, p, N)
+                idx = torch.arange(N, dtype=torch.int32, device=e.device)
+                e.forward(idx, N)
+                e.backward(idx, N, True)
+                torch.cuda.synchronize()
+            finally:
+                lib.nadm_test_force_generic_mlp(0)
             outs.append((e.Q.cpu().numpy().copy(), e.H.cpu().numpy().copy(), e.dZ.cpu().numpy().copy(), e.gsmall.cpu().numpy().copy(),
                          e.read_loss()[1]))
-        monkeypatch.delenv("NADM_MLP_GENERIC", raising=False)
         for a, g in zip(outs[0][:4], outs[1][:4]):
             assert mx(a, g) <= 2e-5 * max(1.0, float(np.abs(g).max()))
         assert abs(outs[0][4] - outs[1][4]) <= 1e-6 * abs(outs[1][4])
@@ -359,7 +358,6 @@ def test_production_step_against_reference_fixture(name):
     Gm = d["G"]
     b = Gm.shape[0]
     e = make_engine(Gm, p, b)
-    assert e.fused_adam and e.defer_small and e.q_images
     idx = torch.arange(b, dtype=torch.int32, device=e.device)
     if "labels" in d.files:
         e.set_labels(d["labels"], ks[0], 100.0)
@@ -432,9 +430,13 @@ def test_pair_product_loss_and_its_exact_fallback(ks):
     assert np.isfinite(out[0]) and abs(out[0] - out[1]) <= 2e-6 * abs(out[1])
 
 
-def test_snp_subrange_launches_give_identical_gradients_and_cover_the_flat_buffer():
-    """The data-parallel step launches passes 2 and 3 on SNP sub-ranges and all-reduces each finished piece of the flat
-    gradient buffer: the pieces must tile gflat exactly once and the gradients must not depend on the split."""
+def test_snp_subrange_launches_give_identical_gradients():
+    """include/nadm.h (nadm_decode_chunk_snps): passes 2 and 3 may be launched on SNP sub-ranges [m0, m1) with m0 a multiple of
+    lcm(chunk, 1024) -- pointers advanced by m0 -- and must write the bits of the whole-range launch: gradients, dQ slab rows, loss
+    slots."""
+    import ctypes as C
+    import math
+    from neural_admixture_amd._lib import lib, check, ptr
     rng = np.random.default_rng(2)
     for M, ks in ((5003, [6]), (9001, [2, 5, 11])):
         N, Hd = 90, 64
@@ -442,29 +444,48 @@ def test_snp_subrange_launches_give_identical_gradients_and_cover_the_flat_buffe
         V0 = (rng.standard_normal((M, 8)) / np.sqrt(M)).astype(np.float32)
         P0 = rng.uniform(0.02, 0.98, size=(sum(ks), M)).astype(np.float32)
         p = O.make_params(1, V0, P0, Hd, ks)
-        res = []
-        for parts in ((1, 1), (2, 2), (3, 4)):
-            e = make_engine(Gm, p, N)
-            idx = torch.arange(N, dtype=torch.int32, device=e.device)
-            pieces = []
-            e.forward(idx, N)
-            e.backward(idx, N, True, on_grad_ready=lambda lo, hi: pieces.append((lo, hi)), p_parts=parts[0], v_parts=parts[1])
+        e = make_engine(Gm, p, N)
+        L = e.lay
+        idx = torch.arange(N, dtype=torch.int32, device=e.device)
+        e.forward(idx, N)
+        e.backward(idx, N, True)
+        torch.cuda.synchronize()
+        whole_g, whole_dq, whole_loss = e.gflat.clone(), e.dqpart.clone(), e.losspart.clone()
+        dq_offs, _ = L.dq_offsets(N)
+        loss_offs = L.loss_offsets()
+        for parts in (2, 3):
+            e.gflat.zero_(); e.dqpart.zero_(); e.losspart.zero_()
+            gbig = e.gflat[L.off_v:]
+            for h, kp in enumerate(L.kp):
+                cs = int(lib.nadm_decode_chunk_snps(kp))
+                align = cs * 1024 // math.gcd(cs, 1024)
+                units = (M + align - 1) // align
+                cuts = sorted({min(M, (units * i // parts) * align) for i in range(parts)} | {M})
+                for m0, m1 in zip(cuts[:-1], cuts[1:]):
+                    c0 = m0 // cs
+                    check(lib.nadm_decode_bce(C.c_void_p(e.xp.data_ptr() + m0 // 4), e.ld, ptr(idx), N, m1 - m0,
+                                              C.c_void_p(e.big.data_ptr() + (L.p_off[h] + m0 * kp) * 4), kp, C.c_void_p(e.Q.data_ptr() + L.qoff[h] * 4), L.SP,
+                                              C.c_void_p(gbig.data_ptr() + (L.p_off[h] + m0 * kp) * 4), C.c_void_p(e.dqpart.data_ptr() + (dq_offs[h] + c0 * N * kp) * 4),
+                                              C.c_void_p(e.losspart.data_ptr() + (loss_offs[h] + c0) * 4), 1, None))
+            units = (M + 1023) // 1024
+            cuts = sorted({min(M, (units * i // parts) * 1024) for i in range(parts)} | {M})
+            dzimg = torch.empty(int(lib.nadm_dz_image_bytes(N)), dtype=torch.uint8, device=e.device)
+            check(lib.nadm_dz_image(ptr(e.dZ), N, L.CP, ptr(dzimg), None))
+            for m0, m1 in zip(cuts[:-1], cuts[1:]):
+                check(lib.nadm_encode_bwd(C.c_void_p(e.xp.data_ptr() + m0 // 4), e.ld, ptr(idx), N, m1 - m0, ptr(e.dZ), ptr(dzimg), L.CP,
+                                          C.c_void_p(gbig.data_ptr() + m0 * L.CP * 4), 0, None))
             torch.cuda.synchronize()
-            cover = np.zeros(e.gflat.numel(), dtype=np.int32)
-            for lo, hi in pieces:
-                cover[lo:hi] += 1
-            assert cover.min() == 1 and cover.max() == 1
-            res.append((e.gflat.cpu().numpy().copy(), e.read_loss()[1]))
-        for g, l in res[1:]:
-            assert np.array_equal(g, res[0][0]) and l == res[0][1]
+            assert torch.equal(e.gflat[L.off_v:], whole_g[L.off_v:])
+            assert torch.equal(e.dqpart, whole_dq) and torch.equal(e.losspart[: L.n_loss], whole_loss[: L.n_loss])
 
 
 def test_snp_sharded_engine_on_gpu():
-    """snp_parallel.SnpShardedEngine with the real kernels: (1) a 1-rank RCCL group must reproduce the plain engine (same
-    kernels, Z and dQ summed by torch instead of inside the MLP kernels -> 1e-6); (2) two slices of one matrix driven stage
-    by stage on one GPU, with the two all-reduces done by hand, must reproduce it as well (slicing of packed columns,
-    of V / P, kernels on a slice whose length is not a multiple of any chunk)."""
-    import torch.distributed as dist
+    """snp_parallel.SnpShardedEngine with the real kernels: (1) on a 1-rank RCCL communicator (nadm_step, NADM_MODE_SNP: the two
+    all-reduces run through RCCL) it must reproduce the plain engine (same kernels, Z and dQ folded by nadm_sum_rows instead of
+    inside the MLP kernels -> 1e-6); (2) two slices of one matrix driven stage by stage on one GPU, with the two all-reduces
+    done by hand, must reproduce it as well (slicing of packed columns, of V / P, kernels on a slice whose length is not a
+    multiple of any chunk)."""
+    from neural_admixture_amd.comm import rccl_comm, torch_comm
     from neural_admixture_amd.snp_parallel import SnpShardedEngine, snp_slices
     from neural_admixture_amd.model import init_encoder_weights
     dev = _dev()
@@ -484,28 +505,25 @@ def test_snp_sharded_engine_on_gpu():
     torch.cuda.synchronize()
     ref_loss = ref.read_loss()[0]
 
-    # (1) world 1, real process group
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = str(29700 + os.getpid() % 200)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    try:
-        e1 = SnpShardedEngine(M, 8, Hd, ks, dev, b, 0, 1)
-        e1.load_params(V0, P0, small)
-        e1.pack_from_host(data)
-        for _ in range(3):
-            e1.train_step(idx, b, 2e-3, True)
-        torch.cuda.synchronize()
-        assert mx(e1.big.cpu().numpy(), ref.big.cpu().numpy()) < 2e-6 and mx(e1.small.cpu().numpy(), ref.small.cpu().numpy()) < 2e-6
-        assert abs(e1.read_loss()[0] - ref_loss) < 1e-6 * abs(ref_loss)
-    finally:
-        dist.destroy_process_group()
+    # (1) world 1, a real RCCL communicator
+    comm = rccl_comm(0, 1)
+    e1 = SnpShardedEngine(M, 8, Hd, ks, dev, b, comm=comm)
+    e1.load_params(V0, P0, small)
+    e1.pack_from_host(data)
+    for _ in range(3):
+        e1.train_step(idx, b, 2e-3, True)
+    torch.cuda.synchronize()
+    assert mx(e1.big.cpu().numpy(), ref.big.cpu().numpy()) < 2e-6 and mx(e1.small.cpu().numpy(), ref.small.cpu().numpy()) < 2e-6
+    assert abs(e1.read_loss()[0] - ref_loss) < 1e-6 * abs(ref_loss)
+    del e1
+    comm.close()
 
     # (2) two slices, stages driven by hand (no process group: _all_reduce is a no-op at world... so sum explicitly)
     sl = snp_slices(M, 2)
     assert sl[0][1] == sl[1][0] and sl[1][1] == M and (sl[0][1] - sl[0][0]) % 4 == 0
     es = []
     for r in range(2):
-        e = SnpShardedEngine(M, 8, Hd, ks, dev, b, r, 2)
+        e = SnpShardedEngine(M, 8, Hd, ks, dev, b, comm=torch_comm(r, 2))      # (its collectives are never called: stages by hand)
         e.load_params(V0, P0, small)
         e.pack_from_host(data)
         es.append(e)
@@ -697,8 +715,7 @@ def test_full_width_against_torch_fp32_on_device(b, M, ks):
     # linearity of pass 3 in dZ: dV(2*dZ) == 2*dV(dZ) exactly (power-of-two scaling is exact in fp32)
     g1 = e.gV().clone()
     e.dZ.mul_(2.0)
-    e.invalidate_dz()
-    check(lib.nadm_encode_bwd(ptr(e.xp), e.ld, ptr(idx), b, M, ptr(e.dZ), e._dz_image(b), e.lay.CP, ptr(e.gbig), 0, None))
+    e.encode_backward(idx, b)                              # (dZ was edited: the pass rebuilds its operand image)
     torch.cuda.synchronize()
     assert torch.equal(e.gV(), 2 * g1)
 
@@ -949,50 +966,77 @@ def test_cli_supervised_run_from_bed_and_pops_file(tmp_path):
 
 
 def test_ddp_step_on_rccl_world1_equals_plain_step():
-    """The RCCL code path (async all-reduce of the flat gradient views, stream waits, 1/world scaling) on a
-    one-rank NCCL group: must be bit-identical to the single-GPU step."""
-    import torch.distributed as dist
+    """The sample-sharded step (nadm_step, NADM_MODE_DP) on a ONE-rank RCCL communicator: reduce-scatter / all-gather through RCCL,
+    message A on the side stream, Adam as launches of its own on the (whole-buffer) slices -- must leave the bits of the single-GPU
+    step with its fused epilogues: parameters, moments, losses."""
+    from neural_admixture_amd.comm import rccl_comm
     dev = _dev()
-    created = False
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 1000))
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        created = True
-    try:
-        Gm = O.synth_genotypes(70, 2300, 4, seed=11)
-        rng = np.random.default_rng(3)
-        p = O.make_params(3, (rng.standard_normal((2300, 8)) / 48).astype(np.float32), rng.uniform(0.1, 0.9, (5, 2300)).astype(np.float32), 64, [5])
-        e1, e2 = make_engine(Gm, p, 70), make_engine(Gm, p, 70)
-        idx = torch.arange(70, dtype=torch.int32, device=dev)
-        for _ in range(3):
-            e1.train_step(idx, 70, 2e-3, True)
-            e2.train_step_ddp(idx, 70, 2e-3, 1, True)
+    comm = rccl_comm(0, 1)
+    Gm = O.synth_genotypes(70, 2300, 4, seed=11)
+    rng = np.random.default_rng(3)
+    p = O.make_params(3, (rng.standard_normal((2300, 8)) / 48).astype(np.float32), rng.uniform(0.1, 0.9, (5, 2300)).astype(np.float32), 64, [5])
+    e1, e2 = make_engine(Gm, p, 70), make_engine(Gm, p, 70, mode="dp", comm=comm)
+    idx = torch.arange(70, dtype=torch.int32, device=dev)
+    for _ in range(3):
+        e1.train_step(idx, 70, 2e-3, True)
+        e2.train_step(idx, 70, 2e-3, True)
+    torch.cuda.synchronize()
+    assert torch.equal(e1.big, e2.big) and torch.equal(e1.small, e2.small)
+    assert e1.read_loss() == e2.read_loss()
+    # several rounds of pass-2 blocks, multi-head (two pass-2 streams, ONE P message), K > 8 (two k slots), K > 16 (generic kernel)
+    for M2, ks2 in ((300_000, [5]), (40_000, [2, 3, 4]), (6_000, [13]), (3_000, [20])):
+        Gw = O.synth_genotypes(12, M2, 3, seed=5)
+        pw = O.make_params(2, (rng.standard_normal((M2, 8)) / 500).astype(np.float32),
+                           rng.uniform(0.1, 0.9, (sum(ks2), M2)).astype(np.float32), 64, ks2)
+        ea, eb = make_engine(Gw, pw, 12), make_engine(Gw, pw, 12, mode="dp", comm=comm)
+        ix = torch.arange(12, dtype=torch.int32, device=dev)
+        for s_ in range(3):
+            ea.train_step(ix, 12, 2e-3, True)
+            eb.train_step(ix, 12, 2e-3, True)
+            if s_ == 1:                                          # a look in between: the accessors settle message A first
+                assert torch.equal(ea.P(0), eb.P(0))
         torch.cuda.synchronize()
-        assert torch.equal(e1.big, e2.big) and torch.equal(e1.small, e2.small)
-        assert e1.read_loss() == e2.read_loss()
-        # several rounds of pass-2 blocks, multi-head (one P message per head), and the deferred updates: P in the prologue of
-        # the next pass 2, V in the prologue of the next pass 1 + the small parameters in its side blocks (or finish_ddp / the
-        # accessors) ... and the K > 8 (two k slots) and K > 16 (generic kernel: the update is a launch in front of it) variants
-        for M2, ks2 in ((300_000, [5]), (40_000, [2, 3, 4]), (6_000, [13]), (3_000, [20])):
-            Gw = O.synth_genotypes(12, M2, 3, seed=5)
-            pw = O.make_params(2, (rng.standard_normal((M2, 8)) / 500).astype(np.float32),
-                               rng.uniform(0.1, 0.9, (sum(ks2), M2)).astype(np.float32), 64, ks2)
-            ea, eb, ec = make_engine(Gw, pw, 12), make_engine(Gw, pw, 12), make_engine(Gw, pw, 12)
-            ix = torch.arange(12, dtype=torch.int32, device=dev)
-            for _ in range(3):
-                ea.train_step(ix, 12, 2e-3, True)
-                eb.train_step_ddp(ix, 12, 2e-3, 1, True)
-                ec.train_step_ddp(ix, 12, 2e-3, 1, True, defer_tail=True)
-                assert ec._pending_ddp is not None and len(ec._pending_ddp[0]) == len(ks2)   # one P message per head, left to the next pass 2 / finish_ddp
-                assert ec._pending_vs is not None                                           # V + small parameters: left to the next pass 1
-            ec.finish_ddp()
-            torch.cuda.synchronize()
-            assert torch.equal(ea.big, eb.big) and torch.equal(ea.big, ec.big) and torch.equal(ea.small, ec.small)
-            assert torch.equal(ea.mbig, ec.mbig) and torch.equal(ea.vbig, ec.vbig)
-    finally:
-        if created:
-            dist.destroy_process_group()
+        assert torch.equal(ea.big, eb.big) and torch.equal(ea.small, eb.small)
+        assert torch.equal(ea.mbig, eb.mbig) and torch.equal(ea.vbig, eb.vbig) and torch.equal(ea.msmall, eb.msmall)
+        assert ea.read_loss() == eb.read_loss()
+        del eb
+    del e2
+    comm.close()
+
+
+def test_emulated_world_updates_only_rank_0s_slices():
+    """nadm_comm_emulated(W) (bench.py --emulate-world): rank 0 of W ranks, no-op collectives.  After a step the parameters inside
+    rank 0's slice of either message equal the 1-rank step's with grad_scale 1/W (Adam is nearly scale-invariant: compare against
+    an engine stepping with the same scale), every other parameter is untouched, and the moments are slice-sized."""
+    from neural_admixture_amd.comm import emulated_comm
+    dev = _dev()
+    W = 4
+    Gm = O.synth_genotypes(40, 3001, 4, seed=2)
+    rng = np.random.default_rng(4)
+    p = O.make_params(3, (rng.standard_normal((3001, 8)) / 55).astype(np.float32), rng.uniform(0.1, 0.9, (7, 3001)).astype(np.float32), 64, [7])
+    comm = emulated_comm(W)
+    e = make_engine(Gm, p, 40, mode="dp", comm=comm)
+    ref = make_engine(Gm, p, 40)
+    L = e.lay
+    assert e.mflat.numel() == L.slice_b + L.slice_a and L.n_flat == W * (L.slice_b + L.slice_a)
+    before = e.pflat.clone()
+    idx = torch.arange(40, dtype=torch.int32, device=dev)
+    e.train_step(idx, 40, 2e-3, True)
+    e.sync()
+    ref.forward(idx, 40); ref.backward(idx, 40, True); ref.adam(2e-3, 1.0 / W)
+    torch.cuda.synchronize()
+    assert e.read_loss() == ref.read_loss()
+    after = e.pflat
+    # the reference engine has the world-1 layout (no gaps): compare region by region
+    own_b = slice(0, L.slice_b)
+    rb = ref.pflat[: L.slice_b]                                     # [small | pad | first rows of V]: same offsets in both layouts
+    assert torch.equal(after[own_b], rb)
+    assert torch.equal(after[L.slice_b: L.msg_a_off], before[L.slice_b: L.msg_a_off])      # the other ranks' slices of message B
+    pa = ref.pflat[ref.lay.msg_a_off: ref.lay.msg_a_off + L.slice_a]
+    assert torch.equal(after[L.msg_a_off: L.msg_a_off + L.slice_a], pa)
+    assert torch.equal(after[L.msg_a_off + L.slice_a:], before[L.msg_a_off + L.slice_a:])
+    del e
+    comm.close()
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -1206,7 +1250,6 @@ def test_pass2_gather_byproduct_and_pass3_on_the_compact_copy(K):
     rng = np.random.default_rng(6)
     p = O.make_params(3, (rng.standard_normal((M, 8)) / 48).astype(np.float32), rng.uniform(0.05, 0.95, (K, M)).astype(np.float32), 64, [K])
     e = make_engine(Gm, p, b)
-    e.gather_batch = False
     idx = torch.from_numpy(rng.permutation(N)[:b].astype(np.int32)).to(dev)
     e.forward(idx, b)
     L = e.lay
@@ -1247,13 +1290,17 @@ def test_pass2_gather_byproduct_and_pass3_on_the_compact_copy(K):
         dv.append(o)
     torch.cuda.synchronize()
     assert torch.equal(dv[0], dv[1])
-    # whole steps: engine with the by-product on (default on a GPU) vs off, two steps, bit-identical state
+    # whole steps: the production step (pass 3 on the copy, fused epilogues) vs the plain phases with pass 3 gathering from the resident
+    # matrix (K <= 16: the copy is dropped by hand), two steps, bit-identical state
     e1, e2 = make_engine(Gm, p, b), make_engine(Gm, p, b)
-    assert e1.gather_batch is None and e1._gather()              # on a GPU the copy is on by default
-    e1.gather_batch, e2.gather_batch = True, False
     for _ in range(2):
         e1.train_step(idx, b, 2e-3, True)
-        e2.train_step(idx, b, 2e-3, True)
+        e2.forward(idx, b)
+        n_loss = e2.decode_all(idx, b, True)
+        e2._xg_key = None
+        e2.mlp_backward(b, n_loss)
+        e2.encode_backward(idx, b)
+        e2.adam(2e-3)
     torch.cuda.synchronize()
     assert torch.equal(e1.big, e2.big) and torch.equal(e1.small, e2.small) and e1.read_loss() == e2.read_loss()
 
@@ -1270,12 +1317,10 @@ def test_adam_in_the_epilogues_of_passes_2_and_3_equals_the_separate_launches(ks
     rng = np.random.default_rng(9)
     p = O.make_params(3, (rng.standard_normal((M, C)) / 48).astype(np.float32), rng.uniform(0.0, 1.0, (sum(ks), M)).astype(np.float32), 64, ks)
     e1, e2 = make_engine(Gm, p, b), make_engine(Gm, p, b)
-    assert e1.fused_adam
-    e2.fused_adam = False
     for s in range(4):
         idx = torch.from_numpy(rng.permutation(N)[:b].astype(np.int32)).to(dev)
         e1.train_step(idx, b, 2e-3, s % 2 == 0)
-        e2.train_step(idx, b, 2e-3, s % 2 == 0)
+        e2.forward(idx, b); e2.backward(idx, b, s % 2 == 0); e2.adam(2e-3)      # passes + nadm_adam
     torch.cuda.synchronize()
     assert e1.step_count == e2.step_count == 4
     assert torch.equal(e1.big, e2.big) and torch.equal(e1.mbig, e2.mbig) and torch.equal(e1.vbig, e2.vbig)
@@ -1296,7 +1341,6 @@ def test_full_size_properties_of_the_step(M, K):
     dev = _dev()
     b = 800
     e = na.Engine(M, 8, 1024, [K], dev, b)
-    e.fused_adam = False                                  # gradients are inspected: keep them in gbig
     g = torch.Generator(device="cpu").manual_seed(3)
     Qt = torch.distributions.Dirichlet(torch.full((K,), 0.3)).sample((b,)).float().to(dev)
     Fq = (0.5 * torch.rand(K, M, generator=g)).clamp(0.005, 0.5).to(dev)
@@ -1401,22 +1445,24 @@ def test_q_operand_images_from_the_mlp_forward_give_the_same_pass2(ks):
     Gm = O.synth_genotypes(N, M, 4, seed=41)
     rng = np.random.default_rng(12)
     p = O.make_params(3, (rng.standard_normal((M, 8)) / 48).astype(np.float32), rng.uniform(0.02, 0.98, (sum(ks), M)).astype(np.float32), 64, ks)
+    from unfused_step import unfused_step
     e1, e2 = make_engine(Gm, p, 100), make_engine(Gm, p, 100)
-    assert e1.q_images and e1.qimg is not None
-    e2.q_images = False
+    assert e1.qimg is not None
     for b in (100, 37, 70):
         idx = torch.from_numpy(rng.permutation(N)[:b].astype(np.int32)).to(dev)
         for e in (e1, e2):
             e.forward(idx, b)
+            if e is e2:
+                e.Q = e.Q                                      # "Q written from outside": drops the images, pass 2 splits Q itself
+            assert e._qimg_b == (b if e is e1 else -1)
             e.backward(idx, b, True)
         torch.cuda.synchronize()
-        assert e1._qimg_b == b and e2._qimg_b == -1
         assert torch.equal(e1.Q, e2.Q)
         assert torch.equal(e1.gbig, e2.gbig), b
         assert torch.equal(e1.gsmall, e2.gsmall), b
         assert e1.read_loss() == e2.read_loss()
         e1.train_step(idx, b, 2e-3, False)
-        e2.train_step(idx, b, 2e-3, False)
+        unfused_step(e2, idx, b, 2e-3, False)                  # (nadm_mlp_fwd without images)
     torch.cuda.synchronize()
     assert torch.equal(e1.big, e2.big) and torch.equal(e1.small, e2.small)
 
@@ -1424,29 +1470,27 @@ def test_q_operand_images_from_the_mlp_forward_give_the_same_pass2(ks):
 @pytest.mark.gpu
 @pytest.mark.parametrize("ks,Hd,M,b", [([8], 1024, 60_000, 800), ([5], 64, 2301, 37), ([2, 3, 4], 96, 2301, 37)])
 def test_small_parameter_update_riding_in_the_next_pass1_equals_the_immediate_one(ks, Hd, M, b):
-    """Engine.defer_small: the single-GPU step leaves the sum of the weight-gradient partials + Adam on the small parameters to
-    side blocks of the NEXT step's pass 1 (nadm_encode_fwd_small).  Parameters, moments, gradients and losses stay bit-identical
-    to the immediate nadm_small_grads launch; reading eng.small (or the moments / gradient) between two steps applies the owed
-    update first; an encoder-only call (infer_q), a non-fused backward and load_params in between are all served correctly."""
+    """nadm_step leaves the sum of the weight-gradient partials + Adam on the small parameters to side blocks of the NEXT step's
+    pass 1 (nadm_encode_fwd_small).  Parameters, moments, gradients and losses stay bit-identical to the immediate
+    nadm_small_grads launch (tests/unfused_step.py); reading eng.small (or the moments / gradient) between two steps applies the
+    owed update first; an encoder-only call (infer_q), a plain forward / backward pair and load_params in between are all served."""
+    from unfused_step import unfused_step
     dev = _dev()
     N = max(b + 20, 90)
     Gm = O.synth_genotypes(N, M, 4, seed=78)
     rng = np.random.default_rng(6)
     p = O.make_params(3, (rng.standard_normal((M, 8)) / 48).astype(np.float32), rng.uniform(0.05, 0.95, (sum(ks), M)).astype(np.float32), Hd, ks)
     e1, e2 = make_engine(Gm, p, b), make_engine(Gm, p, b)
-    assert e1.defer_small and e1.fused_adam
-    e2.defer_small = False
     for s in range(12):
         idx = torch.from_numpy(rng.permutation(N)[:b].astype(np.int32)).to(dev)
         e1.train_step(idx, b, 2e-3, s % 3 == 0)
-        e2.train_step(idx, b, 2e-3, s % 3 == 0)
-        assert e1._pending_small is not None and e2._pending_small is None
+        unfused_step(e2, idx, b, 2e-3, s % 3 == 0)
         if s == 4:                                            # a look in between: applies the update, the next pass 1 then has none to do
-            assert torch.equal(e1.small, e2.small) and e1._pending_small is None
+            assert torch.equal(e1.small, e2.small)
             assert torch.equal(e1.msmall, e2.msmall) and torch.equal(e1.gsmall, e2.gsmall)
         if s == 7:                                            # encoder-only pass in between (final-Q style): consumes the update
             q1, q2 = e1.infer_q(idx, b), e2.infer_q(idx, b)
-            assert e1._pending_small is None and all(torch.equal(a, c) for a, c in zip(q1, q2))
+            assert all(torch.equal(a, c) for a, c in zip(q1, q2))
         if s == 9:                                            # a plain forward / backward pair in between
             for e in (e1, e2):
                 e.forward(idx, b)
@@ -1459,11 +1503,9 @@ def test_small_parameter_update_riding_in_the_next_pass1_equals_the_immediate_on
     assert torch.equal(e1.big, e2.big) and torch.equal(e1.mbig, e2.mbig)
     # load_params with an update still owed: the update must not leak into the new parameters
     e1.train_step(idx, b, 2e-3, False)
-    assert e1._pending_small is not None
     for e in (e1, e2):
         e.load_params(p.V, np.concatenate([P.T for P in p.P], axis=0), small_vec(p))
-    assert e1._pending_small is None and torch.equal(e1.small, e2.small) and float(e1.msmall.abs().max()) == 0.0
-
+    assert torch.equal(e1.small, e2.small) and float(e1.msmall.abs().max()) == 0.0 and e1.step_count == 0
 
 
 @pytest.mark.gpu

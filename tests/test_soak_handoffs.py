@@ -62,7 +62,7 @@ def test_5000_production_steps_equal_the_unfused_sequence_bit_for_bit():
         unfused_step(ref, idx, b, lr, with_loss)
         if s % 50 == 49:
             # the image the MLP backward's last blocks left behind == the image a launch of its own builds from the same dZ
-            check(lib.nadm_dz_image(ptr(prod.dZ), b, prod.lay.CP, ptr(alone), None), "dz_image")
+            check(lib.nadm_dz_image(ptr(prod._dZ), b, prod.lay.CP, ptr(alone), None), "dz_image")
             torch.cuda.synchronize()
             n_img = int(lib.nadm_dz_image_bytes(b))
             # groups of 32 samples past the batch keep whatever an earlier, taller batch left there (pass 3 never reads them): compare
@@ -73,7 +73,7 @@ def test_5000_production_steps_equal_the_unfused_sequence_bit_for_bit():
                 assert torch.equal(prod._dzimg[:nb], alone[:nb]), f"step {s}: fused dZ image differs from nadm_dz_image"
             assert n_img <= prod._dzimg.numel()
             assert int(prod._dzcnt.abs().sum().item()) == 0, f"step {s}: group counters did not return to zero"
-            assert torch.equal(prod.dZ[: b * prod.lay.CP], ref.dZ[: b * ref.lay.CP]), f"step {s}: dZ differs"
+            assert torch.equal(prod._dZ[: b * prod.lay.CP], ref._dZ[: b * ref.lay.CP]), f"step {s}: dZ differs"
             checked += 1
     torch.cuda.synchronize()
     assert checked == steps // 50
@@ -101,32 +101,31 @@ def test_2000_multihead_production_steps_equal_the_unfused_sequence():
     assert _same_state(prod, ref)
 
 
-def test_1000_data_parallel_steps_on_a_one_rank_rccl_group_equal_the_plain_step():
+def test_1000_data_parallel_steps_on_a_one_rank_rccl_communicator_equal_the_plain_step():
+    """nadm_step in NADM_MODE_DP on a 1-rank RCCL communicator: message A on the side stream (event hand-offs in both directions every
+    step), message B on the compute stream, Adam as launches of its own -- 1000 steps with changing batch sizes must leave the bits of
+    the single-GPU step."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    import torch.distributed as dist
+    import neural_admixture_amd as na
+    from neural_admixture_amd.comm import rccl_comm
     dev = torch.device("cuda:0")
-    created = False
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 1000))
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        created = True
-    try:
-        M, N, steps = 60_000, 4000, 1000
-        ddp, plain = _engines(M, [8], 1024, N, seed=29)
-        gen = torch.Generator().manual_seed(3)
-        sizes = (800, 790, 37, 800)
-        for s in range(steps):
-            b = sizes[s % 4]
-            idx = torch.randint(0, N, (b,), generator=gen, dtype=torch.int32).to(dev)
-            ddp.train_step_ddp(idx, b, 2e-3, 1, s % 3 == 0, defer_tail=True)
-            plain.train_step(idx, b, 2e-3, s % 3 == 0)
-        ddp.finish_ddp()
-        torch.cuda.synchronize()
-        assert int(ddp._dzcnt.abs().sum().item()) == 0
-        assert ddp.read_loss() == plain.read_loss()
-        assert _same_state(ddp, plain)
-    finally:
-        if created:
-            dist.destroy_process_group()
+    comm = rccl_comm(0, 1)
+    M, N, steps = 60_000, 4000, 1000
+    plain, tmp = _engines(M, [8], 1024, N, seed=29)
+    ddp = na.Engine(M, 8, 1024, [8], dev, 800, mode="dp", comm=comm)
+    ddp.pflat.copy_(tmp.pflat)
+    ddp.set_packed(tmp.xp)
+    gen = torch.Generator().manual_seed(3)
+    sizes = (800, 790, 37, 800)
+    for s in range(steps):
+        b = sizes[s % 4]
+        idx = torch.randint(0, N, (b,), generator=gen, dtype=torch.int32).to(dev)
+        ddp.train_step(idx, b, 2e-3, s % 3 == 0)
+        plain.train_step(idx, b, 2e-3, s % 3 == 0)
+    torch.cuda.synchronize()
+    assert int(ddp._dzcnt.abs().sum().item()) == 0
+    assert ddp.read_loss() == plain.read_loss()
+    assert _same_state(ddp, plain)
+    del ddp
+    comm.close()

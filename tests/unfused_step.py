@@ -15,10 +15,11 @@ NADM_X_CLEAN = 1
 
 
 def unfused_step(e, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True) -> None:
-    L, fsz = e.lay, 4
+    fsz = 4
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    e.flush_small()
-    big, mbig, vbig, gbig, small = e._big, e._mbig, e._vbig, e.gbig, e._small
+    L = e.lay
+    big, mbig, vbig, gbig, small = e.big, e.mbig, e.vbig, e.gbig, e.small      # (the accessors settle what the last step still owes)
+    msmall, vsmall, gsmall = e.msmall, e.vsmall, e.gsmall
     check(lib.nadm_encode_fwd(ptr(e.xp), e.ld, ptr(idx), b, L.M, ptr(big), L.CP, ptr(e.zpart), st), "encode_fwd")
     check(lib.nadm_mlp_fwd(C.byref(L.heads), ptr(small), ptr(e.zpart), L.enc_chunks, b, ptr(e.Z), ptr(e.rinv), ptr(e.Zn), ptr(e.H),
                            ptr(e._Q), st), "mlp_fwd")
@@ -26,7 +27,7 @@ def unfused_step(e, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True
     dq_offs, _ = L.dq_offsets(b)
     loss_offs = L.loss_offsets()
     tiled = L.CP <= 8
-    xg = e._xg_buf() if tiled else None
+    xg = e._xg if tiled else None
     for h, kp in enumerate(L.kp):
         ad = AdamArgs(mbig.data_ptr() + L.p_off[h] * fsz, vbig.data_ptr() + L.p_off[h] * fsz, lr, e.step_count, 1.0, 0)
         check(lib.nadm_decode_bce_step(ptr(e.xp), e.ld, ptr(idx), b, L.M, C.c_void_p(big.data_ptr() + L.p_off[h] * fsz), kp,
@@ -40,20 +41,20 @@ def unfused_step(e, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True
                                      C.c_void_p(e.losspart.data_ptr() + L.n_loss * fsz), st), "supervised_ce")
         n_loss += 1
     check(lib.nadm_mlp_bwd(C.byref(L.heads), ptr(small), ptr(e.dqpart), L.M, b, ptr(e.Z), ptr(e.rinv), ptr(e.Zn), ptr(e.H), ptr(e._Q),
-                           ptr(e.dL), ptr(e.dHpre), ptr(e.dgp), ptr(e.small_part), ptr(e.dZ), None, ptr(e.losspart),
+                           ptr(e.dL), ptr(e.dHpre), ptr(e.dgp), ptr(e.small_part), ptr(e._dZ), None, ptr(e.losspart),
                            n_loss if with_loss else 0, ptr(e.loss_acc), st), "mlp_bwd")
     dzimg = None
     if tiled:
-        check(lib.nadm_dz_image(ptr(e.dZ), b, L.CP, ptr(e._dzimg), st), "dz_image")
+        check(lib.nadm_dz_image(ptr(e._dZ), b, L.CP, ptr(e._dzimg), st), "dz_image")
         dzimg = ptr(e._dzimg)
     mw = MlpWeights(C.pointer(L.heads), e.Zn.data_ptr(), e.H.data_ptr(), e.dL.data_ptr(), e.dHpre.data_ptr(), e.dgp.data_ptr(),
                     e.small_part.data_ptr())
     av = AdamArgs(mbig.data_ptr(), vbig.data_ptr(), lr, e.step_count, 1.0, 0)
     src, rows, flags = (xg, e._iota, NADM_X_CLEAN) if tiled else (e.xp, idx, 0)
-    check(lib.nadm_encode_bwd_step(ptr(src), e.ld, ptr(rows), b, L.M, ptr(e.dZ), dzimg, L.CP, ptr(big), ptr(gbig), C.byref(av), C.byref(mw),
+    check(lib.nadm_encode_bwd_step(ptr(src), e.ld, ptr(rows), b, L.M, ptr(e._dZ), dzimg, L.CP, ptr(big), ptr(gbig), C.byref(av), C.byref(mw),
                                    flags, st), "encode_bwd_step")
-    sa = AdamArgs(e._msmall.data_ptr(), e._vsmall.data_ptr(), lr, e.step_count, 1.0, 0)
-    check(lib.nadm_small_grads(ptr(e.small_part), int(lib.nadm_sample_splits(b)), L.n_small, ptr(e._gsmall), ptr(small), C.byref(sa), st),
+    sa = AdamArgs(msmall.data_ptr(), vsmall.data_ptr(), lr, e.step_count, 1.0, 0)
+    check(lib.nadm_small_grads(ptr(e.small_part), int(lib.nadm_sample_splits(b)), L.n_small, ptr(gsmall), ptr(small), C.byref(sa), st),
           "small_grads")
     e.p_unit = True
     e._qimg_b = e._dzimg_b = -1

@@ -19,7 +19,6 @@ for spread in (0.0, 2.0, 6.0):
     e.pack_from_host(torch.from_numpy(np.ascontiguousarray(Gm)))
     dZ = (rng.standard_normal((N, Cc)) * np.exp2(rng.uniform(-spread, spread, size=(N, 1)))).astype(np.float32)
     e.dZ[: N * Cc] = torch.from_numpy(dZ.reshape(-1)).to(dev)
-    e.invalidate_dz()
     idx = torch.arange(N, dtype=torch.int32, device=dev)
     check(lib.nadm_encode_bwd(ptr(e.xp), e.ld, ptr(idx), N, M, ptr(e.dZ), e._dz_image(N), Cc, ptr(e.gbig), 0, None))
     torch.cuda.synchronize()
