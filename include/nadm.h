@@ -71,8 +71,7 @@ int64_t     nadm_encode_chunks(int64_t M);      /* zpart  is [chunks, b, CP]  */
 int64_t     nadm_decode_chunks(int64_t M, int kp); /* per head: dqpart slab [chunks, b, kp], losspart [chunks] */
 /* SNPs per chunk of the decoder pass.  nadm_decode_bce / nadm_encode_bwd may be launched on an SNP sub-range
  * [m0, m1) with m0 a multiple of lcm(this, 1024): pass xp + m0/4, P/dP (V/dV) + m0*kp, M = m1 - m0 and the slab /
- * loss pointers advanced by m0/chunk_snps rows -- the data-parallel step does so to start the all-reduce of the first
- * half of a gradient while the second half is still being computed. */
+ * loss pointers advanced by m0/chunk_snps rows (a caller that wants a piece of a gradient early). */
 int32_t     nadm_decode_chunk_snps(int kp);
 int32_t     nadm_sample_splits(int b);          /* small_part is [splits, n_small] */
 
@@ -161,7 +160,7 @@ int nadm_decode_bce_gather(const uint8_t* xp, int64_t ld, const int32_t* idx, in
  * the step reads that row again; likewise for V rows and pass 3.  The *_step entry points take the Adam state of those
  * rows and apply optimizer.step() + restrict_P (neural_admixture.py:187-204,411-412) to them in the kernel's epilogue --
  * the same element update as nadm_adam, bit for bit -- instead of writing the gradient out for a separate launch (which
- * the data-parallel step still does: its gradients have to be all-reduced first).  adam == NULL: exactly
+ * the sample-sharded step still does: its gradients have to be summed over ranks first, nadm_step).  adam == NULL: exactly
  * nadm_decode_bce(_gather) / nadm_encode_bwd.  With adam, m and v point at the Adam moments of the SAME rows as P / V
  * (sub-range launches advance them like P / V), the gradient buffer is left untouched by the matrix-core kernels
  * (K <= 16, C <= 8; the other variants write it and run the update as a second kernel), xg may be NULL. */
@@ -171,11 +170,7 @@ typedef struct {
     float   lr;
     int32_t step;         /* 1-based step count                       */
     float   grad_scale;   /* gradients are multiplied by this first   */
-    int32_t when;         /* 0: in the kernel's epilogue, from the gradient the launch has just completed (single-GPU step).
-                           * 1 (nadm_decode_bce_step only): in its PROLOGUE, from the gradient that already lies in dP -- the
-                           * data-parallel step: dP of the previous step was all-reduced in between (neural_admixture.py:315-319),
-                           * `step` is that step's count, and the launch then overwrites dP with this step's gradient.  Every P row
-                           * belongs to one block of the launch, so the update needs neither a launch of its own nor a second read of P */
+    int32_t reserved;     /* 0 */
 } nadm_adam_t;
 int nadm_decode_bce_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                          float* P, int32_t kp, const float* Q, int32_t SP,
@@ -207,18 +202,6 @@ int nadm_small_grads(const float* small_part, int32_t splits, int32_t n_small, f
 int nadm_encode_fwd_small(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                           const float* V, int32_t CP, float* zpart, const float* small_part, int32_t splits, int32_t n_small,
                           float* grad_small, float* small, const nadm_adam_t* adam, void* stream);
-
-/* Data-parallel step: nadm_encode_fwd of the NEXT step with the update of V owed by this one in its prologue -- the all-reduced
- * gradient lies in dV (neural_admixture.py:315-319), adam_v->when must be 1 and ->step that step's count; every wave applies
- * optimizer.step() (neural_admixture.py:187-204,411; no clamp: V is unconstrained, :179-185) to the V rows it is about to use, so
- * the 7 x 4 x M x C bytes of optimizer traffic of V need no launch of their own and V is read once.  The launch then uses ONE
- * batch split (a V row belongs to exactly one block; b <= 832, CP <= 8 -- otherwise the update runs as a kernel of its own in
- * front).  small_part != NULL: the small-parameter side blocks of nadm_encode_fwd_small ride along (the data-parallel step hands
- * the all-reduced flat gradient as ONE split: small_part = grad_small, splits = 1). */
-int nadm_encode_fwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                         float* V, int32_t CP, float* zpart, const float* dV, const nadm_adam_t* adam_v,
-                         const float* small_part, int32_t splits, int32_t n_small, float* grad_small, float* small,
-                         const nadm_adam_t* adam_small, void* stream);
 
 /* ---- a11: MLP backward (softmax, Linear, ReLU, RMSNorm) ---------------------------------- */
 /* Reduces dqpart (the heads' slabs laid back to back in head order, head h holding
@@ -281,13 +264,6 @@ int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b
  * >= clamp_from are clamped to [0,1] after the update (pass n for "no clamp"). */
 int nadm_adam(float* param, const float* grad, float* m, float* v, int64_t n, int64_t clamp_from,
               float lr, int32_t step, float grad_scale, void* stream);
-
-/* Two parameter segments in ONE launch (the data-parallel step: V and the small parameters become final together, behind the
- * [small | dV] all-reduce; as two launches the second one is pure launch latency).  Same element update as nadm_adam; segment
- * 0 is clamped to [0,1] from element clamp_from0 on, segment 1 never. */
-int nadm_adam2(float* param0, const float* grad0, float* m0, float* v0, int64_t n0, int64_t clamp_from0,
-               float* param1, const float* grad1, float* m1, float* v1, int64_t n1,
-               float lr, int32_t step, float grad_scale, void* stream);
 
 /* ======================================================================================================================
  * The training step as ONE call  (replaces NeuralAdmixture._run_step + the DDP hooks + optimizer.step + restrict_P,

@@ -27,7 +27,7 @@ class Heads(C.Structure):
 class AdamArgs(C.Structure):
     """nadm_adam_t (include/nadm.h)."""
     _fields_ = [("m", C.c_void_p), ("v", C.c_void_p), ("lr", C.c_float), ("step", C.c_int32), ("grad_scale", C.c_float),
-                ("when", C.c_int32)]
+                ("reserved", C.c_int32)]
 
 
 class FlatLayout(C.Structure):
@@ -101,7 +101,6 @@ def _load():
         "nadm_mlp_fwd_images": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, i64, vp]),
         "nadm_q_image_bytes": (C.c_int64, [i32]),
         "nadm_encode_fwd_small": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp]),
-        "nadm_encode_fwd_step": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
         "nadm_encode_bwd_step": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, i32, vp, vp, vp, vp, i32, vp]),
         "nadm_small_grads": (C.c_int, [vp, i32, i32, vp, vp, vp, vp]),
         "nadm_mlp_bwd": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]),
@@ -115,7 +114,6 @@ def _load():
         "nadm_dz_image": (C.c_int, [vp, i32, i32, vp, vp]),
         "nadm_vcf_parse_gt": (C.c_int, [C.c_char_p, i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]),
         "nadm_adam": (C.c_int, [vp, vp, vp, vp, i64, i64, f32, i32, f32, vp]),
-        "nadm_adam2": (C.c_int, [vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, i64, f32, i32, f32, vp]),
         "nadm_synth_packed": (C.c_int, [vp, i64, i64, i64, i64, vp, vp, i32, f32, u64, vp]),
         "nadm_flat_layout": (C.c_int, [HP, i64, i32, C.POINTER(FlatLayout)]),
         "nadm_comm_rccl_unique_id": (C.c_int, [C.c_char_p, vp]),

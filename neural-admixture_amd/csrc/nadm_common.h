@@ -65,9 +65,6 @@ struct AdamFused {            // m == nullptr: no fused update
     float* m;
     float* v;
     float step_size, inv_bc2, grad_scale;
-    int pre;                  // pass 2 only.  0: update in the epilogue, from the gradient the launch has just completed.  1: update in the
-                              // PROLOGUE, from the gradient already lying in dP (the previous step's, all-reduced in between), before
-                              // the rows are used; dP is then overwritten with this step's gradient as if there were no update
 };
 __device__ __forceinline__ float adam_element(float p, float g, float& m, float& v, float step_size, float inv_bc2,
                                               float grad_scale, bool clamp01) {

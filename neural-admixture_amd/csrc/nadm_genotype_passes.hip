@@ -169,8 +169,7 @@ template <int CP>
 __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
                                                               const int32_t* __restrict__ idx, int b, int64_t M,
                                                               const float* V, float* __restrict__ zpart, int tiles_per_block,
-                                                              uint32_t missing_bf16, int n_chunks, int n_splits, SmallSide ss,
-                                                              float* Vrw, const float* __restrict__ dV, AdamFused adv) {
+                                                              uint32_t missing_bf16, int n_chunks, int n_splits, SmallSide ss) {
     static_assert(CP <= 8, "two MFMA column groups hold hi|mid and lo|0");
     // 1-D grid: block = chunk + n_chunks * batch split (the dispatch order a 2-D grid would have), side blocks LAST: they run in
     // the slots the partly filled last round leaves empty instead of pushing main blocks of the first round back
@@ -226,45 +225,10 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
         // rows past M are read from row M - 1 (clamped, unconditional) and zeroed at the LDS store; the clamp as ONE 32-bit minimum per
         // load (a 64-bit "m < M ? m : M - 1" is a compare + two v_cndmask with the mask in VCC: 23 cycles each, nadm_common.h)
         const int row_lim = (int)(M - 1 - slice0 < (int64_t)(EM_SLICE - 1) ? M - 1 - slice0 : (int64_t)(EM_SLICE - 1));
-        if (adv.m != nullptr) {
-            // Data-parallel step: the previous step's Adam update of V, from the all-reduced gradient lying in dV, applied to the
-            // wave's rows on their way in (like pass 2 does for P, AdamFused.pre).  The launch then has ONE batch split, so a V row
-            // belongs to exactly one wave: no launch of its own for 112 MB of optimizer traffic (adam2_kernel: 23 us), and V is
-            // read once.  Same element function as nadm_adam, no clamp (V is unconstrained, neural_admixture.py:179-185).
 #pragma unroll
-            for (int j0 = 0; j0 < CP; j0 += 4) {
-                float4 v4[4], g4[4], m4[4], s4[4];
-                int64_t off[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int e = 4 * (lane + 64 * (j0 + u));
-                    off[u] = (slice0 + min(e / CP, row_lim)) * CP + e % CP;
-                    v4[u] = *reinterpret_cast<const float4*>(Vrw + off[u]);
-                    g4[u] = *reinterpret_cast<const float4*>(dV + off[u]);
-                    m4[u] = *reinterpret_cast<const float4*>(adv.m + off[u]);
-                    s4[u] = *reinterpret_cast<const float4*>(adv.v + off[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float pp[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w}, gg[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
-                    float mm[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w}, vv[4] = {s4[u].x, s4[u].y, s4[u].z, s4[u].w};
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) pp[q4] = adam_element(pp[q4], gg[q4], mm[q4], vv[q4], adv.step_size, adv.inv_bc2, adv.grad_scale, false);
-                    vst[j0 + u] = make_float4(pp[0], pp[1], pp[2], pp[3]);
-                    const int e = 4 * (lane + 64 * (j0 + u));
-                    if (slice0 + e / CP < M) {                // (a clamped row would be updated twice)
-                        *reinterpret_cast<float4*>(Vrw + off[u]) = vst[j0 + u];
-                        *reinterpret_cast<float4*>(adv.m + off[u]) = make_float4(mm[0], mm[1], mm[2], mm[3]);
-                        *reinterpret_cast<float4*>(adv.v + off[u]) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < CP; ++j) {                    // unconditional, clamped; masked at the LDS store
-                const int e = 4 * (lane + 64 * j);
-                vst[j] = *reinterpret_cast<const float4*>(V + (slice0 + min(e / CP, row_lim)) * CP + e % CP);
-            }
+        for (int j = 0; j < CP; ++j) {                        // unconditional, clamped; masked at the LDS store
+            const int e = 4 * (lane + 64 * j);
+            vst[j] = *reinterpret_cast<const float4*>(V + (slice0 + min(e / CP, row_lim)) * CP + e % CP);
         }
 #pragma unroll
         for (int j = 0; j < CP; ++j) {
@@ -847,9 +811,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
     // ---- the block's P rows [chunk SNPs x KP] -> LDS, once, with full 16 B / lane lines (the transposition buffers are free until
     // the first tile); the operands below are built from that image.  Read element by element from global memory -- 48 dword
     // loads per thread whose lanes each touch another sector -- the prologue took 16-27 k cycles of a block's ~215 k (s_memtime
-    // probe), most of it memory latency.  Data-parallel step (ad.pre): the previous step's Adam + clamp is applied on the way,
-    // from the all-reduced gradient lying in dP (a P row belongs to exactly one block of the launch, which overwrites the same
-    // dP rows at its end: the update needs neither a launch of its own nor a second read of P).
+    // probe), most of it memory latency.
     static_assert(sizeof(s_t) >= (size_t)MF_WAVES * 16 * NTW * KP * sizeof(float), "the P image fits the transposition buffers");
     float* const s_p = reinterpret_cast<float*>(&s_t[0][0][0][0]);
     {
@@ -860,8 +822,6 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
             float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < M) {
                 const int64_t o = m * KP + 4 * (e % ROW4P);
-                if (ad.m != nullptr && ad.pre)
-                    adam_float4(P + o, *reinterpret_cast<const float4*>(dP + o), ad.m + o, ad.v + o, ad.step_size, ad.inv_bc2, ad.grad_scale, true);
                 p4 = *reinterpret_cast<const float4*>(P + o);
             }
             reinterpret_cast<float4*>(s_p)[e] = p4;
@@ -1221,7 +1181,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                 const int64_t o = m * KP + 4 * (e % ROW4);
                 // single-GPU step: the gradient of these rows is final here and nothing else in the step reads P again, so
                 // Adam + clamp is applied on the spot (no dP round trip through HBM, no separate launch for the P matrices)
-                if (ad.m != nullptr && !ad.pre) adam_float4(P + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.inv_bc2, ad.grad_scale, true);
+                if (ad.m != nullptr) adam_float4(P + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.inv_bc2, ad.grad_scale, true);
                 else *reinterpret_cast<float4*>(dP + o) = g4;
             }
         }
@@ -1549,7 +1509,6 @@ static int launch_decode(const uint8_t* xp, int64_t ld, const int32_t* idx, int 
                          const float* Q, int SP, float* dP, float* dqpart, float* losspart, int with_loss,
                          hipStream_t st, uint8_t* xg, AdamFused ad) {
     constexpr int SPL = dec_spl(KP);
-    if (ad.m && ad.pre && launch_adam_range(P, dP, ad, M * KP, st, 1)) return 1;   // no prologue in this kernel: update first
     const int64_t chunks = (M + 256 * SPL - 1) / (256 * SPL);
     dim3 grid((unsigned)chunks), block(256);
     if (with_loss)
@@ -1558,7 +1517,7 @@ static int launch_decode(const uint8_t* xp, int64_t ld, const int32_t* idx, int 
         hipLaunchKernelGGL((decode_bce_kernel<KP, SPL, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart);
     if (check_launch("decode_bce")) return 1;
     if (xg && launch_gather_rows(xp, ld, idx, b, M, xg, st)) return 1;
-    return (ad.m && !ad.pre) ? launch_adam_range(P, dP, ad, M * KP, st, 1) : 0;
+    return ad.m ? launch_adam_range(P, dP, ad, M * KP, st, 1) : 0;
 }
 
 }  // namespace nadm
@@ -1589,8 +1548,7 @@ static int enc_rows_per_block(int b) {
 
 static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                            const float* V, int32_t CP, float* zpart, void* stream, uint32_t missing_bf16,
-                           SmallSide ss = SmallSide{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f},
-                           float* Vrw = nullptr, const float* dV = nullptr, AdamFused adv = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0}) {
+                           SmallSide ss = SmallSide{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f}) {
     if (!xp || !idx || !V || !zpart) return fail("nadm_encode_fwd: null pointer");
     if (b <= 0 || M <= 0) return fail("nadm_encode_fwd: empty batch or M");
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_encode_fwd: ld must be a multiple of 16 and >= ceil(M/4)");
@@ -1623,22 +1581,16 @@ static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
             const double cost = rounds_eff((double)(chunks * g) / 512.0) * (11.3 + (double)((ntiles + g - 1) / g));
             if (cost < best) { best = cost; gy = g; }
         }
-        if (adv.m && ntiles <= EM_TILES_PER_BLOCK) gy = 1;                    // prologue update of V: every row in exactly one block
-        else if (adv.m) {                                                     // batch too tall for one split: the update as a launch of its own
-            if (launch_adam_range(Vrw, dV, adv, M * CP, st, 0)) return 1;
-            adv.m = nullptr;
-        }
         int tpb = (int)((ntiles + gy - 1) / gy);
         if (tpb > EM_TILES_PER_BLOCK) tpb = EM_TILES_PER_BLOCK;
         gy = (ntiles + tpb - 1) / tpb;
         const int side_blocks = ss.part ? (ss.n + 511) / 512 : 0;
         dim3 g2((unsigned)(chunks * gy + side_blocks)), b2(512);
-        if (CP == 4) hipLaunchKernelGGL((encode_fwd_mfma_kernel<4>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16, (int)chunks, (int)gy, ss, Vrw, dV, adv);
-        else hipLaunchKernelGGL((encode_fwd_mfma_kernel<8>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16, (int)chunks, (int)gy, ss, Vrw, dV, adv);
+        if (CP == 4) hipLaunchKernelGGL((encode_fwd_mfma_kernel<4>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16, (int)chunks, (int)gy, ss);
+        else hipLaunchKernelGGL((encode_fwd_mfma_kernel<8>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16, (int)chunks, (int)gy, ss);
         return check_launch("encode_fwd_mfma");
     }
     if (ss.part) return fail("nadm_encode_fwd_small: only the matrix-core pass (CP <= 8) hosts the side blocks");
-    if (adv.m && launch_adam_range(Vrw, dV, adv, M * CP, st, 0)) return 1;   // VALU pass 1: the update as a launch of its own
 #define ENC_LAUNCH(cp)                                                                                                 \
     {                                                                                                                  \
         if (lds > 48 * 1024) {                                                                                         \
@@ -1666,14 +1618,13 @@ static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
 }
 
 static int adam_fused_args(const nadm_adam_t* adam, const char* who, AdamFused* out) {
-    *out = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0};
+    *out = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f};
     if (!adam) return 0;
     if (!adam->m || !adam->v) return fail(who);
     if (adam->step < 1) return fail("nadm_*_step: Adam step is 1-based");
     if (((uintptr_t)adam->m | (uintptr_t)adam->v) & 15) return fail("nadm_*_step: Adam state must be 16-byte aligned");
     out->m = adam->m; out->v = adam->v; out->grad_scale = adam->grad_scale;
-    out->pre = adam->when == 1 ? 1 : 0;
-    if (adam->when != 0 && adam->when != 1) return fail("nadm_*_step: nadm_adam_t.when is 0 (epilogue) or 1 (prologue, pass 2 only)");
+    if (adam->reserved != 0) return fail("nadm_*_step: nadm_adam_t.reserved must be 0");
     adam_scalars(adam->lr, adam->step, &out->step_size, &out->inv_bc2);
     return 0;
 }
@@ -1691,34 +1642,11 @@ extern "C" int nadm_encode_fwd_small(const uint8_t* xp, int64_t ld, const int32_
     SmallSide ss{small_part, grad_small, small, nullptr, nullptr, splits, n_small, 0.f, 0.f, 0.f};
     if (adam) {
         if (!adam->m || !adam->v || !small) return fail("nadm_encode_fwd_small: Adam state / parameters are NULL");
-        if (adam->step < 1 || adam->when != 0) return fail("nadm_encode_fwd_small: Adam step is 1-based, when must be 0");
+        if (adam->step < 1) return fail("nadm_encode_fwd_small: Adam step is 1-based");
         ss.m = adam->m; ss.v = adam->v; ss.grad_scale = adam->grad_scale;
         adam_scalars(adam->lr, adam->step, &ss.step_size, &ss.inv_bc2);
     }
     return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0u, ss);
-}
-
-extern "C" int nadm_encode_fwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
-                                    float* V, int32_t CP, float* zpart, const float* dV, const nadm_adam_t* adam_v,
-                                    const float* small_part, int32_t splits, int32_t n_small, float* grad_small, float* small,
-                                    const nadm_adam_t* adam_small, void* stream) {
-    if (!adam_v || !dV || !V) return fail("nadm_encode_fwd_step: V, dV and the Adam state of V are required (use nadm_encode_fwd / _small otherwise)");
-    AdamFused adv;
-    if (adam_fused_args(adam_v, "nadm_encode_fwd_step: Adam state of V is NULL", &adv)) return 1;
-    if (adam_v->when != 1) return fail("nadm_encode_fwd_step: the V update runs in the prologue (nadm_adam_t.when = 1)");
-    if (((uintptr_t)V | (uintptr_t)dV) & 15) return fail("nadm_encode_fwd_step: V and dV must be 16-byte aligned");
-    SmallSide ss{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f};
-    if (small_part) {
-        if (!grad_small || splits <= 0 || n_small <= 0) return fail("nadm_encode_fwd_step: small-parameter side work needs grad_small, splits, n_small");
-        ss = SmallSide{small_part, grad_small, small, nullptr, nullptr, splits, n_small, 0.f, 0.f, 0.f};
-        if (adam_small) {
-            if (!adam_small->m || !adam_small->v || !small) return fail("nadm_encode_fwd_step: Adam state / parameters of the small update are NULL");
-            if (adam_small->step < 1 || adam_small->when != 0) return fail("nadm_encode_fwd_step: small update: step is 1-based, when must be 0");
-            ss.m = adam_small->m; ss.v = adam_small->v; ss.grad_scale = adam_small->grad_scale;
-            adam_scalars(adam_small->lr, adam_small->step, &ss.step_size, &ss.inv_bc2);
-        }
-    }
-    return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0u, ss, V, dV, adv);
 }
 
 extern "C" int nadm_pca_project(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
@@ -1760,14 +1688,14 @@ static int decode_bce_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
 extern "C" int nadm_decode_bce(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                                const float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
                                float* losspart, int32_t with_loss, void* stream) {
-    return decode_bce_impl(xp, ld, idx, b, M, const_cast<float*>(P), kp, Q, SP, dP, dqpart, losspart, with_loss, stream, nullptr, AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0});
+    return decode_bce_impl(xp, ld, idx, b, M, const_cast<float*>(P), kp, Q, SP, dP, dqpart, losspart, with_loss, stream, nullptr, AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f});
 }
 
 extern "C" int nadm_decode_bce_gather(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                                       const float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
                                       float* losspart, int32_t with_loss, uint8_t* xg, void* stream) {
     if (!xg) return fail("nadm_decode_bce_gather: null pointer");
-    return decode_bce_impl(xp, ld, idx, b, M, const_cast<float*>(P), kp, Q, SP, dP, dqpart, losspart, with_loss, stream, xg, AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0});
+    return decode_bce_impl(xp, ld, idx, b, M, const_cast<float*>(P), kp, Q, SP, dP, dqpart, losspart, with_loss, stream, xg, AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f});
 }
 
 extern "C" int nadm_decode_bce_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
@@ -1805,7 +1733,7 @@ extern "C" int nadm_dz_image(const float* dZ, int32_t b, int32_t CP, void* dzimg
 
 static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                            const float* dZ, const void* dzimg, int32_t CP, float* dV, void* stream, uint32_t missing_bf16, int32_t flags = 0,
-                           float* Vrw = nullptr, AdamFused ad = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f, 0},
+                           float* Vrw = nullptr, AdamFused ad = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f},
                            const nadm_mlp_weights_t* mw = nullptr) {
     if (!xp || !idx || !dZ || !dV) return fail("nadm_encode_bwd: null pointer");
     if (CP > 8 && (flags & NADM_X_CLEAN)) return fail("nadm_encode_bwd: the batch copy (NADM_X_CLEAN) is tiled for the matrix-core pass, C <= 8");

@@ -1053,17 +1053,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     adam_segment(p, g, m, v, n, clamp_from, step_size, inv_bc2, grad_scale, ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4,
                  (int64_t)gridDim.x * blockDim.x * 4);
 }
-// two segments, one launch: blocks [0, blocks0) walk segment 0, the rest segment 1 (nadm_adam2)
-__global__ __launch_bounds__(256) void adam2_kernel(float* __restrict__ p0, const float* __restrict__ g0, float* __restrict__ m0, float* __restrict__ v0,
-                                                    int64_t n0, int64_t clamp_from0, float* __restrict__ p1, const float* __restrict__ g1,
-                                                    float* __restrict__ m1, float* __restrict__ v1, int64_t n1, int blocks0,
-                                                    float step_size, float inv_bc2, float grad_scale) {
-    if ((int)blockIdx.x < blocks0)
-        adam_segment(p0, g0, m0, v0, n0, clamp_from0, step_size, inv_bc2, grad_scale, ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4, (int64_t)blocks0 * 256 * 4);
-    else
-        adam_segment(p1, g1, m1, v1, n1, n1, step_size, inv_bc2, grad_scale, ((int64_t)(blockIdx.x - blocks0) * 256 + threadIdx.x) * 4,
-                     (int64_t)(gridDim.x - blocks0) * 256 * 4);
-}
 
 // =================================================================================================
 // pack / unpack (pack2bit.cu:10-62).  One thread per output dword (16 genotypes).
@@ -1724,23 +1713,6 @@ extern "C" int nadm_adam(float* param, const float* grad, float* m, float* v, in
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, clamp_from, step_size,
                        inv_bc2, grad_scale);
     return check_launch("adam");
-}
-
-extern "C" int nadm_adam2(float* param0, const float* grad0, float* m0, float* v0, int64_t n0, int64_t clamp_from0,
-                          float* param1, const float* grad1, float* m1, float* v1, int64_t n1,
-                          float lr, int32_t step, float grad_scale, void* stream) {
-    if (!param0 || !grad0 || !m0 || !v0 || !param1 || !grad1 || !m1 || !v1) return fail("nadm_adam2: null pointer");
-    if (step < 1) return fail("nadm_adam2: step is 1-based");
-    if (n0 <= 0 || n1 <= 0) return fail("nadm_adam2: empty segment (use nadm_adam)");
-    if (((uintptr_t)param0 | (uintptr_t)grad0 | (uintptr_t)m0 | (uintptr_t)v0 | (uintptr_t)param1 | (uintptr_t)grad1 | (uintptr_t)m1 | (uintptr_t)v1) & 15)
-        return fail("nadm_adam2: buffers must be 16-byte aligned");
-    float step_size, inv_bc2;
-    adam_scalars(lr, step, &step_size, &inv_bc2);
-    auto nblk = [](int64_t n) { int64_t x = (n / 4 + 255) / 256; return (int)(x > 256 * 16 ? 256 * 16 : (x < 1 ? 1 : x)); };
-    const int b0 = nblk(n0), b1 = nblk(n1);
-    hipLaunchKernelGGL(adam2_kernel, dim3((unsigned)(b0 + b1)), dim3(256), 0, (hipStream_t)stream, param0, grad0, m0, v0, n0, clamp_from0,
-                       param1, grad1, m1, v1, n1, b0, step_size, inv_bc2, grad_scale);
-    return check_launch("adam2");
 }
 
 extern "C" int nadm_synth_packed(uint8_t* xp, int64_t rows, int64_t row0, int64_t M, int64_t ld, const float* Qt, const float* Fq,
