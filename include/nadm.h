@@ -247,8 +247,8 @@ int64_t nadm_dz_image_bytes(int32_t b);
 int nadm_dz_image(const float* dZ, int32_t b, int32_t CP, void* dzimg, void* stream);
 /* nadm_mlp_bwd that also leaves dZ's operand image in dzimg: the block that completes a group of 32 samples last builds the group's
  * part (no launch of its own, no launch gap).  dz_counters: (b + 31) / 32 int32 on the device, ZERO-FILLED ONCE by the caller (the
- * launch returns them to zero).  A shorter batch than the previous one leaves the image parts of the samples past b as they were;
- * pass 3 multiplies them by zeros. */
+ * launch returns them to zero).  The 128-sample tile the batch ends in is completed with zeros; tiles past it are not touched
+ * (pass 3 does not read them). */
 int nadm_mlp_bwd_image(const nadm_heads_t* hd, const float* small, float* dqpart, int64_t M, int32_t b,
                        const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
                        float* dL, float* dHpre, float* dgp, float* small_part, float* dZ, float* grad_small,

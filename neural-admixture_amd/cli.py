@@ -38,7 +38,9 @@ def parse_train_args(argv):
     p.add_argument("--pops_path", type=str, default="")
     p.add_argument("--n_components", type=int, default=8)
     p.add_argument("--num_gpus", type=int, default=1)
-    p.add_argument("--threads", type=int, default=1)
+    p.add_argument("--threads", type=int, default=1,
+                   help="host thread pools (torch, BLAS, OpenMP), like the reference's flag (entry.py:46,138-146; default 1 as there). "
+                        "The GPU step does not use them; the decoder-init mixture fit and the host side of the readers do: 4 is a good value")
     p.add_argument("--parallelism", choices=("dp", "snp"), default="dp",
                    help="multi-GPU sharding: dp = samples (the reference's DDP), snp = SNPs (two tiny all-reduces per step)")
     p.add_argument("--share_gpu", action="store_true",

@@ -1539,6 +1539,18 @@ extern "C" int64_t nadm_decode_chunks(int64_t M, int kp) {
     return (M + c - 1) / c;
 }
 
+// compute units of the current device (cached per device ordinal; 256 if the runtime cannot say)
+static int device_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
+}
+
 static int enc_rows_per_block(int b) {
     const int max_rows = 832;                           // 13 waves; LDS = rows * 132 B <= 110 KB
     const int gy = (b + max_rows - 1) / max_rows;
@@ -1560,7 +1572,8 @@ static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
         // Every block first splits its 2048 x CP slice of V into bf16 operands (about as much work as 11 sample tiles), so a block
         // should see many tiles; but the 512 block slots of the chip (2 per CU) want to be filled, and a partly filled last round
         // costs most of a full one.  grid.y = the number of batch splits (never fewer than 4 tiles per block) that minimises
-        //   rounds_eff(chunks * gy / 512) * (11.3 + tiles / gy)
+        //   rounds_eff(chunks * gy / slots) * (11.3 + tiles / gy),   slots = 2 blocks per CU of the device the launch goes to (512 on an
+        //   MI355X in SPX mode; a partition or another SKU reports its own CU count)
         // with rounds_eff() read off measured launches (profiles/r03_p1_batch_splits.txt: b = 800, M = 500k .. 1M, grid.y = 1..4; the
         // model reproduces all twenty within 2 us except one): a block alone on its CU runs 1.5 x faster, a round that is a
         // little over-full costs 1.4 rounds.  M = 500k: 2 splits (43.6 us; 1 / 3 / 4: 49.1 / 47.7 / 49.0), 600k: 3 (56.1; 60.0 with
@@ -1575,10 +1588,11 @@ static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
             if (x <= 2.0) return 2.00;
             return 0.45 + 0.72 * x;
         };
+        const double slots = 2.0 * (double)device_cu_count();
         int64_t gy = 1;
         double best = 1e30;
         for (int64_t g = 1; g <= 64 && g <= (ntiles + 3) / 4; ++g) {
-            const double cost = rounds_eff((double)(chunks * g) / 512.0) * (11.3 + (double)((ntiles + g - 1) / g));
+            const double cost = rounds_eff((double)(chunks * g) / slots) * (11.3 + (double)((ntiles + g - 1) / g));
             if (cost < best) { best = cost; gy = g; }
         }
         int tpb = (int)((ntiles + gy - 1) / gy);

@@ -61,6 +61,7 @@ class _Rows:
         chunks = int(lib.nadm_encode_chunks(M))
         rb = min(N, rows)
         zpart = torch.empty(chunks * rb * 8, dtype=torch.float32, device=dev)
+        fold = torch.empty(rb * 8, dtype=torch.float32, device=dev)       # the chunks' partial sums folded in a fixed order (nadm_sum_rows)
         idx = torch.arange(N, dtype=torch.int32, device=dev)
         Bd = B_np if torch.is_tensor(B_np) else torch.from_numpy(np.ascontiguousarray(B_np, dtype=np.float32)).to(dev)
         out = torch.empty((N, kp), dtype=torch.float32, device=dev)
@@ -72,7 +73,8 @@ class _Rows:
             for s in range(0, N, rb):
                 e = min(N, s + rb)
                 check(lib.nadm_pca_project(ptr(self.xp), self.ld, ptr(idx[s:e]), e - s, M, ptr(Vd), 8, ptr(zpart), st), "pca_project")
-                out[s:e, g:g + w] = zpart[: chunks * (e - s) * 8].view(chunks, e - s, 8).sum(dim=0)[:, :w]
+                check(lib.nadm_sum_rows(ptr(zpart), chunks, (e - s) * 8, ptr(fold), st), "sum_rows")
+                out[s:e, g:g + w] = fold[: (e - s) * 8].view(e - s, 8)[:, :w]
         out *= 2.0
         return out if keep_on_device else out.cpu().numpy()
 
@@ -112,7 +114,8 @@ def _preload_mixture_library(N: int) -> None:
             import sklearn.mixture  # noqa: F401
         except Exception:                                        # the fit itself will report what is wrong
             pass
-    threading.Thread(target=_imp, name="nadm-preload-sklearn", daemon=True).start()
+    # not a daemon: a run that ends (or fails) early waits for the import to finish instead of tearing the interpreter down under it
+    threading.Thread(target=_imp, name="nadm-preload-sklearn", daemon=False).start()
 
 
 def RSVD(A_uint8, N: int, M: int, k: int = 8, seed: int = 42, oversampling: int = 10, power_iterations: int = 2,

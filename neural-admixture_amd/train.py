@@ -33,13 +33,15 @@ def pca_project_gpu(data, V_CM: np.ndarray, device: torch.device, chunk_rows: in
     Vd[:, :C_] = torch.as_tensor(np.ascontiguousarray(V_CM.T), dtype=torch.float32).to(device)
     chunks = int(lib.nadm_encode_chunks(M))
     zpart = torch.empty(chunks * min(N, chunk_rows) * CP, dtype=torch.float32, device=device)
+    fold = torch.empty(min(N, chunk_rows) * CP, dtype=torch.float32, device=device)     # chunk partials folded in a fixed order
     idx = torch.arange(min(N, chunk_rows), dtype=torch.int32, device=device)
     out = np.empty((N, C_), dtype=np.float32)
     st = torch.cuda.current_stream().cuda_stream
     for s, e, pk in packed_chunks(data, ld, chunk_rows):
         xp = pk.to(device)
         check(lib.nadm_pca_project(ptr(xp), ld, ptr(idx), e - s, M, ptr(Vd), CP, ptr(zpart), st), "pca_project")
-        out[s:e] = zpart[: chunks * (e - s) * CP].view(chunks, e - s, CP).sum(dim=0)[:, :C_].cpu().numpy()
+        check(lib.nadm_sum_rows(ptr(zpart), chunks, (e - s) * CP, ptr(fold), st), "sum_rows")
+        out[s:e] = fold[: (e - s) * CP].view(e - s, CP)[:, :C_].cpu().numpy()
     return out
 
 

@@ -20,7 +20,7 @@ for spread in (0.0, 2.0, 6.0):
     dZ = (rng.standard_normal((N, Cc)) * np.exp2(rng.uniform(-spread, spread, size=(N, 1)))).astype(np.float32)
     e.dZ[: N * Cc] = torch.from_numpy(dZ.reshape(-1)).to(dev)
     idx = torch.arange(N, dtype=torch.int32, device=dev)
-    check(lib.nadm_encode_bwd(ptr(e.xp), e.ld, ptr(idx), N, M, ptr(e.dZ), e._dz_image(N), Cc, ptr(e.gbig), 0, None))
+    e.encode_backward(idx, N)
     torch.cuda.synchronize()
     got = e.gV().cpu().numpy().astype(np.float64)
     X = np.where(Gm == 3, 0, Gm).astype(np.float64) / 2
