@@ -244,11 +244,14 @@ int nadm_mlp_bwd_weights(const nadm_heads_t* hd, int32_t b, const float* Zn, con
  * for every block of the launch, so it is built once: nadm_dz_image(dZ [b, CP] -> dzimg, nadm_dz_image_bytes(b) bytes, 16-byte
  * aligned), on the stream, before the pass.  dZ itself is read by the CP > 8 variants only (dzimg may be NULL for them). */
 int64_t nadm_dz_image_bytes(int32_t b);
+int64_t nadm_dz_image_tile_bytes(void);      /* bytes of one 128-sample tile of the image */
 int nadm_dz_image(const float* dZ, int32_t b, int32_t CP, void* dzimg, void* stream);
 /* nadm_mlp_bwd that also leaves dZ's operand image in dzimg: the block that completes a group of 32 samples last builds the group's
  * part (no launch of its own, no launch gap).  dz_counters: (b + 31) / 32 int32 on the device, ZERO-FILLED ONCE by the caller (the
- * launch returns them to zero).  The 128-sample tile the batch ends in is completed with zeros; tiles past it are not touched
- * (pass 3 does not read them). */
+ * launch returns them to zero).  Only the 32-sample groups the batch touches are written: a caller whose batch is shorter than the
+ * one before clears the image's last tile first (nadm_dz_image_tile_bytes; nadm_step does), or the groups between the batch and
+ * the end of that tile keep the earlier batch's pieces -- harmless while they are finite (pass 3 multiplies them by X = 0), but
+ * a group that held an inf carries the NaN scale. */
 int nadm_mlp_bwd_image(const nadm_heads_t* hd, const float* small, float* dqpart, int64_t M, int32_t b,
                        const float* Z, const float* rinv, const float* Zn, const float* H, const float* Q,
                        float* dL, float* dHpre, float* dgp, float* small_part, float* dZ, float* grad_small,

@@ -110,6 +110,7 @@ def _load():
         "nadm_supervised_ce": (C.c_int, [vp, i32, i32, i32, vp, vp, i32, i32, f32, vp, vp, vp]),
         "nadm_encode_bwd": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, i32, vp, i32, vp]),
         "nadm_dz_image_bytes": (C.c_int64, [i32]),
+        "nadm_dz_image_tile_bytes": (C.c_int64, []),
         "nadm_batch_copy_bytes": (C.c_int64, [i32, i64]),
         "nadm_dz_image": (C.c_int, [vp, i32, i32, vp, vp]),
         "nadm_vcf_parse_gt": (C.c_int, [C.c_char_p, i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]),

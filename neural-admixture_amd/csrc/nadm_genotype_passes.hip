@@ -748,6 +748,13 @@ __device__ __forceinline__ f32x2_t fp4_pair_x2(const uint32_t w, const int sel) 
     }
 }
 
+// block id -> work item such that the blocks the dispatcher places on one XCD (id % 8) get consecutive items
+__device__ __forceinline__ int64_t xcd_chunk(const unsigned bid, const unsigned nwg) {
+    constexpr unsigned NX = 8;
+    const unsigned q = nwg / NX, r = nwg % NX, x = bid % NX;
+    return (int64_t)(x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / NX;
+}
+
 constexpr int BF_WAVES = NADM_BF_WAVES;
 constexpr int BF_NTW = NADM_BF_NTW;     // 16-SNP tiles per wave
 constexpr int BF_TS = NADM_BF_TS;       // samples per LDS tile
@@ -796,7 +803,12 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int a = lane >> 4, n = lane & 15;
-    const int64_t chunk = blockIdx.x;
+    // block -> chunk, XCD-aware: a block owns 64 bytes of every batch row, and the L2 fetches 128: with the dispatcher's round robin
+    // (block i on XCD i % 8) the two halves of a line are fetched by two different L2s -- 2 x the payload on the fabric, 2.74 x with
+    // unaligned rows (profiles/r04_pmc_req.json).  Here every XCD gets a contiguous range of chunks, so the blocks i and i + 8 -- same
+    // XCD, dispatched back to back, walking the rows in the same order -- own the two halves of the same lines and the second one
+    // hits.  A bijection for any grid size; placement is a matter of speed only (chunk is the index of everything the block writes).
+    const int64_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
     const int64_t byte0 = chunk * RB;
     const int64_t snp_wave0 = chunk * (MF_WAVES * 16 * NTW) + wave * (16 * NTW);
     // MFMA row 4*ab + r of tile t holds SNP code sigma(r) = {0,2,1,3}[r] of the lane group's byte t: registers (0,1) of an
@@ -1735,6 +1747,7 @@ extern "C" int nadm_decode_bce_images(const uint8_t* xp, int64_t ld, const int32
 }
 
 extern "C" int64_t nadm_batch_copy_bytes(int32_t b, int64_t M) { return ((M + 4 * nadm::XG_TILE_COLS - 1) / (4 * nadm::XG_TILE_COLS)) * (int64_t)b * nadm::XG_TILE_COLS; }
+extern "C" int64_t nadm_dz_image_tile_bytes(void) { return (int64_t)nadm::DZI_TILE_U4 * 16; }
 extern "C" int64_t nadm_dz_image_bytes(int32_t b) { return (int64_t)((b + nadm::DZI_TS - 1) / nadm::DZI_TS) * nadm::DZI_TILE_U4 * 16; }
 
 extern "C" int nadm_dz_image(const float* dZ, int32_t b, int32_t CP, void* dzimg, void* stream) {

@@ -798,15 +798,6 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
             s_grpz[tid] = x;
             __syncthreads();
             if (tid < 64) dzi_build_piece<true>(s_grpz, b, CP, dzimg, grp >> 2, grp & 3, tid >> 3, tid & 7);
-            // The batch's last group also clears the K-blocks of its tile that lie past the batch: pass 3 reads whole 128-sample tiles,
-            // and pieces a taller batch of an earlier step left there (a NaN scale, had that dZ held an inf) would meet X = 0
-            if (grp == (b - 1) / 32 && (grp & 3) != 3) {
-                __syncthreads();
-                s_grpz[tid] = 0.f;
-                __syncthreads();
-                for (int q = (grp & 3) + 1; q < 4; ++q)
-                    if (tid < 64) dzi_build_piece<true>(s_grpz, b, CP, dzimg, grp >> 2, q, tid >> 3, tid & 7);
-            }
         }
     }
 }

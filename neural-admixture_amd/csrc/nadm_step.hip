@@ -186,6 +186,7 @@ struct nadm_plan {
     int pend_splits = 0, pend_step = 0;
     float pend_lr = 0.f, pend_scale = 1.f;
     bool a_pending = false;
+    int last_b = 0;                                              // batch size of the previous step (dZ image hygiene, see nadm_step)
     hipStream_t side = nullptr;                                  // DP: message A
     hipEvent_t ev_p2 = nullptr, ev_a = nullptr;
     // multi-head models: the heads' pass-2 launches are independent (own P rows, slab, loss slots; they share X and Q) and each ends
@@ -479,6 +480,13 @@ extern "C" int nadm_step(nadm_plan_t* p, const int32_t* idx, int32_t b, float lr
         if (d.comm && d.comm->all_reduce(d.comm->ctx, d.dqsum, (int64_t)b * hd.SP, stream)) return 1;
         dq_src = d.dqsum; dq_M = 1;
     }
+    if (hd.CP <= 8 && b < p->last_b && b % 128 != 0) {
+        // a shorter batch than the step before: the 32-sample groups between the batch and the end of its last 128-sample tile would
+        // keep that step's pieces (pass 3 reads whole tiles; finite pieces meet X = 0 there, a NaN scale would not vanish)
+        const int64_t tb = nadm_dz_image_tile_bytes();
+        HIP_OK(hipMemsetAsync((char*)d.dzimg + (int64_t)(b / 128) * tb, 0, (size_t)tb, st), "hipMemsetAsync");
+    }
+    p->last_b = b;
     Timed t3{p, NADM_T_MLP_BWD, st};
     if (t3.begin()) return 1;
     const int64_t nl = with_loss ? n_loss : 0;

@@ -85,6 +85,7 @@ class Engine:
         self._iota = torch.arange(b, dtype=torch.int32, device=device) if tiled else None
         # validity of the three by-products for the plain phases below (the plan's own step always produces what it consumes)
         self._qimg_b = self._dzimg_b = -1
+        self._dz_last_b = 0
         self._xg_key = None
         self.xp: Optional[torch.Tensor] = None          # packed genotypes [rows, ld]
         self.labels: Optional[torch.Tensor] = None      # int32 [rows], supervised mode only
@@ -369,6 +370,10 @@ class Engine:
                 ptr(self.H), ptr(self._Q), ptr(self.dL), ptr(self.dHpre), ptr(self.dgp), ptr(self.small_part),
                 ptr(self._dZ), ptr(self.gflat), ptr(self.losspart), n_loss, ptr(self.loss_acc))
         if self._dzimg is not None:     # C <= 8: dZ also as the operand image of pass 3, built by the blocks that finish a 32-sample group
+            if b < self._dz_last_b and b % 128:          # a shorter batch: clear the image's last tile first (include/nadm.h, as nadm_step does)
+                tb = int(lib.nadm_dz_image_tile_bytes())
+                self._dzimg[(b // 128) * tb: (b // 128 + 1) * tb].zero_()
+            self._dz_last_b = b
             check(lib.nadm_mlp_bwd_image(*args, ptr(self._dzimg), ptr(self._dzcnt), st), "mlp_bwd_image")
             self._dzimg_b = b
         else:

@@ -55,6 +55,8 @@ class ModelLayout:
 
     @staticmethod
     def row_stride(M: int) -> int:
-        """Packed row stride in bytes: ceil(M/4) rounded up to 16 (aligned 16 B loads; 64 / 128 / 256-byte row alignment was
-        measured and changes nothing: the genotype passes are issue-bound, not request-bound)."""
-        return ((int(M) + 3) // 4 + 15) // 16 * 16
+        """Packed row stride in bytes: ceil(M/4) rounded up to 128, the size of the L2's requests to memory (the kernels need 16).
+        A gathered row piece then never straddles a request: with 16-byte-aligned rows pass 2's 64-byte pieces cost 1.37 requests
+        each and pass 1's 512-byte pieces five instead of four (request-size counters, profiles/r04_pmc_req.json).  Time is
+        unchanged -- the genotype passes are issue-bound -- the bytes moved are not."""
+        return ((int(M) + 3) // 4 + 127) // 128 * 128

@@ -134,7 +134,7 @@ def test_layout_offsets_and_padding():
     assert L.ks == [2, 3, 4] and L.kp == [4, 4, 4] and L.qoff == [0, 4, 8] and L.SP == 12
     assert L.n_small == 8 + 64 * 8 + 64 + sum(k * 64 + k for k in (2, 3, 4))
     assert L.p_off == [8000, 12000, 16000] and L.n_big == 20000 and L.clamp_from == 8000
-    assert ModelLayout.row_stride(1000) == 256 and ModelLayout.row_stride(8451) == 2128
+    assert ModelLayout.row_stride(1000) == 256 and ModelLayout.row_stride(8451) == 2176      # ceil(M/4) rounded up to 128 bytes
     offs, tot = L.dq_offsets(10)
     assert offs[0] == 0 and tot == sum(c * 10 * kp for c, kp in zip(L.dec_chunks, L.kp))
 

@@ -2,7 +2,12 @@
 """Counter passes of one bench step with rocprofv3 (--pmc only, kernel dispatch records; never combined with tracing
 domains) -> gpurun_out/<round>_pmc_hbm.{json,txt} and gpurun_out/<round>_pmc_sq.{json,txt}; copy them to profiles/.
 
-    python tools/pmc_profile.py [calib] [hbm] [sq] [-- bench flags]
+    python tools/pmc_profile.py [calib] [req] [hbm] [sq] [-- bench flags]
+
+req: (r04) the L2's memory-side REQUEST counters by size -- TCC_EA0_RDREQ / _32B / _64B / _128B, TCC_BUBBLE, TCC_EA0_WRREQ / _64B
+     -- for the calibration kernels and for pass 2: physical bytes = sum over sizes of requests x size, no calibration ratio in
+     between -> gpurun_out/<round>_pmc_req.json.  `hbm` then reports three figures side by side: raw FETCH_SIZE + WRITE_SIZE, the
+     guide's rule (FETCH_SIZE x 2), and the request-size bytes.
 
 calib: what FETCH_SIZE / WRITE_SIZE count for the access patterns of pass 2 (tools/calib_fetch.hip: kernels with a known byte
      count each) -> gpurun_out/<round>_pmc_calib.json = counted / known per pattern.  MI355X_MICROARCH.md "HBM": a wide coalesced
@@ -89,6 +94,61 @@ def calibrate():
     return out
 
 
+REQ_SETS = [["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"],
+            ["TCC_BUBBLE_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"]]
+
+
+def req_bytes(d):
+    """{counter: (n, per dispatch)} of one kernel -> request counts by size and the bytes they move."""
+    g = lambda n: d[n][1] if n in d else None
+    rd, r32, r64, r128, bub = g("TCC_EA0_RDREQ_sum"), g("TCC_EA0_RDREQ_32B_sum"), g("TCC_EA0_RDREQ_64B_sum"), g("TCC_EA0_RDREQ_128B_sum"), g("TCC_BUBBLE_sum")
+    wr, w64 = g("TCC_EA0_WRREQ_sum"), g("TCC_EA0_WRREQ_64B_sum")
+    out = {"rdreq": rd, "rdreq_32b": r32, "rdreq_64b": r64, "rdreq_128b": r128, "tcc_bubble": bub, "wrreq": wr, "wrreq_64b": w64}
+    if None not in (rd, r32, r64, r128):
+        other = rd - r32 - r64 - r128                                  # requests no size counter claims (0 if the three partition RDREQ)
+        out["rdreq_unsized"] = other
+        out["read_bytes_by_request_size"] = 32.0 * r32 + 64.0 * r64 + 128.0 * r128 + 64.0 * max(other, 0.0)
+    if None not in (wr, w64):
+        out["write_bytes_by_request_size"] = 64.0 * w64 + 32.0 * (wr - w64)
+    return out
+
+
+def requests():
+    """Request-size counters of the calibration kernels (known payload per launch) -> physical bytes per payload byte per access
+    pattern; and of the bench step's pass 2."""
+    exe = os.path.join(ROOT, "tools", "abl", "calib")
+    if not os.path.exists(exe):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", os.path.join(ROOT, "tools", "calib_fetch.hip"), "-o", exe], check=True)
+    out = {"round": RND, "note": "TCC_EA0_* = the L2's requests to the fabric (Infinity Cache / HBM side), summed over the TCC instances; bytes = sum "
+                                 "over request sizes of count x size.  physical_per_payload = those bytes / the bytes the kernel asked for"}
+    pats = {}
+    for i, cs in enumerate(REQ_SETS):
+        d = f"/tmp/pmc_calibreq_{i}"
+        shutil.rmtree(d, ignore_errors=True)
+        r = subprocess.run(["rocprofv3", "--pmc", *cs, "-d", d, "-o", "run", "--", exe], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"),
+                           capture_output=True, text=True)
+        m = re.search(r"known_bytes (.*)", r.stdout)
+        if not m:
+            sys.stderr.write(r.stdout[-2000:] + r.stderr[-2000:])
+            raise SystemExit("calibration run under the request counters failed")
+        toks = m.group(1).split()
+        known = {toks[j]: int(toks[j + 1]) for j in range(0, len(toks), 2)}
+        db = [os.path.join(p_, f) for p_, _, fs in os.walk(d) for f in fs if f.endswith(".db")][0]
+        for k, dd in per_kernel(db).items():
+            name = next((n for n in known if n in k), None)
+            if name:
+                pats.setdefault(name, {"known_bytes": known[name], "_c": {}})["_c"].update(dd)
+    for name, e in pats.items():
+        rb = req_bytes(e.pop("_c"))
+        e.update(rb)
+        key = "read_bytes_by_request_size" if name.endswith("read") else "write_bytes_by_request_size"
+        if rb.get(key) is not None:
+            e["physical_per_payload"] = rb[key] / e["known_bytes"]
+    out["patterns"] = pats
+    return out
+
+
 def load_calib():
     for d in (OUT, os.path.join(ROOT, "profiles")):
         try:
@@ -114,6 +174,29 @@ def main():
     if "calib" in what:
         calibrate()
         what = [w for w in what if w != "calib"]
+    req = None
+    if "req" in what:
+        flags_ = flags
+        req = requests()
+        vals = {}
+        line = None
+        for i, cs in enumerate(REQ_SETS):
+            db, line = run_pass(cs, f"req{i}", flags_)
+            for k, d in per_kernel(db).items():
+                if "nadm" in k and "synth" not in k:
+                    vals.setdefault(k, {}).update(d)
+        req["src_hash"], req["workload_key"] = src, workload_key(line)
+        req["kernels"] = {k[:90]: req_bytes(d) for k, d in vals.items()}
+        dec = [k for k in vals if "decode_bce" in k]
+        tot = {}
+        for k in dec:
+            for n, v in req_bytes(vals[k]).items():
+                if v is not None:
+                    tot[n] = tot.get(n, 0.0) + v
+        req["pass2_per_step"] = tot
+        json.dump(req, open(os.path.join(OUT, f"{RND}_pmc_req.json"), "w"), indent=1)
+        print(json.dumps(req))
+        what = [w for w in what if w != "req"]
     if "hbm" in what:
         txt, vals, line = [], {}, None
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -148,8 +231,26 @@ def main():
             traffic, known = (2 * f + w) * 1024.0, None
             corr = ("FETCH_SIZE x2 (gfx950 tallies the 128 B requests of wide coalesced streams at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as "
                     "counted; all pass-2 launches of one step summed (no calibration file)")
+        if req is None:
+            for d_ in (OUT, os.path.join(ROOT, "profiles")):
+                try:
+                    req = json.load(open(os.path.join(d_, f"{RND}_pmc_req.json")))
+                    break
+                except (OSError, ValueError):
+                    pass
+        three = {"raw_counters_bytes": (f + w) * 1024.0, "guide_rule_bytes": (2 * f + w) * 1024.0, "calibrated_bytes_r03_method": traffic if (cal and comp) else None,
+                 "request_size_bytes": None}
+        if req and req.get("src_hash") == src and req.get("workload_key") == workload_key(line):
+            t_ = req["pass2_per_step"]
+            if "read_bytes_by_request_size" in t_ and "write_bytes_by_request_size" in t_:
+                three["request_size_bytes"] = t_["read_bytes_by_request_size"] + t_["write_bytes_by_request_size"]
+                three["request_size_read_bytes"], three["request_size_write_bytes"] = t_["read_bytes_by_request_size"], t_["write_bytes_by_request_size"]
+                traffic = three["request_size_bytes"]               # the physical figure: what bench.py reports as roofline.traffic
+                corr = ("bytes = sum over request sizes of TCC_EA0_RDREQ_{32B,64B,128B} x size + TCC_EA0_WRREQ (64 B / 32 B) x size "
+                        f"({RND}_pmc_req.json, separate --pmc passes); raw FETCH_SIZE + WRITE_SIZE and the guide's x2 rule are listed beside it")
         out = {"round": RND, "src_hash": src, "workload_key": workload_key(line), "kernels": [k[:80] for k in dec],
                "fetch_size_kib_raw": f, "write_size_kib_raw": w, "correction": corr, "known_composition": known,
+               "three_figures": three,
                "traffic_bytes_per_launch": traffic, "launches_per_step": nl,
                "alg_bytes_per_launch_8d": line["roofline"]["alg_bytes_per_launch"], "alg_bytes_min_per_launch": line["roofline"]["alg_bytes_min_per_launch"]}
         json.dump(out, open(os.path.join(OUT, f"{RND}_pmc_hbm.json"), "w"), indent=1)
