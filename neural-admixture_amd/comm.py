@@ -48,10 +48,13 @@ class Comm:
         self.handle = None
 
     def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        # An RCCL communicator is only destroyed by an explicit close(): ncclCommDestroy is a collective-ish call that must not run
+        # from a finalizer (interpreter shutdown, another rank already gone); leaving it to process exit is harmless
+        if self.kind != "rccl":
+            try:
+                self.close()
+            except Exception:
+                pass
 
 
 def loaded_librccl() -> Optional[bytes]:
