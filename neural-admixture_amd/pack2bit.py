@@ -31,7 +31,8 @@ from ._lib import lib, check, ptr
 
 __all__ = ["pack2bit_cpu_to_gpu", "unpack2bit_gpu_to_gpu"]
 
-_CHUNK_ROWS = 8192            # rows per pinned staging buffer (the reference stages 1024 unpacked rows at a time, pack2bit.cu:8,78)
+_STAGE_BYTES = 64 << 20       # pinned staging buffer, sized by BYTES (the reference stages 1024 unpacked rows at a time, pack2bit.cu:8,78;
+_stage = None                 # 8192 packed rows of a 500k-SNP matrix would pin 1 GB) and kept for the process
 
 
 def _check(cond: bool, msg: str) -> None:
@@ -54,8 +55,11 @@ def pack2bit_cpu_to_gpu(input_cpu: torch.Tensor, output_gpu: torch.Tensor) -> No
     if N == 0 or M == 0:
         return
     src = input_cpu.contiguous()
-    rows = min(_CHUNK_ROWS, N)
-    stage = torch.empty((rows, packed_cols), dtype=torch.uint8).pin_memory()
+    global _stage
+    rows = max(1, min(N, _STAGE_BYTES // packed_cols))
+    if _stage is None or _stage.numel() < rows * packed_cols:
+        _stage = torch.empty(rows * packed_cols, dtype=torch.uint8).pin_memory()
+    stage = _stage[: rows * packed_cols].view(rows, packed_cols)
     for s in range(0, N, rows):
         e = min(N, s + rows)
         check(lib.nadm_pack2bit_host(ptr(src[s:e]), ptr(stage), e - s, M, packed_cols), "pack2bit_cpu_to_gpu")
