@@ -139,6 +139,52 @@ def test_layout_offsets_and_padding():
     assert offs[0] == 0 and tot == sum(c * 10 * kp for c, kp in zip(L.dec_chunks, L.kp))
 
 
+@pytest.mark.parametrize("M,ks,world", [(1000, [3], 1), (1000, [3], 2), (509, [2, 3, 4], 3), (8451, [3], 8), (500_000, [8], 8), (77, [20], 5)])
+def test_flat_layout_cuts_both_messages_into_world_equal_slices(M, ks, world):
+    """nadm_flat_layout (include/nadm.h): [small | pad | V | gap | all P | gap]; message B = [0, world * slice_b) holds the small
+    parameters and V, message A = [msg_a_off, n_flat) every head's P; slices are 16-byte multiples; world = 1 has no gaps."""
+    from neural_admixture_amd.layout import ModelLayout
+    L = ModelLayout(M, 8, 64, ks, world)
+    assert L.off_v % 64 == 0 and L.off_v >= L.n_small
+    assert L.slice_b % 4 == 0 and L.slice_a % 4 == 0
+    assert L.msg_a_off == world * L.slice_b and L.n_flat == L.msg_a_off + world * L.slice_a
+    assert L.msg_a_off >= L.off_v + M * L.CP                               # V ends inside message B
+    assert L.off_v + L.p_off[0] == L.msg_a_off                             # the first P starts message A
+    end_p = L.off_v + L.p_off[-1] + M * L.kp[-1]
+    assert end_p <= L.n_flat and L.n_flat - end_p < 4 * world              # the trailing gap is smaller than one rounding unit per rank
+    assert L.msg_a_off - (L.off_v + M * L.CP) < 4 * world
+    for h in range(len(ks) - 1):
+        assert L.p_off[h + 1] == L.p_off[h] + M * L.kp[h]                  # heads back to back
+    if world == 1:
+        assert L.n_flat == L.off_v + M * L.CP + sum(M * kp for kp in L.kp) and L.clamp_from == M * L.CP
+    L1 = ModelLayout(M, 8, 64, ks, 1)
+    assert L.off_v == L1.off_v and L.n_small == L1.n_small                 # the small parameters and V start where they always do
+
+
+def test_plan_and_transport_entry_points_validate_their_arguments():
+    """No GPU needed: nadm_comm_emulated builds rank 0 of W; nadm_plan_create refuses incomplete descriptors, nadm_step a NULL plan."""
+    import ctypes as C
+    from neural_admixture_amd._lib import lib, CommStruct, PlanDesc
+    from neural_admixture_amd.comm import emulated_comm, torch_comm
+    c = emulated_comm(8)
+    assert (c.rank, c.world, c.kind) == (0, 8, "emulated")
+    st = c.handle.contents
+    assert st.rank == 0 and st.world == 8 and st.reduce_scatter(None, None, 4, None) == 0 and st.all_gather(None, None, 4, None) == 0
+    c.close()
+    t = torch_comm(1, 2)
+    assert t.handle.contents.rank == 1 and t.handle.contents.world == 2 and t.transport.buffers == []
+    assert lib.nadm_comm_emulated(0, C.byref(C.POINTER(CommStruct)())) != 0
+    plan = C.c_void_p()
+    d = PlanDesc()
+    assert lib.nadm_plan_create(C.byref(d), C.byref(plan)) != 0 and b"M, bmax" in lib.nadm_last_error()
+    d.mode, d.M, d.ld, d.bmax = 7, 100, 32, 10
+    assert lib.nadm_plan_create(C.byref(d), C.byref(plan)) != 0 and b"unknown mode" in lib.nadm_last_error()
+    d.mode = 0
+    assert lib.nadm_plan_create(C.byref(d), C.byref(plan)) != 0 and b"head table" in lib.nadm_last_error()
+    assert lib.nadm_step(None, None, 1, 1e-3, 1, None) != 0 and b"null pointer" in lib.nadm_last_error()
+    assert lib.nadm_plan_step_count(None) == -1
+
+
 def test_initial_weights_match_reference_rng_stream():
     from neural_admixture_amd.model import init_encoder_weights
     d = np.load(f"{G}/one_step_multihead.npz")
