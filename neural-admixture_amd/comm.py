@@ -70,8 +70,12 @@ def loaded_librccl() -> Optional[bytes]:
     return None
 
 
-def rccl_comm(rank: int, world: int, group=None) -> Comm:
-    """One RCCL communicator over the ranks of ``group`` (default group; world = 1 needs no torch.distributed)."""
+def rccl_comm(rank: int, world: int, group=None, device: Optional[torch.device] = None) -> Comm:
+    """One RCCL communicator over the ranks of ``group`` (default group; world = 1 needs no torch.distributed), for the GPU
+    ``device`` (default: the current one) -- ncclCommInitRank binds the communicator to the HIP device that is current."""
+    if device is not None and device.type == "cuda":
+        with torch.cuda.device(device):
+            return rccl_comm(rank, world, group)
     path = loaded_librccl()
     uid = (C.c_char * 128)()
     if rank == 0:
@@ -155,7 +159,7 @@ def make_comm(device: torch.device, rank: int, world: int, group=None) -> Comm:
     rank), torch.distributed callbacks otherwise."""
     import torch.distributed as dist
     if world == 1:
-        return rccl_comm(0, 1) if device.type == "cuda" else torch_comm(0, 1, group)
+        return rccl_comm(0, 1, device=device) if device.type == "cuda" else torch_comm(0, 1, group)
     if device.type == "cuda" and dist.get_backend(group) == "nccl":
-        return rccl_comm(rank, world, group)
+        return rccl_comm(rank, world, group, device=device)
     return torch_comm(rank, world, group)
