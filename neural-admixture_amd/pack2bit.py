@@ -20,16 +20,38 @@ packs on the device, pack2bit.cu:79-115); the kernels run on torch's current str
 
 The training path of this package never unpacks -- its kernels decode the 2-bit codes in registers (csrc/nadm_genotype_passes.hip);
 ``unpack2bit_gpu_to_gpu`` exists for the reference's own model code and for tests.
+
+Two forms of the same binding: the torch C++ extension ``csrc/ext/_pack2bit.so`` (csrc/pack2bit_ext.cpp, built by
+``__graft_entry__.build()`` with torch.utils.cpp_extension like the reference builds its module) is used when it has been built;
+otherwise the same two functions over ``ctypes`` below.  Same checks, same messages, same results (tests run both).
 """
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
+import os
 
 import torch
 
 from ._lib import lib, check, ptr
 
-__all__ = ["pack2bit_cpu_to_gpu", "unpack2bit_gpu_to_gpu"]
+__all__ = ["pack2bit_cpu_to_gpu", "unpack2bit_gpu_to_gpu", "extension"]
+
+
+def _load_extension():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "ext", "_pack2bit.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        spec = importlib.util.spec_from_file_location("_pack2bit", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)                          # (libnadm.so is already mapped: _lib loaded it by its soname)
+        return mod
+    except ImportError:                                       # built against another torch / Python: the ctypes form serves
+        return None
+
+
+extension = _load_extension()                                 # the torch extension module, or None
 
 _STAGE_BYTES = 64 << 20       # pinned staging buffer, sized by BYTES (the reference stages 1024 unpacked rows at a time, pack2bit.cu:8,78;
 _stage = None                 # 8192 packed rows of a 500k-SNP matrix would pin 1 GB) and kept for the process
@@ -40,7 +62,7 @@ def _check(cond: bool, msg: str) -> None:
         raise RuntimeError(msg)
 
 
-def pack2bit_cpu_to_gpu(input_cpu: torch.Tensor, output_gpu: torch.Tensor) -> None:
+def _pack2bit_cpu_to_gpu_ctypes(input_cpu: torch.Tensor, output_gpu: torch.Tensor) -> None:
     """uint8 [N, M] on the CPU -> 2-bit codes [N, ceil(M / 4)] on the GPU: SNP 4c + i in bits [2i, 2i + 1] of byte c, code = value & 3,
     tail bits 0 (pack2bit.cu:10-36,65-117).  ``output_gpu`` is caller-allocated and fully written; returns None; blocks."""
     _check(input_cpu.device.type == "cpu", "Input tensor must be on CPU")
@@ -67,7 +89,7 @@ def pack2bit_cpu_to_gpu(input_cpu: torch.Tensor, output_gpu: torch.Tensor) -> No
     torch.cuda.synchronize(output_gpu.device)
 
 
-def unpack2bit_gpu_to_gpu(input_gpu: torch.Tensor, output_gpu: torch.Tensor) -> None:
+def _unpack2bit_gpu_to_gpu_ctypes(input_gpu: torch.Tensor, output_gpu: torch.Tensor) -> None:
     """2-bit codes [b, ceil(M / 4)] -> uint8 [b, M] with out[r, 4c + i] = (in[r, c] >> 2i) & 3, both on the same GPU
     (pack2bit.cu:38-62,120-142).  ``output_gpu`` is caller-allocated; returns None; blocks."""
     _check(input_gpu.device.type == "cuda", "Input tensor must be on CUDA device")
@@ -87,3 +109,7 @@ def unpack2bit_gpu_to_gpu(input_gpu: torch.Tensor, output_gpu: torch.Tensor) -> 
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         check(lib.nadm_unpack2bit(ptr(src), ptr(output_gpu), N, M, packed_cols, st), "unpack2bit_gpu_to_gpu")
         torch.cuda.current_stream().synchronize()            # the reference blocks (pack2bit.cu:141)
+
+
+pack2bit_cpu_to_gpu = extension.pack2bit_cpu_to_gpu if extension is not None else _pack2bit_cpu_to_gpu_ctypes
+unpack2bit_gpu_to_gpu = extension.unpack2bit_gpu_to_gpu if extension is not None else _unpack2bit_gpu_to_gpu_ctypes

@@ -601,8 +601,11 @@ def test_pack2bit_module_has_the_reference_names_and_refuses_misplaced_tensors()
     checks raise RuntimeError with the reference's TORCH_CHECK messages (pack2bit.cu:66-76,121-130) before anything touches a GPU."""
     import inspect
     from neural_admixture_amd import pack2bit
-    assert list(inspect.signature(pack2bit.pack2bit_cpu_to_gpu).parameters) == ["input_cpu", "output_gpu"]
-    assert list(inspect.signature(pack2bit.unpack2bit_gpu_to_gpu).parameters) == ["input_gpu", "output_gpu"]
+    assert list(inspect.signature(pack2bit._pack2bit_cpu_to_gpu_ctypes).parameters) == ["input_cpu", "output_gpu"]
+    assert list(inspect.signature(pack2bit._unpack2bit_gpu_to_gpu_ctypes).parameters) == ["input_gpu", "output_gpu"]
+    if pack2bit.extension is not None:                      # the torch C++ extension (csrc/pack2bit_ext.cpp): two Tensors in, None out
+        for f in (pack2bit.pack2bit_cpu_to_gpu, pack2bit.unpack2bit_gpu_to_gpu):
+            assert "(arg0: torch.Tensor, arg1: torch.Tensor) -> None" in f.__doc__
     g = torch.zeros((3, 10), dtype=torch.uint8)
     with pytest.raises(RuntimeError, match="Output tensor must be on CUDA device"):
         pack2bit.pack2bit_cpu_to_gpu(g, torch.zeros((3, 3), dtype=torch.uint8))

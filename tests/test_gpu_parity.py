@@ -1509,14 +1509,22 @@ def test_small_parameter_update_riding_in_the_next_pass1_equals_the_immediate_on
 
 
 @pytest.mark.gpu
-def test_pack2bit_module_runs_the_reference_call_sequence():
+@pytest.mark.parametrize("form", ["torch_extension", "ctypes"])
+def test_pack2bit_module_runs_the_reference_call_sequence(form):
     """The reference's own sequence around its native module, through neural_admixture_amd.pack2bit: allocate
     ``packed_data [N, (M + 3) // 4]`` and pack the whole matrix once (model/train.py:121,126), then per batch gather packed rows
     (DataLoader over the packed tensor, src/loaders.py:62-72), allocate ``unpacked_step [b, M]`` and unpack
     (model/neural_admixture.py:404-406; the final-Q pass does the same with sequential batches of <= 1024, :374-378).  Bit-exact
     against the layout fixture and the oracle's pack rule, caller-owned buffers, shape errors as RuntimeError."""
-    from neural_admixture_amd import pack2bit
+    import types
+    from neural_admixture_amd import pack2bit as p2b
     dev = _dev()
+    if form == "torch_extension":       # the reference's own form: a module built with torch.utils.cpp_extension (model/train.py:122-125)
+        assert p2b.extension is not None, "csrc/ext/_pack2bit.so missing: __graft_entry__.build() builds it"
+        assert p2b.pack2bit_cpu_to_gpu is p2b.extension.pack2bit_cpu_to_gpu          # ... and it is what the package hands out
+        pack2bit = p2b.extension
+    else:
+        pack2bit = types.SimpleNamespace(pack2bit_cpu_to_gpu=p2b._pack2bit_cpu_to_gpu_ctypes, unpack2bit_gpu_to_gpu=p2b._unpack2bit_gpu_to_gpu_ctypes)
     d = np.load(f"{G}/pack_layout.npz")
     rng = np.random.default_rng(5)
     for Gm in (d["G"], d["G_hibits"], rng.integers(0, 4, size=(2311, 4099), dtype=np.uint8), rng.integers(0, 256, size=(9000, 37), dtype=np.uint8)):
