@@ -165,6 +165,13 @@ struct SmallSide {
     float step_size, inv_bc2, grad_scale;
 };
 
+// block id -> work item such that the blocks the dispatcher places on one XCD (id % 8) get consecutive items
+__device__ __forceinline__ int64_t xcd_chunk(const unsigned bid, const unsigned nwg) {
+    constexpr unsigned NX = 8;
+    const unsigned q = nwg / NX, r = nwg % NX, x = bid % NX;
+    return (int64_t)(x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / NX;
+}
+
 template <int CP>
 __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
                                                               const int32_t* __restrict__ idx, int b, int64_t M,
@@ -204,9 +211,12 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
     float (*const s_out)[16 * 8] = reinterpret_cast<float (*)[16 * 8]>(&s_raw[SZ_FLOATS]);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
-    const int64_t chunk = (int)blockIdx.x % n_chunks;
+    // block -> (chunk, batch split), XCD-aware (r04): the blocks i and i + 8 -- same XCD, dispatched back to back -- take the batch
+    // splits of ONE chunk, so the second one finds the chunk's V rows in that XCD's L2 instead of fetching them again
+    const int64_t vwork = xcd_chunk(blockIdx.x, (unsigned)n_main);
+    const int64_t chunk = vwork / n_splits;
     const int64_t slice0 = chunk * EM_CHUNK_SNPS + wave * EM_SLICE;
-    const int tile_begin = ((int)blockIdx.x / n_chunks) * tiles_per_block;
+    const int tile_begin = (int)(vwork % n_splits) * tiles_per_block;
     const int tile_end = min((b + 15) / 16, tile_begin + tiles_per_block);
     // A missing call (code 3) is 0 in the model (neural_admixture.py:170) and 1.5 = bf16 0x3FC0 in the init-time PCA
     // projection (train.py:52), selected by the caller.  FP4 (E2M1) reads the nibble 00cc as c/2 -- 0, 0.5, 1, 1.5 -- so
@@ -746,13 +756,6 @@ __device__ __forceinline__ f32x2_t fp4_pair_x2(const uint32_t w, const int sel) 
         case 2: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 2.0f, 2);
         default: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 2.0f, 3);
     }
-}
-
-// block id -> work item such that the blocks the dispatcher places on one XCD (id % 8) get consecutive items
-__device__ __forceinline__ int64_t xcd_chunk(const unsigned bid, const unsigned nwg) {
-    constexpr unsigned NX = 8;
-    const unsigned q = nwg / NX, r = nwg % NX, x = bid % NX;
-    return (int64_t)(x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / NX;
 }
 
 constexpr int BF_WAVES = NADM_BF_WAVES;
