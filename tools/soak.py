@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""A long version of tests/test_soak_handoffs.py, run once per round on the GPU box: N production steps (nadm_step: Q images, dZ image
+built by the MLP backward's last blocks, small update riding in the next pass 1) against the same steps as the unfused launch
+sequence, bit for bit; batch sizes cycle 800 / 790 / 37 / 800 / 128 / 1.  -> gpurun_out/r04_soak.txt
+
+    python tools/soak.py [steps=100000]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_soak_handoffs import _engines, _same_state          # noqa: E402
+from unfused_step import unfused_step                          # noqa: E402
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+    M, N = 60_000, 4000
+    prod, ref = _engines(M, [8], 1024, N, seed=101)
+    dev = prod.device
+    gen = torch.Generator().manual_seed(11)
+    sizes = (800, 790, 37, 800, 128, 1)
+    t0 = time.time()
+    bad = None
+    for s in range(steps):
+        b = sizes[s % len(sizes)]
+        idx = torch.randint(0, N, (b,), generator=gen, dtype=torch.int32).to(dev)
+        wl = (s % 7) != 3
+        prod.train_step(idx, b, 2e-3, wl)
+        unfused_step(ref, idx, b, 2e-3, wl)
+        if s % 5000 == 4999:
+            torch.cuda.synchronize()
+            ok = _same_state(prod, ref) and int(prod._dzcnt.abs().sum().item()) == 0
+            print(f"step {s + 1}: {'identical' if ok else 'DIFFERENT'}  ({time.time() - t0:.0f} s)", flush=True)
+            if not ok:
+                bad = s + 1
+                break
+    torch.cuda.synchronize()
+    ok = bad is None and _same_state(prod, ref) and prod.read_loss() == ref.read_loss()
+    line = (f"r04 soak: {steps if bad is None else bad} consecutive production steps (M = {M}, K = 8, Hd = 1024, batch sizes cycling {sizes}) vs the unfused "
+            f"launch sequence: parameters, moments and loss sums {'BIT-IDENTICAL' if ok else 'DIFFER'}; group counters zero; {time.time() - t0:.0f} s")
+    print(line)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r04_soak.txt"), "w") as f:
+        f.write(line + "\n")
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
