@@ -440,6 +440,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(eng, args, dev)
         print(json.dumps(out))
         sys.stdout.flush()
+    if comm is not None:                                                # every rank gets here: the communicator goes down together
+        del eng
+        comm.close()
     if use_dist:
         dist.destroy_process_group()
 
