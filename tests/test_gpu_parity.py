@@ -1328,6 +1328,47 @@ def test_adam_in_the_epilogues_of_passes_2_and_3_equals_the_separate_launches(ks
     assert float(e1.P(0).min()) >= 0.0 and float(e1.P(0).max()) <= 1.0
 
 
+def test_production_step_equals_the_plain_phases_on_random_shapes():
+    """nadm_step (fused epilogues, operand images, the small update riding in the next pass 1, two pass-2 streams for several heads,
+    the fallbacks for C > 8 / K > 16 / wide hidden layers) against forward -> backward -> adam on a twin engine: 30 random shapes,
+    three steps each with the loss value on and off, a batch that shrinks on the way -- parameters, moments and loss sums bit for bit.
+    The sample-sharded sequence (NADM_MODE_DP, one rank, no-op transport: gradients written out, Adam as launches on the slices, message
+    A on its side stream) must leave the same bits too."""
+    from neural_admixture_amd.comm import emulated_comm
+    dev = _dev()
+    one_rank = emulated_comm(1)
+    rng = np.random.default_rng(2024)
+    shapes = [(1, 5, [2], 8, 8), (2, 1023, [3], 32, 8), (33, 2500, [16], 64, 12), (20, 1500, [20], 32, 8), (10, 900, [33], 32, 16),
+              (9, 800, [5], 2304, 8), (70, 2600, [2, 3, 4, 5, 6, 7, 8, 9, 10], 64, 8), (900, 1300, [4], 64, 8), (40, 3000, [9, 20], 64, 4)]
+    while len(shapes) < 30:
+        nh = int(rng.integers(1, 4))
+        ks = sorted(set(int(k) for k in rng.integers(2, 25, size=nh)))
+        shapes.append((int(rng.integers(1, 300)), int(rng.integers(4, 9000)), ks, int(rng.choice([8, 32, 64, 96, 256, 1024])), int(rng.choice([4, 8, 8, 8, 12]))))
+    for N, M, ks, Hd, C in shapes:
+        Gm = O.synth_genotypes(N, M, max(2, min(max(ks), 6)), seed=N + M, missing=0.03)
+        V0 = (rng.standard_normal((M, C)) / np.sqrt(M)).astype(np.float32)
+        P0 = rng.uniform(0.02, 0.98, size=(sum(ks), M)).astype(np.float32)
+        p = O.make_params(N, V0, P0, Hd, ks)
+        e1, e2 = make_engine(Gm, p, N), make_engine(Gm, p, N)
+        e3 = make_engine(Gm, p, N, mode="dp", comm=one_rank)         # the sample-sharded sequence of launches, one rank: the same bits
+        for s_ in range(3):
+            b = N if s_ != 1 else max(1, N - N // 3)                 # the middle step on a shorter batch
+            idx = torch.from_numpy(rng.permutation(N)[:b].astype(np.int32)).to(dev)
+            e1.train_step(idx, b, 2e-3, s_ != 1)
+            e2.forward(idx, b); e2.backward(idx, b, s_ != 1); e2.adam(2e-3)
+            e3.train_step(idx, b, 2e-3, s_ != 1)
+        torch.cuda.synchronize()
+        what = (N, M, ks, Hd, C)
+        loss2 = e2.read_loss()
+        for e in (e1, e3):
+            assert e.step_count == e2.step_count == 3, what
+            assert torch.equal(e.big, e2.big) and torch.equal(e.small, e2.small), what
+            assert torch.equal(e.mbig, e2.mbig) and torch.equal(e.vbig, e2.vbig) and torch.equal(e.msmall, e2.msmall), what
+            assert e.read_loss() == loss2, what
+        del e1, e2, e3
+    one_rank.close()
+
+
 @pytest.mark.parametrize("M,K", [(500_000, 8), (600_000, 7)])
 def test_full_size_properties_of_the_step(M, K):
     """BASELINE configs[3] width (M = 500k, b = 800, K = 8) and configs[1] width (M = 600k, K = 7), properties that do not need
