@@ -1561,6 +1561,11 @@ def test_pack2bit_module_runs_the_reference_call_sequence(form):
     from neural_admixture_amd import pack2bit as p2b
     dev = _dev()
     if form == "torch_extension":       # the reference's own form: a module built with torch.utils.cpp_extension (model/train.py:122-125)
+        if p2b.extension is None:       # not shipped with this checkout: build it the way __graft_entry__.build() does (~20 s, host code only)
+            import importlib
+            import __graft_entry__ as ge
+            ge.build_pack2bit_extension(os.path.join(ROOT, "neural-admixture_amd", "csrc"))
+            p2b = importlib.reload(p2b)
         assert p2b.extension is not None, "csrc/ext/_pack2bit.so missing: __graft_entry__.build() builds it"
         assert p2b.pack2bit_cpu_to_gpu is p2b.extension.pack2bit_cpu_to_gpu          # ... and it is what the package hands out
         pack2bit = p2b.extension
