@@ -245,7 +245,7 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            comm = nacomm.torch_comm(rank, world) if args.share_gpu else nacomm.rccl_comm(rank, world)
+            comm = nacomm.torch_comm(rank, world) if args.share_gpu else nacomm.make_comm(dev, rank, world)
             if comm.kind == "rccl":
                 rccl_ranks = comm.count_ranks(dev)                      # every rank contributes 1: the ranks the library's communicator connected
                 if rccl_ranks != world:

@@ -156,10 +156,25 @@ def torch_comm(rank: int, world: int, group=None) -> Comm:
 
 def make_comm(device: torch.device, rank: int, world: int, group=None) -> Comm:
     """The transport for this process: RCCL when the ranks sit on different GPUs behind an nccl process group (or there is one
-    rank), torch.distributed callbacks otherwise."""
+    rank), torch.distributed callbacks otherwise.  Should the library's own communicator fail to come up on ANY rank (librccl not
+    loadable, ncclCommInitRank refused), every rank falls back to the callbacks over the process group together -- slower (the
+    reduce-scatter becomes an all-reduce, every collective a host call) but running; ``Comm.kind`` says which one is in use."""
     import torch.distributed as dist
     if world == 1:
         return rccl_comm(0, 1, device=device) if device.type == "cuda" else torch_comm(0, 1, group)
     if device.type == "cuda" and dist.get_backend(group) == "nccl":
-        return rccl_comm(rank, world, group, device=device)
+        comm, err = None, None
+        try:
+            comm = rccl_comm(rank, world, group, device=device)
+        except Exception as e:                                  # noqa: BLE001 -- whatever it was, the ranks must agree on what happens next
+            err = e
+        ok = torch.tensor([0.0 if comm is None else 1.0], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if float(ok.item()) == 1.0:
+            return comm
+        if comm is not None:
+            comm.close()
+        import sys
+        print(f"[neural_admixture_amd] the step's own RCCL communicator is not available on every rank ({err!r}): "
+              "falling back to torch.distributed callbacks", file=sys.stderr)
     return torch_comm(rank, world, group)
