@@ -317,7 +317,8 @@ void nadm_comm_free(nadm_comm_t* comm);
                               * 1/world slice of the parameters and ITS moments only -> all-gather of the updated parameters.  Same wire
                               * bytes as the all-reduce, optimizer traffic and Adam-moment memory / world.  Message A (all P) travels on a
                               * side stream underneath the MLP backward, pass 3 and the next step's pass 1; message B (small | V) on the
-                              * compute stream behind pass 3 */
+                              * compute stream behind pass 3.  Issue order on the communicator: reduce-scatter A, reduce-scatter B,
+                              * all-gather B, all-gather A -- B, which the next pass 1 waits for, never queues behind A's all-gather */
 #define NADM_MODE_SNP    2   /* SNPs sharded (8(f)-4): every rank owns M/world SNPs of X, V, P and their Adam state and processes the
                               * GLOBAL batch; two small all-reduces per step (partial Z, partial dQ), Adam in the epilogues with 1/world */
 
@@ -367,7 +368,7 @@ int  nadm_plan_infer(nadm_plan_t* plan, const int32_t* idx, int32_t b, void* str
 #define NADM_T_DECODE_BCE 2
 #define NADM_T_MLP_BWD    3
 #define NADM_T_ENCODE_BWD 4
-#define NADM_T_SYNC_A     5   /* DP: message A on the side stream (reduce-scatter, Adam, all-gather) */
+#define NADM_T_SYNC_A     5   /* DP: message A on the side stream: from its reduce-scatter to its all-gather, which is issued behind message B (a span) */
 #define NADM_T_SYNC_B     6   /* DP: small-gradient sum + message B on the compute stream            */
 #define NADM_T_COUNT      7
 int  nadm_plan_timing(nadm_plan_t* plan, uint32_t mask);

@@ -314,19 +314,20 @@ int decode_heads(nadm_plan* p, const int32_t* idx, int b, int with_loss, const f
 }
 
 // one message of the sample-sharded step = reduce-scatter of the gradients -> Adam (+ restrict_P) on this rank's slice -> all-gather of
-// the updated parameters, as two calls so that message A can place its optimizer launch where it disturbs least.  msg_off / slice in
+// the updated parameters, as three calls: message A issues them at different points of the step (nadm_step).  msg_off / slice in
 // floats of the flat buffers; mom_off = where the slice's moments start in d.m / d.v
 int msg_reduce(nadm_plan* p, int64_t msg_off, int64_t slice, void* stream) {
     const nadm_comm_t* c = p->d.comm;
     return (c && c->reduce_scatter(c->ctx, p->d.grads + msg_off, slice, stream)) ? 1 : 0;
 }
-int msg_update_gather(nadm_plan* p, int64_t msg_off, int64_t slice, int64_t mom_off, bool clamp, float lr, void* stream) {
+int msg_update(nadm_plan* p, int64_t msg_off, int64_t slice, int64_t mom_off, bool clamp, float lr, void* stream) {
     const nadm_plan_desc_t& d = p->d;
-    const nadm_comm_t* c = d.comm;
     const int64_t lo = msg_off + (int64_t)p->rank * slice;
-    if (nadm_adam(d.params + lo, d.grads + lo, d.m + mom_off, d.v + mom_off, slice, clamp ? 0 : slice, lr, p->step_count, 1.0f / (float)p->world, stream))
-        return 1;
-    return (c && c->all_gather(c->ctx, d.params + msg_off, slice, stream)) ? 1 : 0;
+    return nadm_adam(d.params + lo, d.grads + lo, d.m + mom_off, d.v + mom_off, slice, clamp ? 0 : slice, lr, p->step_count, 1.0f / (float)p->world, stream);
+}
+int msg_gather(nadm_plan* p, int64_t msg_off, int64_t slice, void* stream) {
+    const nadm_comm_t* c = p->d.comm;
+    return (c && c->all_gather(c->ctx, p->d.params + msg_off, slice, stream)) ? 1 : 0;
 }
 
 }  // namespace
@@ -457,20 +458,19 @@ extern "C" int nadm_step(nadm_plan_t* p, const int32_t* idx, int32_t b, float lr
             return 1;
         n_loss += 1;
     }
+    Timed ta{p, NADM_T_SYNC_A, p->side};
     if (dp) {
-        // Message A on the side stream, right behind pass 2.  Its optimizer launch moves 28 B per element of this rank's slice and costs
-        // the step that HBM time wherever it runs -- underneath the MLP backward (here) 11 us at world = 1, underneath pass 3 14, message
-        // B 14, the next pass 1 19.5; fewer blocks or a low-priority stream change nothing (profiles/r04_ddp_plan.txt).  At world = W
-        // it is 1/W of that.
+        // Message A on the side stream, right behind pass 2: the reduce-scatter and the optimizer launch.  (That launch moves 28 B per
+        // element of this rank's slice and costs the step that HBM time wherever it runs -- underneath the MLP backward (here) 11 us at
+        // world = 1, underneath pass 3 14, message B 14, the next pass 1 19.5; fewer blocks or a low-priority stream change nothing,
+        // profiles/r04_ddp_plan.txt.  At world = W it is 1/W of that.)  Its ALL-GATHER is issued behind message B, at the end of the
+        // step: a communicator runs its collectives in the order they were issued, and message B -- which the next pass 1 waits for --
+        // must not queue behind 16 MB of P that nothing reads before the next pass 2.
         HIP_OK(hipEventRecord(p->ev_p2, st), "hipEventRecord");
         HIP_OK(hipStreamWaitEvent(p->side, p->ev_p2, 0), "hipStreamWaitEvent");
-        Timed ta{p, NADM_T_SYNC_A, p->side};
         if (ta.begin()) return 1;
         if (msg_reduce(p, p->lay.msg_a_off, p->lay.slice_a, p->side)) return 1;
-        if (msg_update_gather(p, p->lay.msg_a_off, p->lay.slice_a, p->lay.slice_b, true, lr, p->side)) return 1;
-        if (ta.end()) return 1;
-        HIP_OK(hipEventRecord(p->ev_a, p->side), "hipEventRecord");
-        p->a_pending = true;
+        if (msg_update(p, p->lay.msg_a_off, p->lay.slice_a, p->lay.slice_b, true, lr, p->side)) return 1;
     }
     p->p_unit = true;                                            // restrict_P ran (epilogue) or runs before P is read next (message A)
 
@@ -524,8 +524,14 @@ extern "C" int nadm_step(nadm_plan_t* p, const int32_t* idx, int32_t b, float lr
         if (tb.begin()) return 1;
         if (nadm_small_grads(d.small_part, splits, hd.n_small, d.grads, d.params, nullptr, stream)) return 1;     // the sum only
         if (msg_reduce(p, 0, p->lay.slice_b, stream)) return 1;
-        if (msg_update_gather(p, 0, p->lay.slice_b, 0, false, lr, stream)) return 1;
-        return tb.end();
+        if (msg_update(p, 0, p->lay.slice_b, 0, false, lr, stream)) return 1;
+        if (msg_gather(p, 0, p->lay.slice_b, stream)) return 1;
+        if (tb.end()) return 1;
+        if (msg_gather(p, p->lay.msg_a_off, p->lay.slice_a, p->side)) return 1;     // message A's all-gather: behind B in the communicator's order
+        if (ta.end()) return 1;
+        HIP_OK(hipEventRecord(p->ev_a, p->side), "hipEventRecord");
+        p->a_pending = true;
+        return 0;
     }
     if (hd.CP <= 8) {                                            // rides in the next pass 1
         p->small_pending = true;
