@@ -90,11 +90,12 @@ def spawn_ranks(args):
 
 
 def source_hash():
-    """Identity of the kernels a profile was taken from: sha256 over the HIP sources of libnadm.so."""
+    """Identity of the kernels a profile was taken from: sha256 over the KERNEL sources of libnadm.so (the host-only files --
+    nadm_step.hip, nadm_host.h -- queue launches and do not change what a launch does)."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "neural-admixture_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
-        if name.endswith((".hip", ".h")):
+        if name in ("nadm_genotype_passes.hip", "nadm_small_kernels.hip", "nadm_common.h"):
             with open(os.path.join(csrc, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
