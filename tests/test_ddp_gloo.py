@@ -173,3 +173,45 @@ def test_global_batch_800_over_4_and_8_ranks(tmp_path, world, parallelism):
     assert np.abs(r["V"] - p.V).max() < 1e-4
     if parallelism == "dp":
         assert np.allclose(r["losses"], losses, rtol=1e-6)
+
+
+def _transport_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neural_admixture_amd.comm import torch_comm
+    c = torch_comm(rank, world)
+    st = c.handle.contents
+    sl = 12
+    g = torch.arange(world * sl, dtype=torch.float32) * (rank + 1)          # "gradients": rank r holds (r + 1) * [0, 1, 2, ...]
+    pbuf = torch.full((world * sl,), -1.0)
+    pbuf[rank * sl:(rank + 1) * sl] = 100.0 * rank + torch.arange(sl, dtype=torch.float32)      # this rank's slice of the "parameters"
+    small = torch.ones(8) * (rank + 1)
+    c.transport.buffers += [g, pbuf, small]
+    # the three collectives exactly as nadm_step calls them: raw pointers into registered buffers, in place
+    assert st.reduce_scatter(None, g.data_ptr(), sl, None) == 0
+    assert st.all_gather(None, pbuf.data_ptr(), sl, None) == 0
+    assert st.all_reduce(None, small.data_ptr() + 8, 4, None) == 0             # a sub-range: elements 2..5
+    tot = world * (world + 1) / 2
+    assert torch.equal(g[rank * sl:(rank + 1) * sl], torch.arange(rank * sl, (rank + 1) * sl, dtype=torch.float32) * tot)     # own slice = the sum
+    for r in range(world):
+        assert torch.equal(pbuf[r * sl:(r + 1) * sl], 100.0 * r + torch.arange(sl, dtype=torch.float32))
+    assert torch.equal(small, torch.tensor([rank + 1.0] * 2 + [tot] * 4 + [rank + 1.0] * 2))
+    # a pointer outside every registered buffer is refused with a status, not an exception across the C frame
+    assert st.all_reduce(None, torch.zeros(4).data_ptr(), 4, None) == 1 and c.transport.error is not None
+    if rank == 0:
+        open(out_path, "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_torch_distributed_transport_of_the_step_collectives(tmp_path, world):
+    """comm.torch_comm: the nadm_comm_t whose three function pointers call back into a torch.distributed group (the transport of the
+    world-2 GPU tests that share one device, and the fallback when the library's RCCL communicator is unavailable) -- called here the
+    way nadm_step calls it, on CPU tensors over gloo."""
+    port = 43500 + (os.getpid() % 1500) + world
+    out = str(tmp_path / "transport.txt")
+    mp.spawn(_transport_worker, args=(world, port, out), nprocs=world, join=True)
+    assert open(out).read() == "ok"
