@@ -199,7 +199,7 @@ class NeuralAdmixture:
         self.lr = float(learning_rate)
         self.supervised_loss_weight = float(supervised_loss_weight)
         if parallelism not in ("dp", "snp"):
-            raise ValueError("parallelism must be 'dp' (samples sharded, gradient all-reduce) or 'snp' (SNPs sharded)")
+            raise ValueError("parallelism must be 'dp' (samples sharded, gradients summed over ranks) or 'snp' (SNPs sharded)")
         self.parallelism = parallelism
         self.loss_mode = loss_mode       # "logged": loss only on epochs that print it (:416); "always": every step
         self.epoch_losses: dict = {}

@@ -181,8 +181,8 @@ def _train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int
     """See module docstring.  ``data`` uint8 [N,M] CPU tensor (or an ``io.PackedGenotypes``, e.g. from
     ``io.read_bed_packed``); ``V`` numpy [C,M] (RSVD output,
     svd.py:83); returns Ps (list of [M,k] float32), Qs (list of [N,k] float32), model.
-    ``parallelism`` (keyword, not in the reference): "dp" = samples sharded over the GPUs with a gradient all-reduce, as the
-    reference does; "snp" = SNPs sharded (snp_parallel.py): same trajectory up to summation order, two tiny all-reduces
+    ``parallelism`` (keyword, not in the reference): "dp" = samples sharded over the GPUs, gradients summed over ranks like the reference's DDP (here: reduce-scatter,
+    optimizer on the rank's slice, all-gather); "snp" = SNPs sharded (snp_parallel.py): same trajectory up to summation order, two tiny all-reduces
     per step instead of the 4*M*(C+S)-byte one."""
     eng_cls = NeuralAdmixture.engine_snp_cls if parallelism == "snp" else NeuralAdmixture.engine_cls
     if device.type != "cuda" and not eng_cls._CPU_TEST_DOUBLE:      # tests/ run this function over gloo with an oracle-backed double
