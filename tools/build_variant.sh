@@ -10,6 +10,7 @@ mkdir -p $out /tmp/abl_$name
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
 hipcc $FLAGS -c $src/nadm_genotype_passes.hip -o /tmp/abl_$name/a.o "$@" &
 hipcc $FLAGS -c $src/nadm_small_kernels.hip -o /tmp/abl_$name/b.o "$@" &
+hipcc $FLAGS -c $src/nadm_step.hip -o /tmp/abl_$name/c.o "$@" &
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o $out/$name.so /tmp/abl_$name/a.o /tmp/abl_$name/b.o -lpthread
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libnadm.so -o $out/$name.so /tmp/abl_$name/a.o /tmp/abl_$name/b.o /tmp/abl_$name/c.o -lpthread -ldl
 echo "built $out/$name.so"
