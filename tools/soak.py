@@ -3,7 +3,10 @@
 built by the MLP backward's last blocks, small update riding in the next pass 1) against the same steps as the unfused launch
 sequence, bit for bit; batch sizes cycle 800 / 790 / 37 / 800 / 128 / 1.  -> gpurun_out/r04_soak.txt
 
-    python tools/soak.py [steps=100000]"""
+    python tools/soak.py [steps=100000] [dp]
+
+dp: the sample-sharded launch sequence (NADM_MODE_DP on a 1-rank RCCL communicator: side stream + events every step, Adam as launches of
+its own) against the single-GPU step instead -> gpurun_out/r04_soak_dp.txt"""
 import os
 import sys
 import time
@@ -20,9 +23,19 @@ from unfused_step import unfused_step                          # noqa: E402
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+    dp = len(sys.argv) > 2 and sys.argv[2] == "dp"
     M, N = 60_000, 4000
     prod, ref = _engines(M, [8], 1024, N, seed=101)
     dev = prod.device
+    if dp:
+        import neural_admixture_amd as na
+        from neural_admixture_amd.comm import rccl_comm
+        comm = rccl_comm(0, 1)
+        e = na.Engine(M, 8, 1024, [8], dev, 800, mode="dp", comm=comm)
+        e.pflat.copy_(prod.pflat)
+        e.set_packed(prod.xp)
+        prod = e
+    step_ref = (lambda idx, b, wl: ref.train_step(idx, b, 2e-3, wl)) if dp else (lambda idx, b, wl: unfused_step(ref, idx, b, 2e-3, wl))
     gen = torch.Generator().manual_seed(11)
     sizes = (800, 790, 37, 800, 128, 1)
     t0 = time.time()
@@ -32,7 +45,7 @@ def main():
         idx = torch.randint(0, N, (b,), generator=gen, dtype=torch.int32).to(dev)
         wl = (s % 7) != 3
         prod.train_step(idx, b, 2e-3, wl)
-        unfused_step(ref, idx, b, 2e-3, wl)
+        step_ref(idx, b, wl)
         if s % 5000 == 4999:
             torch.cuda.synchronize()
             ok = _same_state(prod, ref) and int(prod._dzcnt.abs().sum().item()) == 0
@@ -42,11 +55,12 @@ def main():
                 break
     torch.cuda.synchronize()
     ok = bad is None and _same_state(prod, ref) and prod.read_loss() == ref.read_loss()
-    line = (f"r04 soak: {steps if bad is None else bad} consecutive production steps (M = {M}, K = 8, Hd = 1024, batch sizes cycling {sizes}) vs the unfused "
-            f"launch sequence: parameters, moments and loss sums {'BIT-IDENTICAL' if ok else 'DIFFER'}; group counters zero; {time.time() - t0:.0f} s")
+    what = ("sample-sharded steps (NADM_MODE_DP, 1-rank RCCL communicator) vs the single-GPU step" if dp else "production steps vs the unfused launch sequence")
+    line = (f"r04 soak: {steps if bad is None else bad} consecutive {what} (M = {M}, K = 8, Hd = 1024, batch sizes cycling {sizes}): parameters, moments "
+            f"and loss sums {'BIT-IDENTICAL' if ok else 'DIFFER'}; group counters zero; {time.time() - t0:.0f} s")
     print(line)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r04_soak.txt"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r04_soak_dp.txt" if dp else "r04_soak.txt"), "w") as f:
         f.write(line + "\n")
     return 0 if ok else 1
 
