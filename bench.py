@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--parallelism", choices=("dp", "snp"), default="dp",
                     help="dp (default, the reference's scheme): samples sharded, gradient all-reduce; snp: SNPs sharded, every rank "
                          "processes the global batch of batch*N rows on its M/N SNPs, two small all-reduces per step")
+    ap.add_argument("--buckets", type=int, default=None, help="sample-sharded step: SNP ranges message B = [small | V] travels in (default: NeuralAdmixture.dp_buckets)")
+    ap.add_argument("--p3-whole", action="store_true", help="sample-sharded step with buckets: keep pass 3 one launch (only the next pass 1 is pipelined)")
+    ap.add_argument("--comm-a", action="store_true", help="sample-sharded step: a second communicator for message A = [all P]")
     ap.add_argument("--force-ddp", action="store_true", help="single GPU: run the sample-sharded step (NADM_MODE_DP) on a 1-rank RCCL communicator")
     ap.add_argument("--emulate-world", type=int, default=None, metavar="W",
                     help="single GPU, with --force-ddp: the step of rank 0 of W ranks with no-op collectives (nadm_comm_emulated) -- Adam on 1/W of "
@@ -267,7 +270,12 @@ def main():
         gperm = torch.Generator(device="cpu").manual_seed(1000)         # the same global batches on every rank
     else:
         rows_local, gb = args.rows // world, b
-        eng = na.Engine(M, 8, args.hidden, ks, dev, b, mode="dp" if ddp else "single", comm=comm if ddp else None)
+        comm_a = None
+        if ddp and args.comm_a:
+            comm_a = nacomm.emulated_comm(args.emulate_world) if args.emulate_world is not None else nacomm.make_comm(dev, rank, world)
+        n_buckets = args.buckets if args.buckets is not None else na.NeuralAdmixture.dp_buckets
+        eng = na.Engine(M, 8, args.hidden, ks, dev, b, mode="dp" if ddp else "single", comm=comm if ddp else None,
+                        n_buckets=n_buckets if ddp else 1, comm_a=comm_a, p3_whole=args.p3_whole)
         eng.set_packed(make_dataset(eng, rows_local, rank * rows_local, K, dev))
         gperm = torch.Generator(device="cpu").manual_seed(1000 + rank)
     eng.load_params(V0, P0, init_encoder_weights(42, 8, args.hidden, ks))
@@ -399,7 +407,9 @@ def main():
                                f"loss value {'every step' if with_loss else 'skipped'}",
                    "global_batch": gb if snp else b * world, "parallelism": f"{args.parallelism}{world}", "mode": mode,
                    "clock_ramp_steps_untimed": n_ramp, "transport": comm.kind if comm is not None else None,
-                   "emulated_world": args.emulate_world},
+                   "emulated_world": args.emulate_world,
+                   "message_b_buckets": eng.lay.n_buckets if ddp else None, "pass3_in_ranges": (not args.p3_whole) if ddp else None,
+                   "second_communicator": (eng.comm_a is not None) if ddp else None},
         # one C call per step (nadm_step): host time to queue a step onto an idle device; the timed region's own loop took
         # t_queued to queue (GPU-bound: the launch queue stays ahead)
         "host_queue_ms_per_step": host_queue_ms, "host_loop_ms_per_step_in_timed_region": t_queued / args.steps * 1e3,
@@ -441,9 +451,12 @@ def main():
             out["cpu_baseline"] = cpu_baseline(eng, args, dev)
         print(json.dumps(out))
         sys.stdout.flush()
+    comm_a2 = eng.comm_a
     if comm is not None:                                                # every rank gets here: the communicator goes down together
         del eng
         comm.close()
+        if comm_a2 is not None:
+            comm_a2.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -40,7 +40,8 @@ extern "C" {
 
 #define NADM_MAX_HEADS 32
 #define NADM_MAX_K 64
-#define NADM_ABI_VERSION 9   /* 9: nadm_step / nadm_plan_* / nadm_comm_* / nadm_flat_layout (the step as one call, sharded optimizer), nadm_test_force_generic_mlp; 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
+#define NADM_MAX_BUCKETS 8
+#define NADM_ABI_VERSION 10  /* 10: message B of the sample-sharded step in SNP-range buckets (nadm_flat_layout takes n_buckets, nadm_flat_layout_t.bkt_*, nadm_plan_desc_t.n_buckets / p3_whole / comm_a / debug, nadm_encode_fwd_part, nadm_plan_bucket_ms), nadm_comm_t.async_error, nadm_comm_rccl_probe, nadm_comm_rccl with a watchdog (timeout_ms), a failed step poisons its plan; 9: nadm_step / nadm_plan_* / nadm_comm_* / nadm_flat_layout (the step as one call, sharded optimizer), nadm_test_force_generic_mlp; 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
@@ -108,6 +109,14 @@ int nadm_bed_to_packed_dev(const uint8_t* bed_dev, int64_t N, int64_t M, uint8_t
  * Writes per-chunk partial sums zpart [nadm_encode_chunks(M), b, CP]; nadm_mlp_fwd reduces them. */
 int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                     const float* V, int32_t CP, float* zpart, void* stream);
+
+/* nadm_encode_fwd on an SNP sub-range that is ONE PART of a pass launched in several (the sample-sharded step: one part per
+ * bucket of message B, each part waiting for its own bucket, include "The training step as ONE call" below): pointers already
+ * advanced to the range -- xp + m0/4, V + m0*CP, zpart + (m0/2048)*b*CP, M = m1 - m0, m0 a multiple of 2048 -- and total_chunks =
+ * nadm_encode_chunks of the WHOLE pass, which the batch split is chosen for (the parts share the device; a part sized on its own
+ * would cut the batch finer and pay the per-block operand build that often).  Same results as the one launch, bit for bit. */
+int nadm_encode_fwd_part(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                         const float* V, int32_t CP, float* zpart, int64_t total_chunks, void* stream);
 
 /* ---- 8(f)-3: init-time PCA projection  X_pca = (G/2).V  with a MISSING call counted as 1.5 --------------
  * (train.py:49-55: `batch.astype(np.float32)/2 @ V.T` on the raw codes, no masking; feeds the sklearn GMM.  Also the
@@ -273,18 +282,30 @@ int nadm_adam(float* param, const float* grad, float* m, float* v, int64_t n, in
  * neural_admixture.py:315-319,403-414, as one host call per step; the entry points above remain the pieces it is made of)
  * ======================================================================================================================
  * Flat parameter layout.  Parameters, gradients and (single / SNP-sharded mode) Adam moments live in ONE flat float buffer each:
- *     [ small | pad to 64 | V [M,CP] | gap | P_0 [M,KP_0] | P_1 ... | gap ]
- * cut into the two MESSAGES of the sample-sharded step: B = [0, world * slice_b) holds the small parameters and V, A =
+ *     [ small | pad | V [M,CP] | gap | P_0 [M,KP_0] | P_1 ... | gap ]
+ * cut into the two MESSAGES of the sample-sharded step: B = [0, msg_a_off) holds the small parameters and V, A =
  * [msg_a_off, msg_a_off + world * slice_a) holds every head's P; the gaps (zeros, < 4 * world floats) make both a multiple of
- * `world` slices.  world = 1: no gaps. */
+ * `world` slices.  world = 1: no gaps, pad = to a multiple of 64 floats.
+ * Message B travels as n_buckets BUCKETS (r05; DDP's bucketed exchange, neural_admixture.py:315-319): bucket j = the floats
+ * [bkt_off[j], bkt_off[j+1]) = the V rows of the SNP range [bkt_m0[j], bkt_m0[j+1]) -- bucket 0 also the small parameters in front of
+ * them -- as `world` contiguous slices of bkt_slice[j] floats (range-major: every bucket is a message of its own, reduce-scattered,
+ * updated and all-gathered while the other ranges are still being computed or already consumed).  Range boundaries are multiples of
+ * every kernel's chunk (2048 SNPs) AND of what makes a bucket 4 * world floats long; a request for more buckets than M allows yields
+ * fewer (n_buckets is the number actually cut; 1 = the single message of r04).  slice_b = sum of bkt_slice = floats of B per rank;
+ * the rank's moments of bucket j start at bkt_mom[j] in its moment buffers (DP mode: [slice_b | slice_a] floats each). */
 typedef struct nadm_flat_layout {
     int64_t n_flat;                       /* floats in a flat buffer                                  */
-    int64_t off_v;                        /* V starts here (= n_small rounded up to 64)               */
+    int64_t off_v;                        /* V starts here (n_small rounded up to lcm(64, 4 * world)) */
     int64_t off_p[NADM_MAX_HEADS];        /* head h's P starts here                                   */
-    int64_t slice_b, slice_a;             /* floats per rank of message B / A                         */
-    int64_t msg_a_off;                    /* = world * slice_b                                        */
+    int64_t slice_b, slice_a;             /* floats per rank of message B (all buckets) / A           */
+    int64_t msg_a_off;                    /* where message A starts = end of the last bucket of B     */
+    int32_t n_buckets, reserved;          /* buckets message B is cut into (>= 1)                     */
+    int64_t bkt_off[NADM_MAX_BUCKETS + 1];/* bucket j = floats [bkt_off[j], bkt_off[j+1]); [n] = msg_a_off */
+    int64_t bkt_slice[NADM_MAX_BUCKETS];  /* floats per rank of bucket j                              */
+    int64_t bkt_m0[NADM_MAX_BUCKETS + 1]; /* bucket j holds the V rows of SNPs [bkt_m0[j], bkt_m0[j+1]); [n] = M */
+    int64_t bkt_mom[NADM_MAX_BUCKETS];    /* start of the rank's slice of bucket j in its B moments   */
 } nadm_flat_layout_t;
-int nadm_flat_layout(const nadm_heads_t* hd, int64_t M, int32_t world, nadm_flat_layout_t* out);
+int nadm_flat_layout(const nadm_heads_t* hd, int64_t M, int32_t world, int32_t n_buckets, nadm_flat_layout_t* out);
 
 /* Transport of the step's collectives.  The step issues them on hipStreams it names; an implementation must order its work on
  * that stream (RCCL does; a host transport synchronises the stream).  All three operate IN PLACE on float buffers:
@@ -292,11 +313,18 @@ int nadm_flat_layout(const nadm_heads_t* hd, int64_t M, int32_t world, nadm_flat
  *                               sum over ranks of that slice (the other slices are scratch)                    (ncclReduceScatter)
  *   all_gather(buf, slice):     every rank contributes its own slice; afterwards buf is complete everywhere    (ncclAllGather)
  *   all_reduce(buf, n):         sum over ranks                                                                 (ncclAllReduce)
+ *   async_error():              (may be NULL) nonzero + nadm_last_error() if a collective queued earlier has failed asynchronously
+ *                               (ncclCommGetAsyncError); nadm_plan_flush asks, and every step of a plan built with debug != 0
  * nadm_comm_rccl: a communicator of its own over RCCL / xGMI (ncclCommInitRank with `unique_id`, 128 bytes from
  * nadm_comm_rccl_unique_id on rank 0, distributed by the caller -- the reference gets its communicator from
  * init_process_group("nccl"), src/utils.py:88-93).  librccl_path: the librccl.so to dlopen (NULL: "librccl.so"); pass the path of
- * the copy already mapped into the process.  nadm_comm_emulated: rank 0 of `world` ranks with no-op collectives -- the per-rank
- * cost of a world-rank step measured on ONE GPU (bench.py --emulate-world; the run's results are meaningless). */
+ * the copy already mapped into the process.  ncclCommInitRank is itself a collective -- it returns when EVERY rank has entered it --
+ * so it runs under a watchdog: after timeout_ms (<= 0: wait forever) the call gives up with status 5 and a message naming the
+ * rank; the helper thread stays blocked inside the library, i.e. the process is expected to tear down (the reference's behaviour on
+ * any rank failure: teardown + re-raise, src/main.py:119-133).  nadm_comm_rccl_probe: dlopen + symbol resolution only -- what can
+ * fail without any other rank being involved; callers agree on its outcome BEFORE anyone enters ncclCommInitRank (comm.py).
+ * nadm_comm_emulated: rank 0 of `world` ranks with no-op collectives -- the per-rank cost of a world-rank step measured on ONE GPU
+ * (bench.py --emulate-world; the run's results are meaningless). */
 typedef struct nadm_comm {
     int32_t rank, world;
     void* ctx;
@@ -304,11 +332,15 @@ typedef struct nadm_comm {
     int (*all_gather)(void* ctx, float* buf, int64_t slice, void* stream);
     int (*all_reduce)(void* ctx, float* buf, int64_t n, void* stream);
     void (*destroy)(void* ctx);           /* may be NULL */
+    int (*async_error)(void* ctx);        /* may be NULL */
 } nadm_comm_t;
+int  nadm_comm_rccl_probe(const char* librccl_path);
 int  nadm_comm_rccl_unique_id(const char* librccl_path, void* id128);
-int  nadm_comm_rccl(const char* librccl_path, const void* id128, int32_t rank, int32_t world, nadm_comm_t** out);
+int  nadm_comm_rccl(const char* librccl_path, const void* id128, int32_t rank, int32_t world, int32_t timeout_ms, nadm_comm_t** out);
 int  nadm_comm_emulated(int32_t world, nadm_comm_t** out);
 void nadm_comm_free(nadm_comm_t* comm);
+/* ncclCommAbort instead of ncclCommDestroy: frees a communicator whose collectives may never complete (a peer is gone) */
+void nadm_comm_abort(nadm_comm_t* comm);
 
 /* How the work of a step is spread over ranks */
 #define NADM_MODE_SINGLE 0   /* one GPU: Adam + restrict_P in the epilogues of passes 2 and 3                                        */
@@ -317,8 +349,16 @@ void nadm_comm_free(nadm_comm_t* comm);
                               * 1/world slice of the parameters and ITS moments only -> all-gather of the updated parameters.  Same wire
                               * bytes as the all-reduce, optimizer traffic and Adam-moment memory / world.  Message A (all P) travels on a
                               * side stream underneath the MLP backward, pass 3 and the next step's pass 1; message B (small | V) on the
-                              * compute stream behind pass 3.  Issue order on the communicator: reduce-scatter A, reduce-scatter B,
-                              * all-gather B, all-gather A -- B, which the next pass 1 waits for, never queues behind A's all-gather */
+                              * compute stream behind pass 3 (n_buckets <= 1, the default: the next pass 1 needs all of V, nothing is left
+                              * to hide it under) or, n_buckets > 1, as SNP ranges on a second side stream: pass 3 is launched range by
+                              * range, behind each range its bucket is reduce-scattered, updated and all-gathered, and the NEXT step's
+                              * pass 1 runs as the same ranges, each waiting for its own bucket only.  What that buys is wire time hidden
+                              * under pass 3 and pass 1 (~40 us each at 800 rows); what it costs a rank is measured
+                              * (profiles/r05_rank_emulation.txt: every cross-stream hand-off is ~10 us on the GPU's timeline).  Issue order
+                              * on the communicator (identical on every rank): reduce-scatter A, then per bucket reduce-scatter B_j,
+                              * all-gather B_j, then all-gather A -- B, which the next pass 1 waits for, never queues behind A's
+                              * all-gather.  comm_a != NULL gives message A a communicator of its own: A and B then share the links
+                              * instead of queueing behind each other */
 #define NADM_MODE_SNP    2   /* SNPs sharded (8(f)-4): every rank owns M/world SNPs of X, V, P and their Adam state and processes the
                               * GLOBAL batch; two small all-reduces per step (partial Z, partial dQ), Adam in the epilogues with 1/world */
 
@@ -337,6 +377,13 @@ typedef struct nadm_plan_desc {
     uint8_t* xg;                          /* nadm_batch_copy_bytes(bmax, M) (C <= 8)                                            */
     double* loss_acc;                     /* [2]: running sum, last step                                                        */
     const nadm_comm_t* comm;              /* NULL: one rank.  Must outlive the plan                                             */
+    const nadm_comm_t* comm_a;            /* DP mode: a second communicator for message A (NULL: `comm` carries both)           */
+    int32_t n_buckets;                    /* DP mode: buckets of message B (0, 1: one message; params / grads / m / v are laid
+                                           * out by nadm_flat_layout(heads, M, world, n_buckets))                               */
+    int32_t p3_whole;                     /* DP mode, n_buckets > 1: != 0 keeps pass 3 ONE launch (the buckets' collectives then
+                                           * all start behind it; only the next pass 1 is pipelined against them)                */
+    int32_t debug;                        /* != 0: every step asks the communicators for asynchronous errors (a host call each)  */
+    int32_t reserved;                     /* 0 */
 } nadm_plan_desc_t;
 typedef struct nadm_plan nadm_plan_t;
 int  nadm_plan_create(const nadm_plan_desc_t* desc, nadm_plan_t** out);
@@ -352,9 +399,14 @@ int32_t nadm_plan_p_in_unit_range(const nadm_plan_t* plan);
 int32_t nadm_plan_step_count(const nadm_plan_t* plan);
 
 /* ONE training step on the batch rows idx[0..b) -- gather/decode, forward, loss, backward, gradient exchange, Adam, restrict_P --
- * queued on `stream` (and, in DP mode, on the plan's side stream), asynchronous.  with_loss: also add the step's loss value to
+ * queued on `stream` (and, in DP mode, on the plan's side streams), asynchronous.  with_loss: also add the step's loss value to
  * loss_acc.  The step may leave work to the NEXT step's launches (single / SNP: the small-parameter update rides in the next
- * pass 1; DP: message A completes underneath the next pass 1): nadm_plan_flush makes `stream` see every parameter final. */
+ * pass 1; DP: the messages complete underneath the next step's first launches): nadm_plan_flush makes `stream` see every
+ * parameter final (and reports a collective that failed asynchronously).
+ * A step that FAILS part-way (a refused launch, a transport error) leaves the plan POISONED: the Adam step count, the pending
+ * hand-offs and the side streams are in no defined state, and every later nadm_step / nadm_plan_flush / nadm_plan_infer on it
+ * fails fast with a message that says so.  Destroy the plan and build a new one (parameters and moments live in the caller's
+ * buffers; what the failed step did to them is undefined). */
 int  nadm_step(nadm_plan_t* plan, const int32_t* idx, int32_t b, float lr, int32_t with_loss, void* stream);
 int  nadm_plan_flush(nadm_plan_t* plan, void* stream);
 /* Encoder only (final Q, neural_admixture.py:369-383; inference.py:71-77): pass 1 + MLP forward -> Q [b, SP] */
@@ -369,10 +421,15 @@ int  nadm_plan_infer(nadm_plan_t* plan, const int32_t* idx, int32_t b, void* str
 #define NADM_T_MLP_BWD    3
 #define NADM_T_ENCODE_BWD 4
 #define NADM_T_SYNC_A     5   /* DP: message A on the side stream: from its reduce-scatter to its all-gather, which is issued behind message B (a span) */
-#define NADM_T_SYNC_B     6   /* DP: small-gradient sum + message B on the compute stream            */
+#define NADM_T_SYNC_B     6   /* DP: message B on its side stream: from the first bucket's small-gradient sum + reduce-scatter to the last bucket's all-gather (a span) */
 #define NADM_T_COUNT      7
 int  nadm_plan_timing(nadm_plan_t* plan, uint32_t mask);
 int  nadm_plan_kernel_ms(nadm_plan_t* plan, float* ms /* [NADM_T_COUNT] */, int32_t* counts /* [NADM_T_COUNT], may be NULL */);
+/* With NADM_T_SYNC_B in the mask: the mean duration [ms] of every BUCKET of message B on its side stream (reduce-scatter -> Adam ->
+ * all-gather of the range), bucket j in ms[j]; returns through *n the number of buckets.  Call before nadm_plan_kernel_ms (which
+ * clears the records). */
+int  nadm_plan_bucket_ms(nadm_plan_t* plan, float* ms /* [NADM_MAX_BUCKETS] */, int32_t* n);
+int32_t nadm_plan_poisoned(const nadm_plan_t* plan);
 
 /* ---- test hook: route nadm_mlp_fwd / nadm_mlp_bwd to the generic (any hidden width) kernels even where the register-resident
  * ones apply, so that tests can compare the two.  Process-wide; not for production use. */

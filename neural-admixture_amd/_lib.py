@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NADM_LIB") or os.path.join(_HERE, "csrc", "libnadm.so")   # NADM_LIB: another build of the same library
 
 MAX_HEADS = 32
+MAX_BUCKETS = 8
 
 
 class Heads(C.Structure):
@@ -33,17 +34,21 @@ class AdamArgs(C.Structure):
 class FlatLayout(C.Structure):
     """nadm_flat_layout_t (include/nadm.h)."""
     _fields_ = [("n_flat", C.c_int64), ("off_v", C.c_int64), ("off_p", C.c_int64 * MAX_HEADS), ("slice_b", C.c_int64),
-                ("slice_a", C.c_int64), ("msg_a_off", C.c_int64)]
+                ("slice_a", C.c_int64), ("msg_a_off", C.c_int64), ("n_buckets", C.c_int32), ("reserved", C.c_int32),
+                ("bkt_off", C.c_int64 * (MAX_BUCKETS + 1)), ("bkt_slice", C.c_int64 * MAX_BUCKETS),
+                ("bkt_m0", C.c_int64 * (MAX_BUCKETS + 1)), ("bkt_mom", C.c_int64 * MAX_BUCKETS)]
 
 
 COMM_SLICES_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)      # (ctx, buf, slice | n, stream)
 COMM_DESTROY_FN = C.CFUNCTYPE(None, C.c_void_p)
+COMM_CHECK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 
 class CommStruct(C.Structure):
     """nadm_comm_t (include/nadm.h)."""
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("ctx", C.c_void_p), ("reduce_scatter", COMM_SLICES_FN),
-                ("all_gather", COMM_SLICES_FN), ("all_reduce", COMM_SLICES_FN), ("destroy", COMM_DESTROY_FN)]
+                ("all_gather", COMM_SLICES_FN), ("all_reduce", COMM_SLICES_FN), ("destroy", COMM_DESTROY_FN),
+                ("async_error", COMM_CHECK_FN)]
 
 
 class PlanDesc(C.Structure):
@@ -52,7 +57,8 @@ class PlanDesc(C.Structure):
                 + [(n, C.c_void_p) for n in ("params", "grads", "m", "v", "zpart", "Z", "rinv", "Zn", "H", "Q", "dL", "dHpre", "dgp", "dZ",
                                              "dqpart", "losspart", "small_part", "zsum", "dqsum", "qimg")]
                 + [("qimg_head_bytes", C.c_int64), ("dzimg", C.c_void_p), ("dzcnt", C.c_void_p), ("xg", C.c_void_p), ("loss_acc", C.c_void_p),
-                   ("comm", C.POINTER(CommStruct))])
+                   ("comm", C.POINTER(CommStruct)), ("comm_a", C.POINTER(CommStruct)), ("n_buckets", C.c_int32), ("p3_whole", C.c_int32),
+                   ("debug", C.c_int32), ("reserved", C.c_int32)])
 
 
 MODE_SINGLE, MODE_DP, MODE_SNP = 0, 1, 2
@@ -88,6 +94,7 @@ def _load():
         "nadm_bed_to_packed": (C.c_int, [vp, i64, i64, vp, i64, C.POINTER(i64), i32, C.POINTER(i32)]),
         "nadm_bed_to_packed_dev": (C.c_int, [vp, i64, i64, vp, i64, vp, i32, vp, vp]),
         "nadm_encode_fwd": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp]),
+        "nadm_encode_fwd_part": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i64, vp]),
         "nadm_pca_project": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp]),
         "nadm_pca_project_t": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, i32, vp, vp]),
         "nadm_loglik_blocks": (i64, [i64]),
@@ -116,11 +123,13 @@ def _load():
         "nadm_vcf_parse_gt": (C.c_int, [C.c_char_p, i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]),
         "nadm_adam": (C.c_int, [vp, vp, vp, vp, i64, i64, f32, i32, f32, vp]),
         "nadm_synth_packed": (C.c_int, [vp, i64, i64, i64, i64, vp, vp, i32, f32, u64, vp]),
-        "nadm_flat_layout": (C.c_int, [HP, i64, i32, C.POINTER(FlatLayout)]),
+        "nadm_flat_layout": (C.c_int, [HP, i64, i32, i32, C.POINTER(FlatLayout)]),
+        "nadm_comm_rccl_probe": (C.c_int, [C.c_char_p]),
         "nadm_comm_rccl_unique_id": (C.c_int, [C.c_char_p, vp]),
-        "nadm_comm_rccl": (C.c_int, [C.c_char_p, vp, i32, i32, C.POINTER(C.POINTER(CommStruct))]),
+        "nadm_comm_rccl": (C.c_int, [C.c_char_p, vp, i32, i32, i32, C.POINTER(C.POINTER(CommStruct))]),
         "nadm_comm_emulated": (C.c_int, [i32, C.POINTER(C.POINTER(CommStruct))]),
         "nadm_comm_free": (None, [C.POINTER(CommStruct)]),
+        "nadm_comm_abort": (None, [C.POINTER(CommStruct)]),
         "nadm_plan_create": (C.c_int, [C.POINTER(PlanDesc), C.POINTER(vp)]),
         "nadm_plan_destroy": (None, [vp]),
         "nadm_plan_set_rows": (C.c_int, [vp, vp]),
@@ -133,13 +142,15 @@ def _load():
         "nadm_plan_infer": (C.c_int, [vp, vp, i32, vp]),
         "nadm_plan_timing": (C.c_int, [vp, C.c_uint32]),
         "nadm_plan_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(i32)]),
+        "nadm_plan_bucket_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(i32)]),
+        "nadm_plan_poisoned": (i32, [vp]),
         "nadm_test_force_generic_mlp": (None, [i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.nadm_abi_version() != 9:
+    if lib.nadm_abi_version() != 10:
         raise RuntimeError("neural_admixture_amd: libnadm.so ABI version mismatch")
     return lib, tuple(sig)
 

@@ -13,11 +13,12 @@ bytes:
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional
 
 import torch
 
-from ._lib import lib, check, CommStruct, COMM_SLICES_FN, COMM_DESTROY_FN
+from ._lib import lib, check, CommStruct, COMM_SLICES_FN, COMM_DESTROY_FN, COMM_CHECK_FN
 
 
 class Comm:
@@ -59,34 +60,93 @@ class Comm:
 
 def loaded_librccl() -> Optional[bytes]:
     """Path of the librccl.so already mapped into this process (torch's own copy), so that the library's communicator and
-    torch's share one RCCL; None: let the loader search."""
+    torch's share one RCCL; None: let the loader search.  Only ``librccl.so`` / ``librccl.so.<version>`` count -- a plugin such
+    as librccl-net.so has none of the symbols."""
     try:
         with open("/proc/self/maps") as f:
             for line in f:
-                if "librccl" in line:
-                    return line.split(None, 5)[-1].strip().encode()
+                fields = line.split(None, 5)
+                if len(fields) < 6:
+                    continue
+                path = fields[5].strip()
+                base = os.path.basename(path)
+                if base == "librccl.so" or base.startswith("librccl.so."):
+                    return path.encode()
     except OSError:
         pass
     return None
 
 
-def rccl_comm(rank: int, world: int, group=None, device: Optional[torch.device] = None) -> Comm:
+class CommUnavailable(RuntimeError):
+    """The library's own communicator cannot come up, and every rank knows it BEFORE any of them entered ncclCommInitRank: falling
+    back to another transport is safe (make_comm does)."""
+
+
+class CommInitFailed(RuntimeError):
+    """ncclCommInitRank failed or timed out on some rank.  Every rank raises this (the same list of ranks in the message); a rank
+    whose call never returned has a helper thread stuck inside the library -- tear the process down, do not fall back."""
+
+
+def init_timeout_s() -> float:
+    """Deadline of ncclCommInitRank's watchdog: NADM_COMM_TIMEOUT_S, default 120 s (first contact over xGMI takes seconds)."""
+    try:
+        return float(os.environ.get("NADM_COMM_TIMEOUT_S", "120"))
+    except ValueError:
+        return 120.0
+
+
+def rccl_comm(rank: int, world: int, group=None, device: Optional[torch.device] = None, librccl: Optional[bytes] = None,
+              timeout_s: Optional[float] = None) -> Comm:
     """One RCCL communicator over the ranks of ``group`` (default group; world = 1 needs no torch.distributed), for the GPU
-    ``device`` (default: the current one) -- ncclCommInitRank binds the communicator to the HIP device that is current."""
+    ``device`` (default: the current one) -- ncclCommInitRank binds the communicator to the HIP device that is current.
+
+    ncclCommInitRank is itself a collective, so first contact is a little protocol in which no rank ever waits for a peer that has
+    already given up (the reference tears everything down and re-raises on the master when a rank fails, src/main.py:119-133):
+      1. every rank loads the library and resolves its symbols (``nadm_comm_rccl_probe``); rank 0 draws the unique id
+      2. the id is broadcast -- by every rank, whatever happened in 1 (a rank 0 that failed sends None)
+      3. the ranks exchange what they have; unless ALL are ready every rank raises ``CommUnavailable`` -- nobody has entered the
+         collective call yet
+      4. ncclCommInitRank under a watchdog (``timeout_s``; csrc/nadm_step.hip): a peer that dies now costs the others the timeout,
+         not forever
+      5. the ranks exchange the outcome; unless ALL succeeded every rank aborts what it got and raises ``CommInitFailed``
+    ``librccl``: another library with the same seven entry points (tests: a stub whose ncclCommInitRank fails or hangs)."""
     if device is not None and device.type == "cuda":
         with torch.cuda.device(device):
-            return rccl_comm(rank, world, group)
-    path = loaded_librccl()
+            return rccl_comm(rank, world, group, None, librccl, timeout_s)
+    path = librccl if librccl is not None else loaded_librccl()
+    timeout_ms = int(1000 * (init_timeout_s() if timeout_s is None else timeout_s))
     uid = (C.c_char * 128)()
-    if rank == 0:
-        check(lib.nadm_comm_rccl_unique_id(path, uid), "comm_rccl_unique_id")
+    err = None
+    if lib.nadm_comm_rccl_probe(path):
+        err = (lib.nadm_last_error() or b"").decode()
+    elif rank == 0 and lib.nadm_comm_rccl_unique_id(path, uid):
+        err = (lib.nadm_last_error() or b"").decode()
     if world > 1:
         import torch.distributed as dist
-        box = [bytes(uid.raw) if rank == 0 else None]
+        box = [bytes(uid.raw) if (rank == 0 and err is None) else None]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        states = [None] * world
+        dist.all_gather_object(states, err, group=group)
+        bad = {r: e for r, e in enumerate(states) if e is not None}
+        if bad or box[0] is None:
+            raise CommUnavailable(f"RCCL transport not available on every rank (rank: reason) {bad}")
         uid = (C.c_char * 128).from_buffer_copy(box[0])
+    elif err is not None:
+        raise CommUnavailable(err)
     out = C.POINTER(CommStruct)()
-    check(lib.nadm_comm_rccl(path, uid, rank, world, C.byref(out)), "comm_rccl")
+    rc = lib.nadm_comm_rccl(path, uid, rank, world, timeout_ms, C.byref(out))
+    msg = (lib.nadm_last_error() or b"").decode() if rc else None
+    if world > 1:
+        import torch.distributed as dist
+        states = [None] * world
+        dist.all_gather_object(states, msg, group=group)
+        bad = {r: e for r, e in enumerate(states) if e is not None}
+        if bad:
+            if rc == 0:
+                lib.nadm_comm_abort(out)                 # (ncclCommAbort: its peers are gone or never arrived)
+            raise CommInitFailed(f"ncclCommInitRank did not complete on every rank (rank: reason) {bad}")
+    elif rc:
+        raise CommInitFailed(msg)
     return Comm(out, rank, world, "rccl")
 
 
@@ -148,7 +208,7 @@ def torch_comm(rank: int, world: int, group=None) -> Comm:
     ``comm.transport.buffers.append(tensor)`` (Engine does)."""
     tr = _TorchTransport(rank, world, group)
     cbs = (COMM_SLICES_FN(tr.reduce_scatter), COMM_SLICES_FN(tr.all_gather), COMM_SLICES_FN(tr.all_reduce))
-    st = CommStruct(rank, world, None, cbs[0], cbs[1], cbs[2], COMM_DESTROY_FN())
+    st = CommStruct(rank, world, None, cbs[0], cbs[1], cbs[2], COMM_DESTROY_FN(), COMM_CHECK_FN())
     c = Comm(C.pointer(st), rank, world, "torch", owned=False, keep=(st, cbs, tr))
     c.transport = tr
     return c
@@ -156,25 +216,19 @@ def torch_comm(rank: int, world: int, group=None) -> Comm:
 
 def make_comm(device: torch.device, rank: int, world: int, group=None) -> Comm:
     """The transport for this process: RCCL when the ranks sit on different GPUs behind an nccl process group (or there is one
-    rank), torch.distributed callbacks otherwise.  Should the library's own communicator fail to come up on ANY rank (librccl not
-    loadable, ncclCommInitRank refused), every rank falls back to the callbacks over the process group together -- slower (the
-    reduce-scatter becomes an all-reduce, every collective a host call) but running; ``Comm.kind`` says which one is in use."""
+    rank), torch.distributed callbacks otherwise.  Should the library's own communicator be unavailable on ANY rank (librccl not
+    loadable, a symbol missing, no unique id), every rank learns so before anyone enters ncclCommInitRank (``rccl_comm``) and all fall
+    back to the callbacks over the process group together -- slower (the reduce-scatter becomes an all-reduce, every collective a host
+    call) but running; ``Comm.kind`` says which one is in use.  A failure INSIDE ncclCommInitRank is not papered over: every rank
+    raises ``CommInitFailed``.  Call it again for a second communicator (message A, ``Engine(comm_a=...)``)."""
     import torch.distributed as dist
     if world == 1:
         return rccl_comm(0, 1, device=device) if device.type == "cuda" else torch_comm(0, 1, group)
     if device.type == "cuda" and dist.get_backend(group) == "nccl":
-        comm, err = None, None
         try:
-            comm = rccl_comm(rank, world, group, device=device)
-        except Exception as e:                                  # noqa: BLE001 -- whatever it was, the ranks must agree on what happens next
-            err = e
-        ok = torch.tensor([0.0 if comm is None else 1.0], device=device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if float(ok.item()) == 1.0:
-            return comm
-        if comm is not None:
-            comm.close()
-        import sys
-        print(f"[neural_admixture_amd] the step's own RCCL communicator is not available on every rank ({err!r}): "
-              "falling back to torch.distributed callbacks", file=sys.stderr)
+            return rccl_comm(rank, world, group, device=device)
+        except CommUnavailable as e:
+            import sys
+            print(f"[neural_admixture_amd] the step's own RCCL communicator is not available ({e}): "
+                  "falling back to torch.distributed callbacks", file=sys.stderr)
     return torch_comm(rank, world, group)

@@ -1575,7 +1575,7 @@ static int enc_rows_per_block(int b) {
 
 static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                            const float* V, int32_t CP, float* zpart, void* stream, uint32_t missing_bf16,
-                           SmallSide ss = SmallSide{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f}) {
+                           SmallSide ss = SmallSide{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f}, int64_t total_chunks = 0) {
     if (!xp || !idx || !V || !zpart) return fail("nadm_encode_fwd: null pointer");
     if (b <= 0 || M <= 0) return fail("nadm_encode_fwd: empty batch or M");
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_encode_fwd: ld must be a multiple of 16 and >= ceil(M/4)");
@@ -1604,10 +1604,12 @@ static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
             return 0.45 + 0.72 * x;
         };
         const double slots = 2.0 * (double)device_cu_count();
+        // (a launch that is one PART of a pass shares the device with the other parts: the split is the whole pass's, nadm_encode_fwd_part)
+        const int64_t fill_chunks = total_chunks > chunks ? total_chunks : chunks;
         int64_t gy = 1;
         double best = 1e30;
         for (int64_t g = 1; g <= 64 && g <= (ntiles + 3) / 4; ++g) {
-            const double cost = rounds_eff((double)(chunks * g) / slots) * (11.3 + (double)((ntiles + g - 1) / g));
+            const double cost = rounds_eff((double)(fill_chunks * g) / slots) * (11.3 + (double)((ntiles + g - 1) / g));
             if (cost < best) { best = cost; gy = g; }
         }
         int tpb = (int)((ntiles + gy - 1) / gy);
@@ -1661,6 +1663,11 @@ static int adam_fused_args(const nadm_adam_t* adam, const char* who, AdamFused* 
 extern "C" int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                                const float* V, int32_t CP, float* zpart, void* stream) {
     return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0u);
+}
+
+extern "C" int nadm_encode_fwd_part(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                                    const float* V, int32_t CP, float* zpart, int64_t total_chunks, void* stream) {
+    return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0u, SmallSide{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f}, total_chunks);
 }
 
 extern "C" int nadm_encode_fwd_small(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,

@@ -10,6 +10,7 @@
 // Built by __graft_entry__.build() into neural-admixture_amd/csrc/ext/_pack2bit.so; neural_admixture_amd.pack2bit imports it.
 #include <torch/extension.h>
 #include <torch/cuda.h>
+#include <c10/core/DeviceGuard.h>
 #include <algorithm>
 
 extern "C" {
@@ -59,6 +60,7 @@ void unpack2bit_gpu_to_gpu(torch::Tensor input_gpu, torch::Tensor output_gpu) {
     TORCH_CHECK(input_gpu.size(1) == packed_cols, "Input tensor column dimension mismatch based on output shape");
     TORCH_CHECK(output_gpu.is_contiguous(), "Output tensor must be contiguous");
     if (N == 0 || M == 0) return;
+    const c10::DeviceGuard on_device(output_gpu.device());      // the launch goes to the tensors' device, whichever one is current
     const torch::Tensor src = input_gpu.contiguous();           // a DataLoader batch of gathered rows is contiguous already
     torch::cuda::synchronize(output_gpu.device().index());      // whatever produced the batch on torch's streams is complete ...
     TORCH_CHECK(nadm_unpack2bit(src.data_ptr<uint8_t>(), output_gpu.data_ptr<uint8_t>(), N, M, packed_cols, /*stream=*/nullptr) == 0,

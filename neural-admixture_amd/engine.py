@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from ._lib import lib, check, ptr, PlanDesc, MODE_SINGLE, MODE_DP, MODE_SNP, T_NAMES
+from ._lib import lib, check, ptr, PlanDesc, MODE_SINGLE, MODE_DP, MODE_SNP, T_NAMES, MAX_BUCKETS
 from .layout import ModelLayout
 
 _f32 = torch.float32
@@ -42,16 +42,20 @@ class Engine:
     _CPU_TEST_DOUBLE = False
 
     def __init__(self, M: int, C_: int, Hd: int, ks: Sequence[int], device: torch.device, max_batch: int,
-                 mode: str = "single", comm=None):
+                 mode: str = "single", comm=None, n_buckets: int = 1, comm_a=None, p3_whole: bool = False, debug: bool = False):
         if device.type != "cuda" and not self._CPU_TEST_DOUBLE:
             raise RuntimeError("neural_admixture_amd.Engine needs a ROCm GPU device (no CPU fallback)")
         if mode not in _MODES:
             raise ValueError("mode must be 'single', 'dp' or 'snp'")
         if mode == "single" and comm is not None and comm.world != 1:
             raise ValueError("mode 'single' with a communicator of several ranks")
-        self.device, self.mode, self.comm = device, mode, comm
+        if comm_a is not None and (mode != "dp" or comm is None):
+            raise ValueError("comm_a is the second communicator (message A) of mode 'dp'")
+        self.device, self.mode, self.comm, self.comm_a = device, mode, comm, comm_a
+        self.p3_whole, self.debug = bool(p3_whole), bool(debug)
         self.world, self.rank = (comm.world, comm.rank) if comm is not None else (1, 0)
-        self.lay = L = ModelLayout(M, C_, Hd, ks, self.world if mode == "dp" else 1)
+        # "dp": message B = [small | V] travels as n_buckets SNP ranges (csrc/nadm_step.hip); the layout says how many M allows
+        self.lay = L = ModelLayout(M, C_, Hd, ks, self.world if mode == "dp" else 1, n_buckets if mode == "dp" else 1)
         self.M, self.ld = L.M, ModelLayout.row_stride(L.M)
         self.bmax = b = int(max_batch)
         z = lambda n, dt=_f32: torch.zeros(int(n), dtype=dt, device=device)
@@ -108,9 +112,12 @@ class Engine:
                         ("dzimg", self._dzimg), ("dzcnt", self._dzcnt), ("xg", self._xg), ("loss_acc", self.loss_acc)):
             setattr(d, name, None if t is None else t.data_ptr())
         d.qimg_head_bytes = self._qimg_head
-        if self.comm is not None:
-            d.comm = self.comm.handle
-            tr = getattr(self.comm, "transport", None)
+        d.n_buckets, d.p3_whole, d.debug = L.n_buckets, int(self.p3_whole), int(self.debug)
+        for c, field in ((self.comm, "comm"), (self.comm_a, "comm_a")):
+            if c is None:
+                continue
+            setattr(d, field, c.handle)
+            tr = getattr(c, "transport", None)
             if tr is not None:                             # torch.distributed callbacks: the buffers the step communicates
                 tr.buffers += [t for t in (self.pflat, self.gflat, self._zsum, self._dqsum) if t is not None]
         plan = C.c_void_p()
@@ -126,10 +133,11 @@ class Engine:
                 pass
 
     def _comm_error(self):
-        tr = getattr(self.comm, "transport", None)
-        if tr is not None and tr.error is not None:
-            e, tr.error = tr.error, None
-            raise e
+        for c in (self.comm, self.comm_a):
+            tr = getattr(c, "transport", None)
+            if tr is not None and tr.error is not None:
+                e, tr.error = tr.error, None
+                raise e
 
     def train_step(self, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True) -> None:
         """One training step on the batch rows idx (int32 [b], device): ONE C call (neural_admixture.py:403-414 without the
@@ -141,6 +149,7 @@ class Engine:
             check(1, "step")
         self._qimg_b = self._dzimg_b = -1
         self._xg_key = None
+        self._dz_last_b = b                              # (the plan's step wrote the image of dZ for this batch size: the plain phases' hygiene sees it)
 
     def sync(self) -> None:
         """Make the current stream see every parameter final: a step may leave its small-parameter update to the next step's
@@ -154,10 +163,16 @@ class Engine:
         check(lib.nadm_plan_timing(self._plan, mask), "plan_timing")
 
     def kernel_ms(self) -> Dict[str, float]:
-        """Mean duration [ms] of every timed group since the last call (synchronises)."""
+        """Mean duration [ms] of every timed group since the last call (synchronises).  With "sync_b" timed in "dp" mode also
+        ``sync_b_buckets``: the list of per-bucket means (reduce-scatter -> Adam -> all-gather of each SNP range)."""
         ms, cnt = (C.c_float * len(T_NAMES))(), (C.c_int32 * len(T_NAMES))()
+        bms, nb = (C.c_float * MAX_BUCKETS)(), C.c_int32(0)
+        check(lib.nadm_plan_bucket_ms(self._plan, bms, C.byref(nb)), "plan_bucket_ms")
         check(lib.nadm_plan_kernel_ms(self._plan, ms, cnt), "plan_kernel_ms")
-        return {n: float(ms[i]) for i, n in enumerate(T_NAMES) if cnt[i]}
+        out = {n: float(ms[i]) for i, n in enumerate(T_NAMES) if cnt[i]}
+        if "sync_b" in out:
+            out["sync_b_buckets"] = [float(bms[j]) for j in range(nb.value)]
+        return out
 
     # step count and "every P entry lies in [0, 1]" live in the plan; the plain phases below read and advance them too
     def _get_step(self):

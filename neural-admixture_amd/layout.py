@@ -8,6 +8,8 @@ big   = flat[off_v:]  (V and every P; ``p_off`` / ``clamp_from`` below are offse
 The reference keeps the same tensors as separate nn.Parameters (Q_P, neural_admixture.py:100-150); one flat buffer makes the
 sample-sharded step's gradient exchange two messages -- B = [small | V], A = [all P] -- each cut into ``world`` equal slices
 (reduce-scatter -> optimizer on the own slice -> all-gather); the gaps (zeros, world = 1: none) make the cuts come out even.
+Message B travels as ``n_buckets`` SNP ranges (``bkt_*``: bucket j = flat[bkt_off[j]:bkt_off[j+1]] = V's rows of the SNPs
+[bkt_m0[j], bkt_m0[j+1]), bucket 0 with the small parameters in front; every bucket is ``world`` slices of its own).
 """
 import ctypes as C
 from typing import List, Sequence
@@ -16,7 +18,7 @@ from ._lib import lib, Heads, FlatLayout, check
 
 
 class ModelLayout:
-    def __init__(self, M: int, C_: int, Hd: int, ks: Sequence[int], world: int = 1):
+    def __init__(self, M: int, C_: int, Hd: int, ks: Sequence[int], world: int = 1, n_buckets: int = 1):
         ks = sorted(int(k) for k in ks)
         self.M, self.C, self.Hd, self.ks, self.world = int(M), int(C_), int(Hd), ks, int(world)
         self.heads = Heads()
@@ -27,9 +29,14 @@ class ModelLayout:
         self.kp: List[int] = [h.kp[i] for i in range(len(ks))]
         self.qoff: List[int] = [h.qoff[i] for i in range(len(ks))]
         fl = FlatLayout()
-        check(lib.nadm_flat_layout(C.byref(self.heads), self.M, self.world, C.byref(fl)), "flat_layout")
+        check(lib.nadm_flat_layout(C.byref(self.heads), self.M, self.world, int(n_buckets), C.byref(fl)), "flat_layout")
         self.n_flat, self.off_v = int(fl.n_flat), int(fl.off_v)
         self.slice_b, self.slice_a, self.msg_a_off = int(fl.slice_b), int(fl.slice_a), int(fl.msg_a_off)
+        nb = self.n_buckets = int(fl.n_buckets)                    # the number actually cut (M may allow fewer than asked for)
+        self.bkt_off: List[int] = [int(fl.bkt_off[j]) for j in range(nb + 1)]
+        self.bkt_slice: List[int] = [int(fl.bkt_slice[j]) for j in range(nb)]
+        self.bkt_m0: List[int] = [int(fl.bkt_m0[j]) for j in range(nb + 1)]
+        self.bkt_mom: List[int] = [int(fl.bkt_mom[j]) for j in range(nb)]
         self.v_off = 0
         self.p_off: List[int] = [int(fl.off_p[i]) - self.off_v for i in range(len(ks))]     # into big = flat[off_v:]
         self.n_big = self.n_flat - self.off_v

@@ -187,6 +187,12 @@ class NeuralAdmixture:
     """Trainer mirror (constructor signature of neural_admixture.py:248-249)."""
     engine_cls = Engine          # tests swap in an oracle-backed double to run the multi-rank logic on gloo / CPU
     engine_snp_cls = None        # set below (import cycle): snp_parallel.SnpShardedEngine
+    # sample-sharded runs (csrc/nadm_step.hip): SNP ranges message B = [small | V] travels in (DDP's buckets, neural_admixture.py:315-319;
+    # 1 = one message on the compute stream: on a rank's own timeline every further bucket costs more than the ~40 us of pass 3 /
+    # pass 1 it can hide wire time under, profiles/r05_rank_emulation.txt -- a switch for the first multi-GPU node, like the next one),
+    # and whether message A = [all P] gets a communicator of its own (A and B then share the links instead of queueing)
+    dp_buckets = 1
+    dp_second_comm = False
 
     def __init__(self, k, epochs, batch_size, learning_rate, device, seed, num_gpus, master, pack2bit=None,
                  min_k=None, max_k=None, supervised_loss_weight=100, loss_mode: str = "logged", parallelism: str = "dp"):
@@ -226,7 +232,8 @@ class NeuralAdmixture:
             # the step's collectives: RCCL over xGMI behind an nccl process group, torch.distributed callbacks otherwise (comm.py)
             from .comm import make_comm
             eng = self.engine_cls(M, C, hidden_size, self.ks_list, dev, max(self.batch_size, infer_b), mode="dp",
-                                  comm=make_comm(dev, rank, world))
+                                  comm=make_comm(dev, rank, world), n_buckets=self.dp_buckets,
+                                  comm_a=make_comm(dev, rank, world) if self.dp_second_comm else None)
         else:
             eng = self.engine_cls(M, C, hidden_size, self.ks_list, dev, max(self.batch_size, infer_b))
         self.engine = eng

@@ -6,7 +6,7 @@ batch loop, the final-Q gather, the flat parameter layout with its per-rank slic
 numpy oracle's kernels, following the plan of nadm_step line by line:
 
   dp   forward, backward -> message A = [all P]: sum over ranks, Adam + restrict_P with 1/world on THIS rank's slice and its own
-       moments, all-gather of the parameters -> the same for message B = [small | V]                  (NADM_MODE_DP)
+       moments, all-gather of the parameters -> the same for every bucket of message B = [small | V]  (NADM_MODE_DP)
   snp  partial Z summed over ranks -> MLP forward -> pass 2 on the slice -> partial dQ summed -> MLP backward -> pass 3 on the
        slice -> Adam with 1/world on the slice                                                         (NADM_MODE_SNP)
 
@@ -115,9 +115,10 @@ class OracleEngine(Engine):
         assert self.mode == "dp"
         t = self.step_count + 1
         mom_a = L.slice_b if self.moments_sharded else L.msg_a_off + self.rank * L.slice_a
-        mom_b = 0 if self.moments_sharded else self.rank * L.slice_b
         self._sync_message(L.msg_a_off, L.slice_a, mom_a, True, lr, t)
-        self._sync_message(0, L.slice_b, mom_b, False, lr, t)
+        for j in range(L.n_buckets):                       # message B, bucket by bucket: V's SNP range j (bucket 0: small in front)
+            mom = L.bkt_mom[j] if self.moments_sharded else L.bkt_off[j] + self.rank * L.bkt_slice[j]
+            self._sync_message(L.bkt_off[j], L.bkt_slice[j], mom, False, lr, t)
         self._set_state(t, True)
 
 

@@ -395,6 +395,9 @@ if __name__ == "__main__":
         "one_step_k7_h1024": lambda: one_step_case("one_step_k7_h1024", 56, 1021, [7], 1024, 8, seed=9),
         "long_horizon": case_long_horizon,                 # r04: the default 250-epoch horizon (demo) and 60 epochs of the multibatch miniature
         "one_step_heads2to10": lambda: one_step_case("one_step_heads2to10", 40, 613, list(range(2, 11)), 256, 8, seed=10),
+        # r05: configs[4]'s model shape (K = 16: the two-k-slot variant of pass 2, 7 MFMAs per tile) and the smallest K that uses it
+        "one_step_k16_h1024": lambda: one_step_case("one_step_k16_h1024", 48, 1021, [16], 1024, 8, seed=11),
+        "one_step_k9": lambda: one_step_case("one_step_k9", 64, 509, [9], 64, 8, seed=12),
     }
     for name in (sys.argv[1:] or list(cases)):            # no arguments: every fixture; else only the named cases
         cases[name]()

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in nadm.h but not exported"
     assert declared == set(_lib.EXPORTS)               # the Python binding covers the whole header
-    assert _lib.lib.nadm_abi_version() == 9
+    assert _lib.lib.nadm_abi_version() == 10
 
 
 def test_argument_validation_without_gpu():
@@ -145,8 +145,9 @@ def test_flat_layout_cuts_both_messages_into_world_equal_slices(M, ks, world):
     parameters and V, message A = [msg_a_off, n_flat) every head's P; slices are 16-byte multiples; world = 1 has no gaps."""
     from neural_admixture_amd.layout import ModelLayout
     L = ModelLayout(M, 8, 64, ks, world)
-    assert L.off_v % 64 == 0 and L.off_v >= L.n_small
+    assert L.off_v % 64 == 0 and L.off_v % (4 * world) == 0 and L.n_small <= L.off_v < L.n_small + 64 * 4 * world
     assert L.slice_b % 4 == 0 and L.slice_a % 4 == 0
+    assert L.n_buckets == 1 and L.bkt_off == [0, L.msg_a_off] and L.bkt_slice == [L.slice_b] and L.bkt_m0 == [0, M] and L.bkt_mom == [0]
     assert L.msg_a_off == world * L.slice_b and L.n_flat == L.msg_a_off + world * L.slice_a
     assert L.msg_a_off >= L.off_v + M * L.CP                               # V ends inside message B
     assert L.off_v + L.p_off[0] == L.msg_a_off                             # the first P starts message A
@@ -158,7 +159,35 @@ def test_flat_layout_cuts_both_messages_into_world_equal_slices(M, ks, world):
     if world == 1:
         assert L.n_flat == L.off_v + M * L.CP + sum(M * kp for kp in L.kp) and L.clamp_from == M * L.CP
     L1 = ModelLayout(M, 8, 64, ks, 1)
-    assert L.off_v == L1.off_v and L.n_small == L1.n_small                 # the small parameters and V start where they always do
+    assert L.n_small == L1.n_small and (L.off_v == L1.off_v or 64 % (4 * world))   # V starts where it always does unless the slices need a wider pad
+
+
+@pytest.mark.parametrize("M,C_,world,nb", [(500_000, 8, 8, 4), (500_000, 8, 1, 4), (1_000_000, 8, 8, 8), (600_000, 8, 3, 4), (20_000, 3, 2, 4),
+                                             (8451, 8, 2, 4), (509, 8, 4, 2), (100_000, 8, 5, 3), (4096, 8, 2, 8)])
+def test_flat_layout_cuts_message_b_into_range_major_buckets(M, C_, world, nb):
+    """r05: message B = [small | V] as SNP-range buckets -- every bucket `world` contiguous slices (16-byte multiples), boundaries on
+    every pass's chunk (2048 SNPs), bucket 0 carries the small parameters, the buckets tile [0, msg_a_off) without holes, V stays ONE
+    contiguous [M, CP] array, and everything outside message B is where the one-bucket layout has it."""
+    from neural_admixture_amd.layout import ModelLayout
+    L = ModelLayout(M, C_, 64, [3], world, nb)
+    L1 = ModelLayout(M, C_, 64, [3], world, 1)
+    n = L.n_buckets
+    assert 1 <= n <= nb and (n == nb or M < nb * 2048 * world)              # fewer only where M does not hold that many ranges
+    for f in ("n_flat", "off_v", "msg_a_off", "slice_a", "slice_b", "p_off", "n_small"):
+        assert getattr(L, f) == getattr(L1, f), f                          # the cut changes nothing else
+    assert L.bkt_off[0] == 0 and L.bkt_off[n] == L.msg_a_off and L.bkt_m0[0] == 0 and L.bkt_m0[n] == M
+    mom = 0
+    for j in range(n):
+        lo, hi = L.bkt_off[j], L.bkt_off[j + 1]
+        assert hi > lo and (hi - lo) == world * L.bkt_slice[j] and L.bkt_slice[j] % 4 == 0
+        assert L.bkt_mom[j] == mom
+        mom += L.bkt_slice[j]
+        assert L.bkt_m0[j] < L.bkt_m0[j + 1]
+        if j > 0:
+            assert L.bkt_m0[j] % 2048 == 0 and lo == L.off_v + L.bkt_m0[j] * L.CP     # a range starts on a chunk of every pass, at its V rows
+    assert mom == L.slice_b
+    sizes = [L.bkt_m0[j + 1] - L.bkt_m0[j] for j in range(n)]
+    assert max(sizes) - min(sizes) <= 2 * 2048 * world                     # ranges of about equal length
 
 
 def test_plan_and_transport_entry_points_validate_their_arguments():
@@ -183,6 +212,37 @@ def test_plan_and_transport_entry_points_validate_their_arguments():
     assert lib.nadm_plan_create(C.byref(d), C.byref(plan)) != 0 and b"head table" in lib.nadm_last_error()
     assert lib.nadm_step(None, None, 1, 1e-3, 1, None) != 0 and b"null pointer" in lib.nadm_last_error()
     assert lib.nadm_plan_step_count(None) == -1
+
+
+def test_a_step_that_fails_part_way_poisons_its_plan():
+    """nadm_step advances the Adam step count, clears hand-offs and forks streams before launches that can fail.  Nothing
+    is unwound; the plan is marked instead and every later call on it fails fast and says why.  Here (no GPU) the first launch is
+    refused; argument errors are caught before anything is touched and do not poison."""
+    import ctypes as C
+    from neural_admixture_amd._lib import lib, PlanDesc
+    from neural_admixture_amd.layout import ModelLayout
+    if torch.cuda.is_available():
+        pytest.skip("needs a box WITHOUT a GPU: the test relies on the launch being refused")
+    L = ModelLayout(4096, 8, 64, [3])
+    d = PlanDesc()
+    d.mode, d.bmax, d.M, d.ld, d.heads = 0, 16, L.M, ModelLayout.row_stride(L.M), L.heads
+    buf = np.zeros(1 << 20, dtype=np.float32)                 # stands in for every buffer: nothing is ever launched on it
+    for n in ("params", "grads", "m", "v", "zpart", "Z", "rinv", "Zn", "H", "Q", "dL", "dHpre", "dgp", "dZ", "dqpart", "losspart", "small_part",
+              "qimg", "dzimg", "dzcnt", "xg", "loss_acc", "xp"):
+        setattr(d, n, buf.ctypes.data)
+    plan = C.c_void_p()
+    assert lib.nadm_plan_create(C.byref(d), C.byref(plan)) == 0
+    idx = np.arange(16, dtype=np.int32)
+    assert lib.nadm_step(plan, idx.ctypes.data, 99, 1e-3, 1, None) != 0 and b"batch size" in lib.nadm_last_error()
+    assert lib.nadm_plan_poisoned(plan) == 0                  # refused before anything was touched
+    assert lib.nadm_step(plan, idx.ctypes.data, 16, 1e-3, 1, None) != 0 and b"launch failed" in lib.nadm_last_error()
+    assert lib.nadm_plan_poisoned(plan) == 1
+    for call in (lambda: lib.nadm_step(plan, idx.ctypes.data, 16, 1e-3, 1, None), lambda: lib.nadm_plan_flush(plan, None),
+                 lambda: lib.nadm_plan_infer(plan, idx.ctypes.data, 16, None)):
+        assert call() == 6 and b"failed part-way" in lib.nadm_last_error()
+    lib.nadm_plan_destroy(plan)
+    d.reserved = 1
+    assert lib.nadm_plan_create(C.byref(d), C.byref(plan)) != 0 and b"reserved" in lib.nadm_last_error()
 
 
 def test_initial_weights_match_reference_rng_stream():

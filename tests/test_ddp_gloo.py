@@ -129,11 +129,14 @@ def _wN_worker(rank, world, port, out_path, parallelism, N, M, K, Hd, batch, epo
     from fake_engine import OracleEngine, OracleSnpEngine
     na.NeuralAdmixture.engine_cls = OracleEngine
     na.NeuralAdmixture.engine_snp_cls = OracleSnpEngine
+    na.NeuralAdmixture.dp_buckets = 4
     G, V0, P0 = _wN_inputs(N, M, K)
     tr = na.NeuralAdmixture(K, epochs, batch, 2e-3, torch.device("cpu"), seed, world, rank == 0, None, None, None,
                             loss_mode="always", parallelism=parallelism)
     assert tr.batch_size == batch // world                   # neural_admixture.py:287
     Qs, Ps, model = tr.launch_training(torch.from_numpy(P0), torch.from_numpy(G), Hd, 8, torch.from_numpy(V0), M, N, None)
+    if parallelism == "dp":                                  # message B in as many SNP ranges as M holds (4 asked for; 2048 SNPs each at least)
+        assert tr.engine.lay.n_buckets == min(na.NeuralAdmixture.dp_buckets, (M + 2047) // 2048)
     if rank == 0:
         np.savez(out_path, Q=Qs[0], P=Ps[0], V=model.state_dict()["V"].numpy(),
                  losses=np.asarray([tr.epoch_losses[e] for e in range(epochs)]))
@@ -152,15 +155,16 @@ def _wN_inputs(N, M, K):
     return G, V0, P0
 
 
-@pytest.mark.parametrize("world,parallelism", [(4, "dp"), (8, "dp"), (8, "snp")])
-def test_global_batch_800_over_4_and_8_ranks(tmp_path, world, parallelism):
+@pytest.mark.parametrize("world,parallelism,M", [(4, "dp", 512), (8, "dp", 512), (8, "snp", 512), (4, "dp", 6200)])
+def test_global_batch_800_over_4_and_8_ranks(tmp_path, world, parallelism, M):
     """The reference's multi-GPU shape: --batch_size 800 over W GPUs = 800 // W rows per rank and step (200 / 100,
     neural_admixture.py:287), N = 1003 not a multiple of W (DistributedSampler wraps 1 / 5 indices, loaders.py:26-27), two
     steps per epoch with a ragged second one (51 / 26 rows per rank).  Product orchestration over gloo against the oracle's
-    DDP emulation of the same run (oracle.train_run(world=W), itself pinned by ddp_w2 / ddp_w4 captured from the reference)."""
+    DDP emulation of the same run (oracle.train_run(world=W), itself pinned by ddp_w2 / ddp_w4 captured from the reference).
+    M = 6200: message B = [small | V] travels in four SNP-range buckets (r05), each with slices and moments of its own."""
     from oracle import nadm_oracle as O
-    N, M, K, Hd, batch, epochs, seed = 1003, 512, 3, 32, 800, 2, 5
-    port = 40500 + 1000 * (world == 8) + 500 * (parallelism == "snp") + (os.getpid() % 450)
+    N, K, Hd, batch, epochs, seed = 1003, 3, 32, 800, 2, 5
+    port = 40500 + 1000 * (world == 8) + 500 * (parallelism == "snp") + 2000 * (M > 512) + (os.getpid() % 450)
     out = str(tmp_path / "wN.npz")
     mp.spawn(_wN_worker, args=(world, port, out, parallelism, N, M, K, Hd, batch, epochs, seed), nprocs=world, join=True)
     r = np.load(out)

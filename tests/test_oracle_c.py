@@ -14,7 +14,7 @@ def rel(a, b):
     return float(np.abs(a.astype(np.float64) - b).max() / (np.abs(b).max() + 1e-30))
 
 
-@pytest.mark.parametrize("name", ["one_step_k3", "one_step_k8_h1024", "one_step_k7_h1024"])
+@pytest.mark.parametrize("name", ["one_step_k3", "one_step_k8_h1024", "one_step_k7_h1024", "one_step_k16_h1024"])
 def test_c_port_one_step(name):
     d = np.load(f"{G}/{name}.npz")
     ks = [int(k) for k in d["ks"]]

@@ -44,7 +44,7 @@ def test_bce_elementwise_semantics():
 
 
 @pytest.mark.parametrize("name", ["one_step_k3", "one_step_multihead", "one_step_k8_h1024", "one_step_edge",
-                                  "one_step_supervised", "one_step_k7_h1024", "one_step_heads2to10"])
+                                  "one_step_supervised", "one_step_k7_h1024", "one_step_heads2to10", "one_step_k16_h1024", "one_step_k9"])
 def test_one_step(name):
     d = np.load(f"{G}/{name}.npz")
     ks = [int(k) for k in d["ks"]]
@@ -178,7 +178,7 @@ def test_supervised_run():
 END_OF_RUN = dict(mean_dq=1e-2, max_dp=1e-2, loglik_rel=1e-4, loss_rel=1e-3)
 
 
-def check_end_of_run(Q, P, losses, loglik, d):
+def check_end_of_run(Q, P, losses, loglik, d, worst_sample_factor=1.0):
     """Q / P / per-epoch loss / log-likelihood of a run against the reference's fp32 ("hi") run of the same length, next to the
     distance of the reference's own bf16 ("med") run from it -- the yardstick: two fp32 summation orders separate over
     hundreds of steps like the reference separates from itself."""
@@ -186,9 +186,11 @@ def check_end_of_run(Q, P, losses, loglik, d):
     ref_dq = np.abs(d["med_Q"] - d["hi_Q"])
     assert dq.mean() <= END_OF_RUN["mean_dq"], dq.mean()
     assert dp.max() <= END_OF_RUN["max_dp"], dp.max()
-    # the yardstick: on average closer to the fp32 run than the reference's own bf16 run is; the single worst sample of a chaotic 250-epoch
-    # trajectory is of the yardstick's order (measured r04: demo e250 max 0.058 against the reference's 0.060, mean 5.6e-3 against 7.7e-3)
-    assert dq.mean() <= ref_dq.mean() and dq.max() <= 2.0 * ref_dq.max()
+    # the yardstick: on average closer to the fp32 run than the reference's own bf16 run is, and so is the single worst sample -- for the
+    # pinned CPU oracle (measured r04: demo e250 max 0.058 against the reference's 0.060, mean 5.6e-3 against 7.7e-3).  The GPU production
+    # path passes worst_sample_factor = 2: its summation orders differ from the oracle's, and the worst sample of a chaotic 250-epoch
+    # trajectory is a single draw of the yardstick's order, not a bound on it (the mean is held to the yardstick itself either way)
+    assert dq.mean() <= ref_dq.mean() and dq.max() <= worst_sample_factor * ref_dq.max(), (dq.max(), ref_dq.max())
     ref_l = np.asarray(d["hi_losses"], dtype=np.float64).reshape(len(losses), -1).sum(1)
     assert np.max(np.abs(np.asarray(losses) - ref_l) / ref_l) <= END_OF_RUN["loss_rel"]
     assert abs(loglik - float(d["hi_loglik"])) / abs(float(d["hi_loglik"])) <= END_OF_RUN["loglik_rel"]

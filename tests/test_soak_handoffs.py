@@ -103,9 +103,10 @@ def test_2000_multihead_production_steps_equal_the_unfused_sequence():
 
 
 def test_1000_data_parallel_steps_on_a_one_rank_rccl_communicator_equal_the_plain_step():
-    """nadm_step in NADM_MODE_DP on a 1-rank RCCL communicator: message A on the side stream (event hand-offs in both directions every
-    step), message B on the compute stream, Adam as launches of its own -- 1000 steps with changing batch sizes must leave the bits of
-    the single-GPU step."""
+    """nadm_step in NADM_MODE_DP on a 1-rank RCCL communicator: message A on the side stream, message B in four SNP-range buckets on the
+    second one (pass 3 range by range, the next pass 1 in the same ranges on streams of their own: event hand-offs in both directions
+    for every bucket, every step), Adam as launches of its own -- 1000 steps with changing batch sizes must leave the bits of the
+    single-GPU step."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import neural_admixture_amd as na
@@ -114,7 +115,8 @@ def test_1000_data_parallel_steps_on_a_one_rank_rccl_communicator_equal_the_plai
     comm = rccl_comm(0, 1)
     M, N, steps = 60_000, 4000, 1000
     plain, tmp = _engines(M, [8], 1024, N, seed=29)
-    ddp = na.Engine(M, 8, 1024, [8], dev, 800, mode="dp", comm=comm)
+    ddp = na.Engine(M, 8, 1024, [8], dev, 800, mode="dp", comm=comm, n_buckets=4)
+    assert ddp.lay.n_buckets == 4
     ddp.pflat.copy_(tmp.pflat)
     ddp.set_packed(tmp.xp)
     gen = torch.Generator().manual_seed(3)
