@@ -182,6 +182,43 @@ def cpu_baseline(eng, args, dev):
                       f"fused C/OpenMP port of the step (oracle/nadm_oracle_c.c), cpu={model}"}
 
 
+def cpu_baseline_reference_shaped(eng, args, dev):
+    """The step in the reference's own shape -- its sequence of torch CPU operators, true fp32 (oracle/torch_shape.py, pinned against
+    the reference's fixtures) -- on every host core: what SURVEY 8d / BASELINE.md section 3 describe, beside the fused C port."""
+    from neural_admixture_amd._lib import lib, check, ptr
+    from oracle.torch_shape import TorchShapedModel
+    L = eng.lay
+    b = min(args.batch, eng.xp.shape[0])
+    n = min(eng.xp.shape[0], 2 * b)
+    Gd = torch.empty((n, L.M), dtype=torch.uint8, device=dev)
+    check(lib.nadm_unpack2bit(ptr(eng.xp), ptr(Gd), n, L.M, eng.ld, None), "unpack")
+    G = Gd.cpu()
+    del Gd
+    sm = eng.small.cpu().numpy()
+    h, K = L.heads, L.ks[0]
+    cores = os.cpu_count() or 1
+    prev = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    torch.set_float32_matmul_precision("highest")
+    try:
+        m = TorchShapedModel(eng.V().cpu().numpy(), [eng.P(0).cpu().numpy()], sm[h.g_off:h.g_off + L.C], sm[h.w1_off:h.w1_off + L.Hd * L.C].reshape(L.Hd, L.C),
+                             sm[h.b1_off:h.b1_off + L.Hd], [sm[h.wk_off[0]:h.wk_off[0] + K * L.Hd].reshape(K, L.Hd)], [sm[h.bk_off[0]:h.bk_off[0] + K]], 2e-3)
+        m.step(G[:b])                                  # warm-up (thread pool, allocator)
+        times = []
+        for s_ in range(3):
+            t0 = time.perf_counter()
+            m.step(G[(s_ % (n // b)) * b:(s_ % (n // b) + 1) * b])
+            times.append(time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": b * L.M / float(np.median(times)), "unit": "genotypes/s", "cores": cores, "kind": "port",
+            "shape": "the reference's operator sequence on torch CPU ops, fp32 (oracle/torch_shape.py)",
+            "step_s": {"min": float(np.min(times)), "median": float(np.median(times)), "max": float(np.max(times)), "n": len(times)},
+            "sample": f"3 timed steps (after 1 warm-up) of {b} rows x {L.M} SNPs, torch {torch.__version__} CPU, {cores} threads",
+            "reference_itself_in_the_survey_container": {"value": 9.2e7, "cores": 8, "source": "BASELINE.md section 2: the unmodified reference, "
+                                                         "8 Xeon cores (AMX bf16 matmuls), 8000 x 50000, K=8 -- another machine, quoted for scale"}}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -346,6 +383,32 @@ def main():
         step(s)
     host_queue_ms = (time.perf_counter() - t_h) / 20 * 1e3
     torch.cuda.synchronize()
+    # ---- the literal "epoch-seconds" of the metric: the production trainer's epoch loop (model.NeuralAdmixture.launch_training: the
+    # sampler's order per epoch drawn and copied underneath the steps, every batch of the epoch incl. a ragged last one, the loss value
+    # only on the epochs that log it -- every 5th, neural_admixture.py:416) over whole epochs of the resident matrix.  Reported beside
+    # the K-step figure, which stays the headline (`value`): that one computes the loss value on EVERY step like the reference does.
+    full_run = None
+    if world == 1 and not snp and args.emulate_world is None and not args.force_ddp:
+        from neural_admixture_amd.model import _EpochOrders
+        n_ep = 5                                                            # epochs 0..4: one logged epoch in five, like a default run
+        orders = _EpochOrders(torch.Generator().manual_seed(42), rows_local, dev)
+        torch.cuda.synchronize()
+        t_e = time.perf_counter()
+        for epoch in range(n_ep):
+            logged = epoch % 5 == 0
+            order = orders.take(epoch, prefetch=epoch + 1 < n_ep)
+            for s0 in range(0, rows_local, b):
+                bb = min(b, rows_local - s0)
+                eng.train_step(order[s0:s0 + bb], bb, lr, logged)
+            orders.epoch_queued()
+            if logged:
+                eng.read_loss(reset=True)
+        eng.sync()
+        torch.cuda.synchronize()
+        ep_s = (time.perf_counter() - t_e) / n_ep
+        full_run = {"epoch_ms_full_run": ep_s * 1e3, "genotypes_per_s": rows_local * M / ep_s, "epochs_timed": n_ep,
+                    "steps_per_epoch": (rows_local + b - 1) // b,
+                    "note": "production epoch loop, loss value on logged epochs only (1 in 5); `value` above computes it on every step"}
     # ---- roofline of the dominant kernel = pass 2 (decode_bce: all heads of the step) ----
     # Algorithmic bytes in the accounting of SURVEY.md 8d (whole step = 0.75 B/genotype of packed X + 36 B per parameter of
     # parameter/optimizer traffic): one 2-bit pass over the batch + the pass's share of the per-parameter traffic.
@@ -424,8 +487,10 @@ def main():
                      "valu_issue_rate_frac": issue["achieved_frac_of_valu_issue_peak"] if issue else None,
                      "x_walks": x_walks, "bytes_incl_x_rewalks": alg_8d + (x_walks - 1) * rows_b * m_loc / 4,
                      "traffic": hbm["traffic_bytes_per_launch"] if hbm else None,
-                     "traffic_source": (f"profiles/{PROFILE_ROUND}_pmc_hbm.json (separate --pmc passes of FETCH_SIZE and WRITE_SIZE; {hbm['correction']}; src_hash {hbm['src_hash']})"
+                     "traffic_source": (f"profiles/{PROFILE_ROUND}_pmc_hbm.json (replayed, not measured in this run: separate --pmc passes of FETCH_SIZE and WRITE_SIZE; {hbm['correction']}; src_hash {hbm['src_hash']})"
                                         if hbm else None),
+                     "issue_source": (f"profiles/{PROFILE_ROUND}_pmc_sq.json (replayed, not measured in this run: separate --pmc passes of the SQ counters on "
+                                      f"the same kernel sources and workload; src_hash {sq['src_hash']})" if sq else None),
                      "traffic_composition": composition,
                      "kernel_ms": kms, "alg_bytes_per_launch": alg_8d, "alg_bytes_min_per_launch": alg_min,
                      "alg_bytes_note": "frac/frac_8d: 2-bit pass over the batch + %d B per P parameter (SURVEY 8d rule; %s); frac_min: the same pass "
@@ -441,6 +506,7 @@ def main():
                               "peak_tflops": MFMA_BF16_PEAK_TFLOPS,
                               "frac": b * M * args.steps / dt * (4 * 8 + 6 * S) / 1e12 / MFMA_BF16_PEAK_TFLOPS}},
         "loss_last_step": loss_last,
+        "epoch_loop": full_run,
     }
     if world > 1:
         out["ms_per_step_this_rank"] = dt_rank / args.steps * 1e3          # rank 0's own clock; ms_per_step is the max over ranks
@@ -449,6 +515,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and len(ks) == 1 and args.emulate_world is None:
             out["cpu_baseline"] = cpu_baseline(eng, args, dev)
+            out["cpu_baseline_reference_shaped"] = cpu_baseline_reference_shaped(eng, args, dev)
         print(json.dumps(out))
         sys.stdout.flush()
     comm_a2 = eng.comm_a

@@ -444,6 +444,15 @@ int64_t nadm_loglik_blocks(int64_t M);
 int nadm_loglik(const uint8_t* xp, int64_t ld, int64_t rows, int64_t M, const float* P, const float* Q, int32_t K,
                 int32_t q_stride, double eps, double* partial, void* stream);
 
+/* ---- 8(f)-3: decoder init, the means of the mixture the reference fits in the PCA subspace (model/train.py:61-66, scikit-learn's
+ * GaussianMixture(n_components=K, n_init=5, init_params='k-means++', tol=1e-4, covariance_type='full', max_iter=100,
+ * random_state=seed).fit(X).means_): the EM iterations of that call in float64 on the host (csrc/nadm_gmm.cpp restates the
+ * algorithm and the library's conventions).  X [N, d] row-major; picks [n_init, K] = the k-means++ seed rows of every restart,
+ * drawn by the caller from the library's own random stream (gmm.kmeanspp_picks); means [K, d] out; lower_bound / n_iter (may be
+ * NULL) = the winning restart's objective and iteration count.  Host code, one thread per restart, synchronous. */
+int nadm_gmm_fit_means(const double* X, int64_t N, int32_t d, int32_t K, const int32_t* picks, int32_t n_init, double tol,
+                       int32_t max_iter, double reg_covar, double* means, double* lower_bound, int32_t* n_iter);
+
 /* ---- VCF genotypes (src/snp_reader.py:73-87: scikit-allel read_vcf, calldata/GT as int8 with -1 fills, summed over the two
  * alleles, negative sums -> 3).  buf = the whole decompressed file; out == NULL only counts samples and variant lines;
  * out = uint8 [n_samples, n_variants], sample-major like the reference's matrix.  Host code (threads), no GPU. */

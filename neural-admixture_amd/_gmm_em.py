@@ -96,7 +96,7 @@ def fit_means(X_pca: np.ndarray, k: int, seed: int, device=None, n_init: int = 5
     X = torch.from_numpy(Xh).to(device if device is not None else "cpu")
     rs = check_random_state(seed)
     mix = _Mixture(X, reg_covar)
-    best_bound, best_means = -math.inf, None
+    runs = []
     for _ in range(n_init):
         _, picks = kmeans_plusplus(Xh, k, random_state=rs)
         resp = torch.zeros((N, k), dtype=X.dtype, device=X.device)
@@ -109,6 +109,8 @@ def fit_means(X_pca: np.ndarray, k: int, seed: int, device=None, n_init: int = 5
             mix.m_step(torch.exp(log_resp), seeding=False)
             if abs(bound - prev) < tol:
                 break
-        if bound > best_bound or best_bound == -math.inf:
-            best_bound, best_means = bound, mix.means.cpu().numpy().copy()
-    return best_means
+        runs.append((bound, mix.means.cpu().numpy().copy()))
+    # the highest objective wins; restarts within 1e-10 of it reached the same optimum (in the library the winner among those is decided
+    # by the rounding of its sums): the first of them, like csrc/nadm_gmm.cpp
+    top = max(b for b, _ in runs)
+    return next(m for b, m in runs if b >= top - 1e-10)

@@ -100,6 +100,7 @@ def _load():
         "nadm_loglik_blocks": (i64, [i64]),
         "nadm_loglik": (C.c_int, [vp, i64, i64, i64, vp, vp, i32, i32, C.c_double, vp, vp]),
         "nadm_savetxt_f32": (C.c_int, [C.c_char_p, vp, i64, i64, i64]),
+        "nadm_gmm_fit_means": (C.c_int, [vp, i64, i32, i32, vp, i32, C.c_double, i32, C.c_double, vp, C.POINTER(C.c_double), C.POINTER(i32)]),
         "nadm_mlp_fwd": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]),
         "nadm_decode_bce": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
         "nadm_decode_bce_gather": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp]),

@@ -137,8 +137,7 @@ def main(argv=None):
         data = _read(args.data_path, torch.device("cuda:0"), keep_on_device=(num_gpus == 1))   # 2-bit transpose on the GPU
         log.info("")
         log.info("    Running SVD...")
-        V = RSVD(data, data.N, data.M, args.n_components, args.seed,
-                 preload_mixture=args.k is not None or args.max_k - args.min_k < 2)     # (more K: the fit runs in child processes)
+        V = RSVD(data, data.N, data.M, args.n_components, args.seed)
         if num_gpus > 1:
             data.packed.share_memory_()
             torch.multiprocessing.spawn(_train_worker, args=(args, num_gpus, data, V, pops, t0), nprocs=num_gpus)

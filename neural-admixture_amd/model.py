@@ -116,6 +116,19 @@ def hudsons_fst(p1: torch.Tensor, p2: torch.Tensor) -> float:
     return (num / den).item()
 
 
+def fst_table(P: torch.Tensor) -> torch.Tensor:
+    """Hudson's Fst of every pair of columns of P [M, k] at once: with G = P^T P and s = the column sums,
+    mean((p_l - p_j)^2) = (G_ll + G_jj - 2 G_lj) / M and mean(p_l (1 - p_j) + p_j (1 - p_l)) = (s_l + s_j - 2 G_lj) / M -- one
+    float64 product instead of k (k - 1) / 2 passes with a host read each (165 passes over 600k SNPs for heads K = 2..10)."""
+    Pd = P.detach().to(torch.float64)
+    M = Pd.shape[0]
+    G = Pd.T @ Pd
+    sq, s1 = torch.diagonal(G), Pd.sum(dim=0)
+    num = (sq[:, None] + sq[None, :] - 2 * G) / M
+    den = (s1[:, None] + s1[None, :] - 2 * G) / M + 1e-7
+    return (num / den).cpu()
+
+
 def epoch_order(generator: torch.Generator, n: int) -> torch.Tensor:
     """The sample order ``iter(RandomSampler(range(n), generator=generator))`` yields for one epoch, as an int32 tensor,
     leaving ``generator`` in the state the sampler leaves it in: torch's sampler draws ``randperm(n)`` for the epoch and
@@ -392,6 +405,7 @@ class NeuralAdmixture:
             return
         for i, k in enumerate(self.ks_list):
             dec = P_full[i] if P_full is not None else self.engine.P(i)
+            fst = fst_table(dec)
             header = '\t'.join([f'Pop{p}' for p in range(k - 1)])
             log.info("    Results:")
             log.info(f'\n            Fst divergences between estimated populations: (K = {k})')
@@ -401,7 +415,7 @@ class NeuralAdmixture:
             for j in range(1, k):
                 out = f'            Pop{j}'
                 for l in range(j):
-                    out += f"\t{hudsons_fst(dec[:, l], dec[:, j]):0.3f}"
+                    out += f"\t{float(fst[l, j]):0.3f}"
                 log.info(out)
             log.info("\n")
 

@@ -101,6 +101,30 @@ class _Rows:
         return out if keep_on_device else np.ascontiguousarray(out.t().cpu().numpy())
 
 
+def _omega_to_device(rng, M: int, kp: int, device: torch.device, chunk: int = 32768) -> torch.Tensor:
+    """Omega [M, k'] ~ N(0, 1) float32 from the reference's own stream (``rng.standard_normal(size=(M, kp), dtype=float32)``,
+    src/svd.py:47-48) straight into HBM: generated ``chunk`` rows at a time into two small pinned buffers that are copied while the
+    next chunk is drawn.  Chunked draws continue the generator's stream exactly (checked by tests/test_abi_and_host.py); what
+    changes is where the time goes: one call into a fresh 48 MB host array (M = 600k) takes 0.25-0.36 s, two thirds of it page
+    faults; the same numbers through a 2.6 MB ring take 0.15 s, underneath which the copies run (r05, profiles/r05_init_profile_*.txt)."""
+    out = torch.empty((M, kp), dtype=torch.float32, device=device)
+    ring = [torch.empty((min(chunk, M), kp), dtype=torch.float32).pin_memory() for _ in range(2)]
+    done = [None, None]
+    with torch.cuda.device(device):
+        for i, s in enumerate(range(0, M, chunk)):
+            e = min(M, s + chunk)
+            if done[i & 1] is not None:
+                done[i & 1].synchronize()                    # the copy that last read this buffer
+            rng.standard_normal(dtype=np.float32, out=ring[i & 1].numpy()[: e - s])
+            out[s:e].copy_(ring[i & 1][: e - s], non_blocking=True)
+            done[i & 1] = torch.cuda.Event()
+            done[i & 1].record()
+        for ev in done:                                      # Omega is complete in HBM when this returns, whatever stream the caller is on
+            if ev is not None:
+                ev.synchronize()
+    return out
+
+
 def _preload_mixture_library(N: int) -> None:
     """The decoder-init mixture fit that follows the SVD (train.gmm_p_init) calls scikit-learn for N <= 20000, and importing
     scikit-learn takes 1.0 s on this image -- half of a default run on a 1000-Genomes-sized matrix.  Started here, on a thread,
@@ -119,19 +143,43 @@ def _preload_mixture_library(N: int) -> None:
 
 
 def RSVD(A_uint8, N: int, M: int, k: int = 8, seed: int = 42, oversampling: int = 10, power_iterations: int = 2,
-         device: torch.device = None, rows: int = 2048, preload_mixture: bool = True) -> np.ndarray:
+         device: torch.device = None, rows: int = 2048, preload_mixture: bool = False) -> np.ndarray:
     if device is None:
         device = torch.device("cuda:0") if torch.cuda.is_available() else None
-    if preload_mixture:               # (a caller that knows the fit will run in child processes -- more than two K -- passes False)
+    if preload_mixture:               # (only callers that will fit with the library itself, train.gmm_p_init(fit="sklearn"), ask for it)
         _preload_mixture_library(N)
     old_prec = torch.get_float32_matmul_precision()
     torch.set_float32_matmul_precision("highest")
     try:
-        src = _Rows(A_uint8 if hasattr(A_uint8, "shape") else np.asarray(A_uint8), device)
         rng = np.random.default_rng(seed)
         kp = max(k + oversampling, 20)
         t0 = time.time()
-        Omega = rng.standard_normal(size=(M, kp), dtype=np.float32)
+        on_gpu = device is not None and device.type == "cuda"
+        if on_gpu:
+            # Omega is drawn (numpy releases the GIL) and shipped on a helper thread while this one moves the packed matrix to HBM and
+            # pays the first-use costs of the device ops below -- the draw is the longest single item of the GPU path
+            import threading
+            box = {}
+
+            def _draw():
+                try:
+                    box["omega"] = _omega_to_device(rng, M, kp, device)
+                except BaseException as e:                   # re-raised on the caller's thread
+                    box["error"] = e
+            th = threading.Thread(target=_draw, name="nadm-rsvd-omega")
+            th.start()
+        src = _Rows(A_uint8 if hasattr(A_uint8, "shape") else np.asarray(A_uint8), device)
+        if on_gpu:
+            with torch.cuda.device(device):
+                w = torch.linalg.qr(torch.eye(kp, dtype=torch.float32, device=device).repeat(4, 1), mode="reduced")[0]     # first-use cost of the
+                _ = torch.arange(4, dtype=torch.int32, device=device) + 1                                                  # solver / of torch's own kernels
+                del w
+            th.join()
+            if "error" in box:
+                raise box["error"]
+            Omega = box["omega"]
+        else:
+            Omega = rng.standard_normal(size=(M, kp), dtype=np.float32)
 
         if src.xp is not None:
             # GPU path: everything after Omega stays in HBM.  QR through torch (rocSOLVER); the final SVD of the wide

@@ -52,7 +52,8 @@ def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_comp
     ``data_np``: uint8 [N,M] array or an io.PackedGenotypes.  With a GPU ``device`` and n_components <= 8 the
     projection runs on the GPU (pca_project_gpu); otherwise on the host, 1024 rows at a time like the reference.
     The mixture fit (``fit``): "sklearn" = the reference's scikit-learn call, "em" = its float64 restatement in device ops
-    (_gmm_em.py, same means to 1e-13), "auto" = the device for N > 20000 on a GPU, the library otherwise."""
+    (_gmm_em.py), "native" = the same on the host (gmm.py + csrc/nadm_gmm.cpp), "auto" = the device for N > 20000 on a GPU, the
+    host restatement otherwise -- all three give the library's means to 1e-10."""
     N = data_np.shape[0]
     if device is not None and device.type == "cuda" and n_components <= 8:
         X_pca = pca_project_gpu(data_np, V_CM, device)
@@ -65,17 +66,26 @@ def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_comp
     ks = [K] if K is not None else list(range(min_k, max_k + 1))
     how = fit
     on_gpu = device is not None and device.type == "cuda"
-    # device EM: ~0.6 ms per iteration whatever N (launch-bound) + ~0.8 s of one-off start-up (first float64 batched GEMMs);
-    # library fit: proportional to N (1 s at N = 2504, 22-45 s at N = 100k), and several K can run as concurrent child
-    # processes -> the device for large N, the library for 1000-Genomes-sized inputs
+    # "auto": the library's algorithm restated (same seeding draws, same EM, means equal to 1e-10 -- tests/test_abi_and_host.py) where it
+    # is fastest: on the host for 1000-Genomes-sized inputs (gmm.py + csrc/nadm_gmm.cpp: ~0.05 s where the library takes 0.55 s + a 1.0 s
+    # import, several K on threads), in device ops for N > 20000 on a GPU (_gmm_em.py: ~0.6 ms per iteration whatever N, where the
+    # library takes 22-45 s at N = 100k).  "sklearn": the library itself, several K as concurrent child processes.
     if how == "em" or (how == "auto" and on_gpu and N > 20_000):
         from ._gmm_em import fit_means as fit_means_device
         means = [fit_means_device(X_pca, k, seed, device) for k in ks]
+    elif how in ("auto", "native"):
+        from .gmm import fit_means as fit_means_host
+        if len(ks) > 1:
+            from concurrent.futures import ThreadPoolExecutor     # (the C call releases the GIL; each fit runs its restarts on threads of its own)
+            with ThreadPoolExecutor(max_workers=len(ks)) as pool:
+                means = list(pool.map(lambda k_: fit_means_host(X_pca, k_, seed), ks))
+        else:
+            means = [fit_means_host(X_pca, ks[0], seed)]
     else:
         means = _gmm_means_parallel(X_pca, ks, seed) if len(ks) > 2 else None
-    if means is None:
-        from ._gmm_fit import fit_means
-        means = [fit_means(X_pca, k, seed) for k in ks]
+        if means is None:
+            from ._gmm_fit import fit_means
+            means = [fit_means(X_pca, k, seed) for k in ks]
     return np.concatenate([np.clip(m @ V_CM, 5e-6, 1 - 5e-6) for m in means], axis=0)
 
 

@@ -347,6 +347,21 @@ def test_read_bed_packed_demo_fixture(tmp_path):
     assert np.array_equal(pg.unpack_rows(3, 9), O.unpack2bit(d["G_packed"], int(d["M"]))[3:9])
 
 
+def test_chunked_draws_continue_the_generators_stream():
+    """svd._omega_to_device draws Omega chunk by chunk into a small ring (r05): the concatenation must be the one array the reference
+    draws in a single call (src/svd.py:47-48) -- PCG64's buffered 32-bit half carries over between calls."""
+    for M, kp, chunk in ((8451, 20, 1000), (70_001, 20, 32768), (5, 20, 32768), (40_000, 23, 4097)):
+        whole = np.random.default_rng(42).standard_normal(size=(M, kp), dtype=np.float32)
+        rng = np.random.default_rng(42)
+        out = np.empty((M, kp), dtype=np.float32)
+        buf = np.empty((min(chunk, M), kp), dtype=np.float32)
+        for s in range(0, M, chunk):
+            e = min(M, s + chunk)
+            rng.standard_normal(dtype=np.float32, out=buf[: e - s])
+            out[s:e] = buf[: e - s]
+        assert np.array_equal(out, whole)
+
+
 def test_rsvd_matches_reference_on_demo():
     """8(f)-2: same Omega stream, QR/SVD steps and sign flip as src/svd.py:39-83 (host path, no GPU)."""
     from neural_admixture_amd.svd import RSVD
@@ -504,6 +519,49 @@ def test_device_em_restatement_gives_the_library_mixture_means():
         torch.set_num_threads(nt)
 
 
+def _mixture_cases():
+    rng = np.random.default_rng(0)
+    for N, k, seed, sep in ((600, 3, 42, 3.0), (1500, 7, 42, 1.0), (200, 2, 3, 0.1), (2504, 7, 42, 0.7), (2504, 10, 5, 0.5), (105, 3, 42, 2.0)):
+        cent = rng.standard_normal((k, 8)) * sep
+        X = (rng.dirichlet(np.full(k, 0.5), N) @ cent + 0.3 * rng.standard_normal((N, 8))).astype(np.float32).astype(np.float64)
+        yield X, k, seed
+
+
+def test_seeding_picks_are_the_librarys():
+    """gmm.kmeanspp_picks: the k-means++ seed rows of five consecutive restarts drawn from ONE numpy RandomState -- the stream, the
+    greedy local trials and the searches in the cumulative distances -- against sklearn.cluster.kmeans_plusplus itself."""
+    from sklearn.cluster import kmeans_plusplus
+    from sklearn.utils import check_random_state
+    from neural_admixture_amd.gmm import kmeanspp_picks
+    for X, k, seed in _mixture_cases():
+        rs_lib, rs_own = check_random_state(seed), np.random.RandomState(seed)
+        for _ in range(5):
+            assert np.array_equal(kmeans_plusplus(X, k, random_state=rs_lib)[1], kmeanspp_picks(X, k, rs_own))
+        assert rs_lib.randint(1 << 30) == rs_own.randint(1 << 30)           # ... and the streams are in the same place afterwards
+
+
+def test_host_em_restatement_gives_the_library_mixture_means():
+    """gmm.fit_means (numpy seeding + csrc/nadm_gmm.cpp, the default decoder init up to 20000 samples since r05) against sklearn's
+    GaussianMixture with the reference's arguments (train.py:61): means equal to 1e-10, the library's own error for too few samples
+    and for a collapsed component.  Restarts that reach the SAME optimum (objectives equal to ~1e-15) are ordered by rounding noise in
+    the library; there the means must agree as a set, at the level the stopping rule (tol = 1e-4 on the objective) leaves."""
+    from neural_admixture_amd.gmm import fit_means as native
+    from neural_admixture_amd._gmm_fit import fit_means as sk
+    for X, k, seed in _mixture_cases():
+        assert np.abs(native(X, k, seed) - sk(X, k, seed)).max() < 1e-10
+    with pytest.raises(ValueError, match="n_samples >= n_components"):
+        native(np.zeros((2, 8)), 3, 0)
+    with pytest.raises(ValueError, match="ill-defined empirical covariance"):
+        native(np.ones((50, 8)), 2, 0, reg_covar=0.0)
+    # well-separated clusters: every restart ends in the same optimum, the winner is a matter of rounding
+    rng = np.random.default_rng(1)
+    cent = rng.standard_normal((5, 8)) * 6
+    X = cent[rng.integers(0, 5, 1200)] + 0.5 * rng.standard_normal((1200, 8))
+    a, b = native(X, 5, 9), sk(X, 5, 9)
+    order = [int(np.argmin(np.abs(b - a[i]).sum(1))) for i in range(5)]
+    assert sorted(order) == list(range(5)) and np.abs(a - b[order]).max() < 1e-3
+
+
 def test_epoch_order_is_the_random_sampler_sequence():
     """model.epoch_order replaces iterating torch's RandomSampler (loaders.py:29-31): same indices, same generator state
     after every epoch (the sampler's discarded second draw included)."""
@@ -629,6 +687,11 @@ def test_hudsons_fst_of_the_product_matches_the_reference_table():
             assert abs(hudsons_fst(P[:, b], P[:, a]) - float(fst[a, b])) < 1e-6
             assert abs(hudsons_fst(P[:, a], P[:, b]) - float(fst[a, b])) < 1e-6     # symmetric in its arguments
     assert hudsons_fst(P[:, 0], P[:, 0]) == 0.0
+    from neural_admixture_amd.model import fst_table        # all pairs from one product (what display_divergences prints)
+    T = fst_table(P)
+    for a in range(P.shape[1]):
+        for b in range(P.shape[1]):
+            assert abs(float(T[a, b]) - hudsons_fst(P[:, a], P[:, b])) < 1e-6
 
 
 def test_bed_reader_applies_the_reference_biallelic_check(tmp_path):
@@ -671,3 +734,37 @@ def test_pack2bit_module_has_the_reference_names_and_refuses_misplaced_tensors()
         pack2bit.pack2bit_cpu_to_gpu(g, torch.zeros((3, 3), dtype=torch.uint8))
     with pytest.raises(RuntimeError, match="Input tensor must be on CUDA device"):
         pack2bit.unpack2bit_gpu_to_gpu(torch.zeros((3, 3), dtype=torch.uint8), g)
+
+
+def test_dz_image_hand_off_compiles_to_the_instructions_its_contract_names(tmp_path):
+    """the cross-block hand-off of the dZ image (mlp_bwd_a kernels) is ordered without a fence.  What it relies on is
+    which INSTRUCTIONS the compiler emits: write-through payload stores (`global_store_dword ... sc1`), `s_waitcnt vmcnt(0)` before the
+    block is counted, a returning device-scope counter update (`global_atomic_add ... sc0`), and `sc1` loads by the block that arrives
+    last.  A toolchain upgrade that changes any of them shows up here, not as a one-in-a-million wrong gradient."""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "neural-admixture_amd", "csrc", "nadm_small_kernels.hip")
+    out = tmp_path / "small.s"
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", str(out), src],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    funcs, cur = {}, None
+    for line in open(out):
+        if line.startswith("_Z") and ":" in line:              # "<mangled name>:   ; @<mangled name>"
+            cur = line.split(":")[0]
+            funcs[cur] = []
+        elif cur is not None and line.startswith("\t") and not line.startswith("\t."):
+            funcs[cur].append(line.strip())
+    kernels = {k: v for k, v in funcs.items() if "mlp_bwd_a" in k and any(i.startswith("global_atomic_add ") for i in v)}
+    assert len(kernels) >= 2                                   # the instantiations of the MLP backward that build the image
+    for name, ins in kernels.items():
+        at = [i for i, s_ in enumerate(ins) if s_.startswith("global_atomic_add ")]
+        assert len(at) == 1 and ins[at[0]].endswith("sc0"), (name, [ins[i] for i in at])       # ONE counter update, returning the old value
+        before, after = ins[: at[0]], ins[at[0] + 1:]
+        st = [i for i, s_ in enumerate(before) if s_.startswith("global_store_dword ") and s_.endswith(" sc1")]
+        assert st, name                                        # the dZ payload goes through to memory
+        waits = [i for i, s_ in enumerate(before) if s_.startswith("s_waitcnt") and "vmcnt(0)" in s_ and i > st[-1]]
+        assert waits, name                                     # ... and is acknowledged before the block is counted
+        assert any(s_.startswith("s_barrier") for s_ in before[waits[-1]:]), name      # every wave of the block has waited
+        assert any(s_.startswith("global_load_dword ") and s_.endswith(" sc1") for s_ in after), name      # the last block reads past its L1 / L2 copies

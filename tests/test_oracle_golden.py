@@ -82,6 +82,26 @@ def test_one_step(name):
             assert mx(p.P[h], d[f"after{s}_decoders_decoders_{h}_weight"]) < tol
 
 
+@pytest.mark.parametrize("name", ["one_step_k3", "one_step_multihead", "one_step_k8_h1024", "one_step_k16_h1024"])
+def test_reference_shaped_torch_restatement(name):
+    """oracle/torch_shape.py -- the reference's own operator sequence on torch CPU ops, bench.py's second CPU baseline -- against the
+    tensors captured from the reference: loss of three steps, parameters after each."""
+    import torch
+    from oracle.torch_shape import TorchShapedModel
+    d = np.load(f"{G}/{name}.npz")
+    ks = [int(k) for k in d["ks"]]
+    p = O.make_params(int(d["seed"]), d["V0"], d["P0"], int(d["Hd"]), ks)
+    torch.set_float32_matmul_precision("highest")
+    m = TorchShapedModel(p.V, p.P, p.g, p.W1, p.b1, p.Wk, p.bk, float(d["lr"]))
+    Gt = torch.from_numpy(np.ascontiguousarray(d["G"]))
+    for s in range(3):
+        loss = m.step(Gt)
+        assert abs(loss - float(d[f"loss{s}"])) / float(d[f"loss{s}"]) < 2e-6
+        assert mx(m.V.detach().numpy(), d[f"after{s}_V"]) < 2e-6
+        for h in range(len(ks)):
+            assert mx(m.P[h].detach().numpy(), d[f"after{s}_decoders_decoders_{h}_weight"]) < 1e-6
+
+
 def test_multibatch_trajectory_and_batch_order():
     d = np.load(f"{G}/multibatch_k8.npz")
     Gm = O.unpack2bit(d["G_packed"], int(d["M"]))

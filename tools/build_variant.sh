@@ -11,6 +11,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-u
 hipcc $FLAGS -c $src/nadm_genotype_passes.hip -o /tmp/abl_$name/a.o "$@" &
 hipcc $FLAGS -c $src/nadm_small_kernels.hip -o /tmp/abl_$name/b.o "$@" &
 hipcc $FLAGS -c $src/nadm_step.hip -o /tmp/abl_$name/c.o "$@" &
+hipcc $FLAGS -x hip -c $src/nadm_gmm.cpp -o /tmp/abl_$name/d.o "$@" &
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libnadm.so -o $out/$name.so /tmp/abl_$name/a.o /tmp/abl_$name/b.o /tmp/abl_$name/c.o -lpthread -ldl
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libnadm.so -o $out/$name.so /tmp/abl_$name/a.o /tmp/abl_$name/b.o /tmp/abl_$name/c.o /tmp/abl_$name/d.o -lpthread -ldl
 echo "built $out/$name.so"

@@ -43,7 +43,7 @@ def main():
     del xp
     out = {"config": which, "N": N, "M": M, "epochs": epochs}
     t0 = time.time()
-    V = RSVD(data, N, M, 8, 42, preload_mixture=which != "c3")           # like the CLI: nine K -> the mixture fits run in child processes
+    V = RSVD(data, N, M, 8, 42)
     out["rsvd_s"] = time.time() - t0
     K, mn, mx = {"c2": (7, None, None), "c4": (8, None, None), "c5": (16, None, None)}.get(which, (None, 2, 10))
     # phase timers inside train(): wrap the module-level helpers it calls
