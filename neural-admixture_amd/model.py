@@ -120,10 +120,11 @@ def fst_table(P: torch.Tensor) -> torch.Tensor:
     """Hudson's Fst of every pair of columns of P [M, k] at once: with G = P^T P and s = the column sums,
     mean((p_l - p_j)^2) = (G_ll + G_jj - 2 G_lj) / M and mean(p_l (1 - p_j) + p_j (1 - p_l)) = (s_l + s_j - 2 G_lj) / M -- one
     float64 product instead of k (k - 1) / 2 passes with a host read each (165 passes over 600k SNPs for heads K = 2..10)."""
-    Pd = P.detach().to(torch.float64)
+    from .svd import gram64                                  # (elementwise: no first BLAS call of the process for a k x k product)
+    Pd = P.detach()
     M = Pd.shape[0]
-    G = Pd.T @ Pd
-    sq, s1 = torch.diagonal(G), Pd.sum(dim=0)
+    G = gram64(Pd)
+    sq, s1 = torch.diagonal(G), Pd.to(torch.float64).sum(dim=0)
     num = (sq[:, None] + sq[None, :] - 2 * G) / M
     den = (s1[:, None] + s1[None, :] - 2 * G) / M + 1e-7
     return (num / den).cpu()

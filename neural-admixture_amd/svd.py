@@ -6,8 +6,10 @@ codes (0,1,2,3 with missing kept as 3, no centering), exactly like the reference
 The two tall-skinny products that the reference runs as naive Cython triple loops on the CPU
 (src/utils_c/rsvd.pyx:16-50) run here on the GPU straight from the 2-bit packed matrix with the pass-1 / pass-3
 matrix-core kernels (nadm_pca_project / nadm_pca_project_t: genotype/2 with missing = 1.5, i.e. half the raw code,
-fp32-exact bf16 splitting), eight of the k' columns per launch.  Without a GPU the same algorithm runs through
-torch/numpy on the host (unpacked chunks)."""
+fp32-exact bf16 splitting), eight of the k' columns per launch.  What is left is k' = 20 columns wide: the QRs of [N, k'] run on
+the host with the reference's own numpy call, the SVD of the wide B comes from the Cholesky factor of its float64 Gram matrix --
+no device BLAS / solver call anywhere (r05: their first-use cost, ~0.2 s each, was most of this function).  Without a GPU the
+same algorithm runs through torch/numpy on the host (unpacked chunks)."""
 from __future__ import annotations
 
 import logging
@@ -101,6 +103,18 @@ class _Rows:
         return out if keep_on_device else np.ascontiguousarray(out.t().cpu().numpy())
 
 
+def gram64(A: torch.Tensor, chunk: int = 32768) -> torch.Tensor:
+    """A^T A in float64 for a tall, narrow A [n, c] (c <= ~32) on its own device, from elementwise products and sums -- no BLAS call.
+    The first GEMM / solver call of a process loads hipBLASLt / rocBLAS / rocSOLVER: 0.15-0.2 s each on this stack, a third of a
+    default run on a 1000-Genomes-sized matrix (profiles/r05_init_profile_c2.txt), for products a few reductions do in a millisecond."""
+    n, c = A.shape
+    G = torch.zeros((c, c), dtype=torch.float64, device=A.device)
+    for s in range(0, n, chunk):
+        blk = A[s:s + chunk].to(torch.float64)
+        G += (blk[:, :, None] * blk[:, None, :]).sum(dim=0)
+    return G
+
+
 def _omega_to_device(rng, M: int, kp: int, device: torch.device, chunk: int = 32768) -> torch.Tensor:
     """Omega [M, k'] ~ N(0, 1) float32 from the reference's own stream (``rng.standard_normal(size=(M, kp), dtype=float32)``,
     src/svd.py:47-48) straight into HBM: generated ``chunk`` rows at a time into two small pinned buffers that are copied while the
@@ -143,7 +157,9 @@ def _preload_mixture_library(N: int) -> None:
 
 
 def RSVD(A_uint8, N: int, M: int, k: int = 8, seed: int = 42, oversampling: int = 10, power_iterations: int = 2,
-         device: torch.device = None, rows: int = 2048, preload_mixture: bool = False) -> np.ndarray:
+         device: torch.device = None, rows: int = 2048, preload_mixture: bool = False, phases: dict = None) -> np.ndarray:
+    """``phases``: a dict that receives the wall-clock of the GPU path's stages (the device is synchronised at every boundary:
+    for profiling, tools/full_run.py)."""
     if device is None:
         device = torch.device("cuda:0") if torch.cuda.is_available() else None
     if preload_mixture:               # (only callers that will fit with the library itself, train.gmm_p_init(fit="sklearn"), ask for it)
@@ -155,9 +171,18 @@ def RSVD(A_uint8, N: int, M: int, k: int = 8, seed: int = 42, oversampling: int 
         kp = max(k + oversampling, 20)
         t0 = time.time()
         on_gpu = device is not None and device.type == "cuda"
+        t_mark = [t0]
+
+        def mark(name):
+            if phases is not None:
+                if on_gpu:
+                    torch.cuda.synchronize(device)
+                now = time.time()
+                phases[name] = phases.get(name, 0.0) + now - t_mark[0]
+                t_mark[0] = now
         if on_gpu:
-            # Omega is drawn (numpy releases the GIL) and shipped on a helper thread while this one moves the packed matrix to HBM and
-            # pays the first-use costs of the device ops below -- the draw is the longest single item of the GPU path
+            # Omega is drawn (numpy releases the GIL) and shipped on a helper thread while this one moves the packed matrix to HBM --
+            # the draw is the longest single item of the GPU path
             import threading
             box = {}
 
@@ -169,33 +194,47 @@ def RSVD(A_uint8, N: int, M: int, k: int = 8, seed: int = 42, oversampling: int 
             th = threading.Thread(target=_draw, name="nadm-rsvd-omega")
             th.start()
         src = _Rows(A_uint8 if hasattr(A_uint8, "shape") else np.asarray(A_uint8), device)
+        mark("rows_to_hbm")
         if on_gpu:
-            with torch.cuda.device(device):
-                w = torch.linalg.qr(torch.eye(kp, dtype=torch.float32, device=device).repeat(4, 1), mode="reduced")[0]     # first-use cost of the
-                _ = torch.arange(4, dtype=torch.int32, device=device) + 1                                                  # solver / of torch's own kernels
-                del w
             th.join()
             if "error" in box:
                 raise box["error"]
             Omega = box["omega"]
+            mark("omega_wait")
         else:
             Omega = rng.standard_normal(size=(M, kp), dtype=np.float32)
 
         if src.xp is not None:
-            # GPU path: everything after Omega stays in HBM.  QR through torch (rocSOLVER); the final SVD of the wide
-            # B [k',M] is taken from the QR of its transpose: B^T = Q2 R2  ->  B = (U S W^T) Q2^T with U S W^T = svd(R2^T).
+            # GPU path: the two tall products run on the HIP kernels and stay in HBM; everything else is k' = 20 columns wide and is
+            # done WITHOUT the device's BLAS / solver libraries (their first call costs more than this whole function, gram64):
+            #   * the QR of Y [N, k'] on the host with numpy's LAPACK -- the reference's own call (src/svd.py:56,64), so Q carries its
+            #     sign convention; Y is 200 KB at N = 2504, 8 MB at 100k
+            #   * the SVD of the wide B [k', M] from the Cholesky factor of its float64 Gram matrix: B^T = Q2 R2 with R2 = chol(B B^T)^T
+            #     -> svd(R2^T) = U S W^T gives B = U S (Q2 W)^T, i.e. Vt = W^T R2^-T B.  (Which orthonormal factor of B^T is used does
+            #     not touch U, so the sign rule below sees what the reference's svd(B) sees; kappa(B)^2 ~ 1e4-1e5 is nothing in float64.)
+            def host_qr(Yd):
+                q = np.linalg.qr(Yd.cpu().numpy(), mode="reduced")[0]
+                return torch.from_numpy(np.ascontiguousarray(q)).to(device)
             Y = src.a_times(Omega, keep_on_device=True)
+            mark("products")
             for _ in range(power_iterations):
-                Qy, _ = torch.linalg.qr(Y, mode="reduced")
+                Qy = host_qr(Y)
+                mark("qr_small")
                 Bt = src.qt_times(Qy, keep_on_device=True)                 # [M,k']
                 Y = src.a_times(Bt, keep_on_device=True)
-            Q, _ = torch.linalg.qr(Y, mode="reduced")
+                mark("products")
+            Q = host_qr(Y)
+            mark("qr_small")
             Bt = src.qt_times(Q, keep_on_device=True)                      # B^T [M,k']
-            Q2, R2 = torch.linalg.qr(Bt, mode="reduced")                   # [M,k'], [k',k']
-            Ut, St, Wt = np.linalg.svd(R2.t().cpu().numpy().astype(np.float64), full_matrices=False)
-            Vt = (torch.from_numpy(Wt.astype(np.float32)).to(device) @ Q2.t())[:k]
-            signs = np.sign(Ut[np.argmax(np.abs(Ut), axis=0), np.arange(Ut.shape[1])])[:k]
-            Vt = (Vt * torch.from_numpy(signs.astype(np.float32)).to(device)[:, None]).cpu().numpy()
+            mark("products")
+            R2 = np.linalg.cholesky(gram64(Bt).cpu().numpy()).T            # upper triangular, B^T = Q2 R2
+            Ut, St, Wt = np.linalg.svd(R2.T, full_matrices=False)
+            signs = np.sign(Ut[np.argmax(np.abs(Ut), axis=0), np.arange(Ut.shape[1])])     # svd_flip on U (svd.py:16-37)
+            T = (signs[:, None] * np.linalg.solve(R2, Wt.T).T)[:k]          # rows of W^T R2^-T, sign-flipped: Vt = T B
+            Td = torch.from_numpy(np.ascontiguousarray(T)).to(device)       # float64 [k, k']
+            Bt64 = Bt.to(torch.float64)
+            Vt = torch.stack([(Bt64 * Td[i]).sum(dim=1) for i in range(k)]).to(torch.float32).cpu().numpy()
+            mark("svd_and_result")
             log.info(f"    Total time SVD: {time.time() - t0:.4f}s")
             return np.ascontiguousarray(Vt.astype(np.float32))
 

@@ -43,8 +43,11 @@ def main():
     del xp
     out = {"config": which, "N": N, "M": M, "epochs": epochs}
     t0 = time.time()
-    V = RSVD(data, N, M, 8, 42)
+    rsvd_phases = {} if os.environ.get("NADM_RSVD_PHASES") else None     # (synchronises at every stage boundary: not for the headline total)
+    V = RSVD(data, N, M, 8, 42, phases=rsvd_phases)
     out["rsvd_s"] = time.time() - t0
+    if rsvd_phases is not None:
+        out["rsvd_phases"] = {k_: round(v_, 4) for k_, v_ in rsvd_phases.items()}
     K, mn, mx = {"c2": (7, None, None), "c4": (8, None, None), "c5": (16, None, None)}.get(which, (None, 2, 10))
     # phase timers inside train(): wrap the module-level helpers it calls
     import importlib
