@@ -37,13 +37,15 @@ def _stream():
 
 
 class Engine:
-    # tests/ subclass this with the oracle behind the kernel-calling methods to exercise the multi-rank logic of model.py /
-    # train.py on CPU/gloo; the product class itself refuses to run without a GPU.
-    _CPU_TEST_DOUBLE = False
+    @classmethod
+    def supports(cls, device: torch.device) -> bool:
+        """Whether this engine class runs on ``device``: the HIP engine needs a ROCm GPU -- there is no CPU fallback.  (A subclass
+        that computes the step some other way says so here; model.NeuralAdmixture.engine_cls is the extension point.)"""
+        return device.type == "cuda"
 
     def __init__(self, M: int, C_: int, Hd: int, ks: Sequence[int], device: torch.device, max_batch: int,
                  mode: str = "single", comm=None, n_buckets: int = 1, comm_a=None, p3_whole: bool = False, debug: bool = False):
-        if device.type != "cuda" and not self._CPU_TEST_DOUBLE:
+        if not self.supports(device):
             raise RuntimeError("neural_admixture_amd.Engine needs a ROCm GPU device (no CPU fallback)")
         if mode not in _MODES:
             raise ValueError("mode must be 'single', 'dp' or 'snp'")
@@ -76,7 +78,7 @@ class Engine:
         self.loss_acc = torch.zeros(2, dtype=torch.float64, device=device)
         self._zsum = z(b * L.CP) if mode == "snp" else None
         self._dqsum = z(b * L.SP) if mode == "snp" else None
-        gpu = not self._CPU_TEST_DOUBLE
+        gpu = device.type == "cuda"
         # Q as the bf16 operand images of pass 2, written by the MLP forward (heads with padded K <= 16; zero-filled once, one
         # region per head); dZ as the FP6 operand image of pass 3, written by the MLP backward (C <= 8); the batch as a copy of
         # its own, tiled by pass 3's chunks, written by pass 2 (C <= 8) -- include/nadm.h

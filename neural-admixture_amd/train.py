@@ -52,8 +52,8 @@ def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_comp
     ``data_np``: uint8 [N,M] array or an io.PackedGenotypes.  With a GPU ``device`` and n_components <= 8 the
     projection runs on the GPU (pca_project_gpu); otherwise on the host, 1024 rows at a time like the reference.
     The mixture fit (``fit``): "sklearn" = the reference's scikit-learn call, "em" = its float64 restatement in device ops
-    (_gmm_em.py), "native" = the same on the host (gmm.py + csrc/nadm_gmm.cpp), "auto" = the device for N > 20000 on a GPU, the
-    host restatement otherwise -- all three give the library's means to 1e-10."""
+    (_gmm_em.py), "native" = "auto" = the same on the host (gmm.py + csrc/nadm_gmm.cpp) -- all three give the library's means to
+    1e-10."""
     N = data_np.shape[0]
     if device is not None and device.type == "cuda" and n_components <= 8:
         X_pca = pca_project_gpu(data_np, V_CM, device)
@@ -65,12 +65,11 @@ def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_comp
     X_pca = X_pca.astype("float64")
     ks = [K] if K is not None else list(range(min_k, max_k + 1))
     how = fit
-    on_gpu = device is not None and device.type == "cuda"
-    # "auto": the library's algorithm restated (same seeding draws, same EM, means equal to 1e-10 -- tests/test_abi_and_host.py) where it
-    # is fastest: on the host for 1000-Genomes-sized inputs (gmm.py + csrc/nadm_gmm.cpp: ~0.05 s where the library takes 0.55 s + a 1.0 s
-    # import, several K on threads), in device ops for N > 20000 on a GPU (_gmm_em.py: ~0.6 ms per iteration whatever N, where the
-    # library takes 22-45 s at N = 100k).  "sklearn": the library itself, several K as concurrent child processes.
-    if how == "em" or (how == "auto" and on_gpu and N > 20_000):
+    # "auto" / "native": the library's algorithm restated on the host (gmm.py + csrc/nadm_gmm.cpp: same seeding draws, same EM, means equal
+    # to 1e-10 -- tests/test_abi_and_host.py): ~0.05 s at N = 2504 where the library takes 0.55 s + a 1.0 s import, ~0.2 s at N = 100k
+    # (restarts and sample ranges on threads) where it takes 22-45 s; several K run concurrently.  "em": the same in float64 device ops
+    # (_gmm_em.py; pays the device BLAS's first-use cost).  "sklearn": the library itself, several K as concurrent child processes.
+    if how == "em":
         from ._gmm_em import fit_means as fit_means_device
         means = [fit_means_device(X_pca, k, seed, device) for k in ks]
     elif how in ("auto", "native"):
@@ -195,7 +194,7 @@ def _train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int
     optimizer on the rank's slice, all-gather); "snp" = SNPs sharded (snp_parallel.py): same trajectory up to summation order, two tiny all-reduces
     per step instead of the 4*M*(C+S)-byte one."""
     eng_cls = NeuralAdmixture.engine_snp_cls if parallelism == "snp" else NeuralAdmixture.engine_cls
-    if device.type != "cuda" and not eng_cls._CPU_TEST_DOUBLE:      # tests/ run this function over gloo with an oracle-backed double
+    if not eng_cls.supports(device):
         raise RuntimeError("neural_admixture_amd.train requires a ROCm GPU device; the CPU path is the reference's own")
     N, M = data.shape
     if n_components is None:

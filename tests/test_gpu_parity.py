@@ -1246,10 +1246,11 @@ def test_mixture_means_on_the_gpu_equal_the_library_fit():
     Gm = O.synth_genotypes(300, 4000, 3, seed=2)
     V = np.linalg.svd(Gm.astype(np.float32), full_matrices=False)[2][:8].astype(np.float32)
     res = {}
-    for how in ("em", "sklearn"):
+    for how in ("em", "sklearn", "native", "auto"):
         res[how] = gmm_p_init(Gm, V, None, 2, 4, 8, 42, dev, fit=how)
     a, b = res["em"], res["sklearn"]
     assert a.shape == b.shape == (9, 4000) and np.abs(a - b).max() < 1e-6
+    assert np.array_equal(res["auto"], res["native"]) and np.abs(res["native"] - b).max() < 1e-6      # the default: the host restatement (r05)
 
 
 @pytest.mark.parametrize("K", [5, 13, 20])
