@@ -3,9 +3,10 @@
 //                                   max_iter=100, random_state=seed).fit(X_pca).means_ ).
 // scikit-learn (>= 1.1.0, setup.cfg:29; 1.7.2 in this image) is a third-party dependency of the reference; this file restates the
 // published algorithm it runs for exactly that call -- EM for a full-covariance mixture (Dempster, Laird & Rubin 1977; Bishop, PRML
-// 9.2) with the library's conventions -- in float64 on the host, for 1000-Genomes-sized inputs: there the library's fit is ~480 EM
-// iterations of numpy calls on a [2504, 8] matrix, 0.55 s of a 1.9 s default run whose 250 epochs take 0.34 s, plus a 1.0 s import
-// (profiles/r05_init_profile_c2.txt).  Host code only; N > 20000 runs the same algorithm in device ops (_gmm_em.py).
+// 9.2) with the library's conventions -- in float64 on the host.  On a 1000-Genomes-sized input the library's fit is ~480 EM iterations of
+// numpy calls on a [2504, 8] matrix, 0.55 s of a 1.9 s default run whose 250 epochs take 0.34 s, plus a 1.0 s import
+// (profiles/r05_init_profile_c2.txt); here 0.02 s.  At N = 100k the library takes 22-45 s, this 0.8 s (tools/gmm_timing.py).  Host code
+// only; _gmm_em.py holds the same algorithm in device ops (train.gmm_p_init(fit="em")).
 //
 //   seeding   the only random draws are the k-means++ picks of K samples per restart; the CALLER makes them (gmm.kmeanspp_picks:
 //             numpy's RandomState stream consumed exactly as the library consumes it) and passes the K row indices of every restart.
@@ -21,9 +22,10 @@
 //             objectives within 1e-10 of the best count as tied and the first of them wins: the rule of exact arithmetic, and the same
 //             answer on every machine.
 // The restarts are independent once their seeds are known: they run on threads of their own, and each splits its sums over the
-// samples into up to 16 fixed ranges that run concurrently (n_parts) -- 100k samples fit in ~0.2 s where the library takes 22-45 s.
+// samples into up to 64 fixed ranges swept by a few worker threads (n_parts, Fit).
 #include "../../include/nadm.h"
 #include "nadm_host.h"
+#include <atomic>
 #include <cmath>
 #include <limits>
 #include <thread>
@@ -79,19 +81,32 @@ int precision_factor(const double* S, int d, double* U, double* logdet) {
 }
 
 // The sums over samples run over P fixed sample ranges ("parts": P depends on N only, never on the machine) whose partial sums are
-// combined in range order -- the same bits whatever the number of hardware threads; the parts of a step run on threads of their own.
+// combined in range order -- the same bits whatever the number of hardware threads.  A restart keeps W worker threads for its lifetime
+// (at most 8, see nadm_gmm_fit_means); a step is two sweeps over the parts with the combination in between,
+// sequenced by a spinning barrier (a thread per sweep costs more than the sweep: 49 parts x 200 sweeps x 5 restarts at N = 100k).
 int n_parts(int64_t N) {
-    const int64_t p = (N + 8191) / 8192;
-    return (int)(p < 1 ? 1 : (p > 16 ? 16 : p));
+    const int64_t p = (N + 2047) / 2048;
+    return (int)(p < 1 ? 1 : (p > 64 ? 64 : p));
 }
-template <typename F>
-void for_parts(int P, F&& fn) {
-    if (P == 1) { fn(0); return; }
-    std::vector<std::thread> th;
-    for (int q = 1; q < P; ++q) th.emplace_back([&fn, q] { fn(q); });
-    fn(0);
-    for (auto& t : th) t.join();
-}
+
+struct Barrier {
+    explicit Barrier(int n_) : n(n_) {}
+    void wait() {
+        if (n == 1) return;
+        const int g = gen.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+            count.store(0, std::memory_order_relaxed);
+            gen.fetch_add(1, std::memory_order_release);
+            return;
+        }
+        for (int spins = 0; gen.load(std::memory_order_acquire) == g; ++spins) {
+            if (spins < 1024) __builtin_ia32_pause();
+            else std::this_thread::yield();
+        }
+    }
+    const int n;
+    std::atomic<int> count{0}, gen{0};
+};
 
 struct Partial {                                                // one part's share of a step's sums
     double bound = 0.0;
@@ -99,8 +114,9 @@ struct Partial {                                                // one part's sh
 };
 
 // E step on the samples [i0, i1): responsibilities -> resp, the part's sum of log-likelihoods -> bound
-void e_part(const double* X, int64_t i0, int64_t i1, const Model& m, double* resp, Partial* out) {
-    const int K = m.K, d = m.d;
+template <int D>                                                // D = the dimension at compile time (0: read it from the model)
+void e_part_d(const double* X, int64_t i0, int64_t i1, const Model& m, double* resp, Partial* out) {
+    const int K = m.K, d = D ? D : m.d;
     const double c0 = (double)d * std::log(2.0 * M_PI);
     double total = 0.0;
     for (int64_t i = i0; i < i1; ++i) {
@@ -122,16 +138,18 @@ void e_part(const double* X, int64_t i0, int64_t i1, const Model& m, double* res
             if (lp[k] > mx) mx = lp[k];
         }
         double s = 0.0;
-        for (int k = 0; k < K; ++k) s += std::exp(lp[k] - mx);
-        const double norm = mx + std::log(s);
-        for (int k = 0; k < K; ++k) lp[k] = std::exp(lp[k] - norm);
-        total += norm;
+        for (int k = 0; k < K; ++k) { lp[k] = std::exp(lp[k] - mx); s += lp[k]; }
+        const double inv = 1.0 / s;
+        for (int k = 0; k < K; ++k) lp[k] *= inv;                // = exp(lp - norm) up to an ulp, for half the exponentials
+        total += mx + std::log(s);
     }
     out->bound = total;
 }
 
 // first half of the M step on [i0, i1): nk and sum r x
-void m1_part(const double* X, int64_t i0, int64_t i1, int K, int d, const double* resp, Partial* out) {
+template <int D>
+void m1_part_d(const double* X, int64_t i0, int64_t i1, int K, int d_, const double* resp, Partial* out) {
+    const int d = D ? D : d_;
     out->nk.assign(K, 0.0);
     out->sx.assign((size_t)K * d, 0.0);
     for (int64_t i = i0; i < i1; ++i) {
@@ -148,8 +166,9 @@ void m1_part(const double* X, int64_t i0, int64_t i1, int K, int d, const double
 }
 
 // second half on [i0, i1): sum r (x - mu)(x - mu)^T, upper triangle
-void m2_part(const double* X, int64_t i0, int64_t i1, const Model& m, const double* resp, Partial* out) {
-    const int K = m.K, d = m.d;
+template <int D>
+void m2_part_d(const double* X, int64_t i0, int64_t i1, const Model& m, const double* resp, Partial* out) {
+    const int K = m.K, d = D ? D : m.d;
     out->cov.assign((size_t)K * d * d, 0.0);
     for (int64_t i = i0; i < i1; ++i) {
         const double* x = X + i * d;
@@ -169,68 +188,122 @@ void m2_part(const double* X, int64_t i0, int64_t i1, const Model& m, const doub
     }
 }
 
-// M step from the responsibilities (optionally fused behind the E step of the same samples: `with_e`); returns 1 on a covariance that
-// is not positive definite.  *bound receives the mean log-likelihood per sample when with_e
-int em_step(const double* X, int64_t N, int P, double* resp, bool with_e, bool seeding, double reg, Model* m, double* bound) {
-    const int K = m->K, d = m->d;
-    std::vector<Partial> part(P);
-    auto range = [&](int q, int64_t* i0, int64_t* i1) { *i0 = N * q / P; *i1 = N * (q + 1) / P; };
-    for_parts(P, [&](int q) {
-        int64_t i0, i1;
-        range(q, &i0, &i1);
-        if (with_e) e_part(X, i0, i1, *m, resp, &part[q]);
-        m1_part(X, i0, i1, K, d, resp, &part[q]);
-    });
-    std::vector<double> nk(K, 0.0);
-    std::fill(m->mu.begin(), m->mu.end(), 0.0);
-    double total = 0.0;
-    for (int q = 0; q < P; ++q) {                               // fixed order
-        total += part[q].bound;
-        for (int k = 0; k < K; ++k) nk[k] += part[q].nk[k];
-        for (size_t e = 0; e < m->mu.size(); ++e) m->mu[e] += part[q].sx[e];
-    }
-    if (with_e) *bound = total / (double)N;
-    double nsum = 0.0;
-    for (int k = 0; k < K; ++k) {
-        nk[k] += 10.0 * std::numeric_limits<double>::epsilon();
-        nsum += nk[k];
-        for (int a = 0; a < d; ++a) m->mu[(size_t)k * d + a] /= nk[k];
-    }
-    for_parts(P, [&](int q) {
-        int64_t i0, i1;
-        range(q, &i0, &i1);
-        m2_part(X, i0, i1, *m, resp, &part[q]);
-    });
-    std::vector<double> cov((size_t)K * d * d, 0.0);
-    for (int q = 0; q < P; ++q)
-        for (size_t e = 0; e < cov.size(); ++e) cov[e] += part[q].cov[e];
-    for (int k = 0; k < K; ++k) {
-        double* c = &cov[(size_t)k * d * d];
-        for (int a = 0; a < d; ++a)
-            for (int b = a; b < d; ++b) {
-                const double v = c[a * d + b] / nk[k] + (a == b ? reg : 0.0);
-                c[a * d + b] = v; c[b * d + a] = v;
-            }
-        if (precision_factor(c, d, &m->U[(size_t)k * d * d], &m->logdet[k])) return 1;
-        m->logw[k] = std::log(seeding ? nk[k] / (double)N : nk[k] / nsum);
-    }
-    return 0;
+// (n_components = 8 is the reference's default, entry.py:33: its loops are unrolled and vectorised at compile time)
+void e_part(const double* X, int64_t i0, int64_t i1, const Model& m, double* resp, Partial* out) {
+    if (m.d == 8) e_part_d<8>(X, i0, i1, m, resp, out); else e_part_d<0>(X, i0, i1, m, resp, out);
+}
+void m1_part(const double* X, int64_t i0, int64_t i1, int K, int d, const double* resp, Partial* out) {
+    if (d == 8) m1_part_d<8>(X, i0, i1, K, d, resp, out); else m1_part_d<0>(X, i0, i1, K, d, resp, out);
+}
+void m2_part(const double* X, int64_t i0, int64_t i1, const Model& m, const double* resp, Partial* out) {
+    if (m.d == 8) m2_part_d<8>(X, i0, i1, m, resp, out); else m2_part_d<0>(X, i0, i1, m, resp, out);
 }
 
-void run_restart(const double* X, int64_t N, int d, int K, const int32_t* picks, double tol, int max_iter, double reg, Restart* out) {
-    Model m{K, d, std::vector<double>((size_t)K * d), std::vector<double>((size_t)K * d * d), std::vector<double>(K), std::vector<double>(K)};
-    std::vector<double> resp((size_t)N * K, 0.0);
-    const int P = n_parts(N);
-    for (int k = 0; k < K; ++k) resp[(size_t)picks[k] * K + k] = 1.0;
+// One restart: the model, the responsibilities, the parts' partial sums and the worker threads that sweep them
+struct Fit {
+    const double* X;
+    int64_t N;
+    int P, W;
+    Model m;
+    std::vector<double> resp;
+    std::vector<Partial> part;
+    Barrier bar;
+    bool with_e = false, stop = false;                          // published by the main thread before it releases the workers
+    std::vector<std::thread> workers;
+
+    Fit(const double* X_, int64_t N_, int d, int K, int W_)
+        : X(X_), N(N_), P(n_parts(N_)), W(W_ < 1 ? 1 : (W_ > n_parts(N_) ? n_parts(N_) : W_)),
+          m{K, d, std::vector<double>((size_t)K * d), std::vector<double>((size_t)K * d * d), std::vector<double>(K), std::vector<double>(K)},
+          resp((size_t)N_ * K, 0.0), part(n_parts(N_)), bar(W) {
+        for (int w = 1; w < W; ++w) workers.emplace_back([this, w] { work(w); });
+    }
+    ~Fit() {
+        stop = true;
+        bar.wait();
+        for (auto& t : workers) t.join();
+    }
+    void range(int q, int64_t* i0, int64_t* i1) const { *i0 = N * q / P; *i1 = N * (q + 1) / P; }
+    void sweep_a(int w) {                                       // [E step +] nk, sum r x of this worker's parts
+        for (int q = w; q < P; q += W) {
+            int64_t i0, i1;
+            range(q, &i0, &i1);
+            if (with_e) e_part(X, i0, i1, m, resp.data(), &part[q]);
+            m1_part(X, i0, i1, m.K, m.d, resp.data(), &part[q]);
+        }
+    }
+    void sweep_b(int w) {                                       // sum r (x - mu)(x - mu)^T
+        for (int q = w; q < P; q += W) {
+            int64_t i0, i1;
+            range(q, &i0, &i1);
+            m2_part(X, i0, i1, m, resp.data(), &part[q]);
+        }
+    }
+    void work(int w) {
+        for (;;) {
+            bar.wait();                                         // a step begins (or the fit ends)
+            if (stop) return;
+            sweep_a(w);
+            bar.wait();                                         // every part's first sums are in
+            bar.wait();                                         // the means are combined
+            sweep_b(w);
+            bar.wait();                                         // every part's covariance sums are in
+        }
+    }
+    // M step from the responsibilities, optionally behind the E step of the same samples; returns 1 on a covariance that is not positive
+    // definite.  *bound receives the mean log-likelihood per sample when e_first
+    int step(bool e_first, bool seeding, double reg, double* bound) {
+        const int K = m.K, d = m.d;
+        with_e = e_first;
+        bar.wait();
+        sweep_a(0);
+        bar.wait();
+        std::vector<double> nk(K, 0.0);
+        std::fill(m.mu.begin(), m.mu.end(), 0.0);
+        double total = 0.0;
+        for (int q = 0; q < P; ++q) {                           // fixed order
+            total += part[q].bound;
+            for (int k = 0; k < K; ++k) nk[k] += part[q].nk[k];
+            for (size_t e = 0; e < m.mu.size(); ++e) m.mu[e] += part[q].sx[e];
+        }
+        if (e_first) *bound = total / (double)N;
+        double nsum = 0.0;
+        for (int k = 0; k < K; ++k) {
+            nk[k] += 10.0 * std::numeric_limits<double>::epsilon();
+            nsum += nk[k];
+            for (int a = 0; a < d; ++a) m.mu[(size_t)k * d + a] /= nk[k];
+        }
+        bar.wait();
+        sweep_b(0);
+        bar.wait();
+        std::vector<double> cov((size_t)K * d * d, 0.0);
+        for (int q = 0; q < P; ++q)
+            for (size_t e = 0; e < cov.size(); ++e) cov[e] += part[q].cov[e];
+        for (int k = 0; k < K; ++k) {
+            double* c = &cov[(size_t)k * d * d];
+            for (int a = 0; a < d; ++a)
+                for (int b = a; b < d; ++b) {
+                    const double v = c[a * d + b] / nk[k] + (a == b ? reg : 0.0);
+                    c[a * d + b] = v; c[b * d + a] = v;
+                }
+            if (precision_factor(c, d, &m.U[(size_t)k * d * d], &m.logdet[k])) return 1;
+            m.logw[k] = std::log(seeding ? nk[k] / (double)N : nk[k] / nsum);
+        }
+        return 0;
+    }
+};
+
+void run_restart(const double* X, int64_t N, int d, int K, const int32_t* picks, double tol, int max_iter, double reg, int workers, Restart* out) {
+    Fit f(X, N, d, K, workers);
+    for (int k = 0; k < K; ++k) f.resp[(size_t)picks[k] * K + k] = 1.0;
     double bound = -std::numeric_limits<double>::infinity();
-    if (em_step(X, N, P, resp.data(), false, true, reg, &m, &bound)) { out->status = 1; return; }
+    if (f.step(false, true, reg, &bound)) { out->status = 1; return; }
     int it = 0;
     for (; it < max_iter; ++it) {
         const double prev = bound;
-        if (em_step(X, N, P, resp.data(), true, false, reg, &m, &bound)) { out->status = 1; return; }
+        if (f.step(true, false, reg, &bound)) { out->status = 1; return; }
         if (std::fabs(bound - prev) < tol) { ++it; break; }
     }
-    out->bound = bound; out->iters = it; out->means = m.mu;
+    out->bound = bound; out->iters = it; out->means = f.m.mu;
 }
 
 }  // namespace
@@ -243,8 +316,15 @@ extern "C" int nadm_gmm_fit_means(const double* X, int64_t N, int32_t d, int32_t
         if (picks[j] < 0 || picks[j] >= N) return fail("nadm_gmm_fit_means: a seed index lies outside the samples");
     std::vector<Restart> res(n_init);
     std::vector<std::thread> th;
-    for (int r = 1; r < n_init; ++r) th.emplace_back(run_restart, X, N, (int)d, (int)K, picks + (int64_t)r * K, tol, (int)max_iter, reg_covar, &res[r]);
-    run_restart(X, N, d, K, picks, tol, max_iter, reg_covar, &res[0]);
+    // worker threads per restart: the restarts run side by side, and the barriers spin -- never more threads than the host has
+    // (at most 8 each: the parts are ~2048 samples, a sweep is tens of microseconds per part, and a GPU host is shared -- 5 x 8 threads
+    // is the measured sweet spot on a 256-thread host: 51 each spent their time spinning on each other's hyperthreads)
+    int hw = (int)std::thread::hardware_concurrency();
+    if (hw < 1) hw = 1;
+    int workers = hw / (2 * n_init);
+    if (workers > 8) workers = 8;
+    for (int r = 1; r < n_init; ++r) th.emplace_back(run_restart, X, N, (int)d, (int)K, picks + (int64_t)r * K, tol, (int)max_iter, reg_covar, workers, &res[r]);
+    run_restart(X, N, d, K, picks, tol, max_iter, reg_covar, workers, &res[0]);
     for (auto& t : th) t.join();
     double top = -std::numeric_limits<double>::infinity();
     for (int r = 0; r < n_init; ++r) {
