@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak (same guide); the three GEMM-shaped products run as bf16 pieces
 N_SIMD = 256 * 4          # 256 CUs x 4 SIMDs
 VALU_CYCLES_PER_INST = 4  # one wave64 VALU instruction occupies its SIMD for 4 cycles (tools/ubench_valu.hip; packed f32 alike)
-PROFILE_ROUND = "r04"     # profiles/<round>_pmc_*.json hold the counter passes of the kernels of THIS build (tools/pmc_profile.py)
+PROFILE_ROUND = "r05"     # profiles/<round>_pmc_*.json hold the counter passes of the kernels of THIS build (tools/pmc_profile.py)
 
 
 def parse():
