@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true",
                     help="functional check of the N>1 flow on a ONE-GPU box: all ranks use cuda:0 and gloo carries the tensors "
                          "(RCCL refuses two ranks per device); not a measurement")
+    ap.add_argument("--no-epoch-loop", action="store_true", help="skip the production epoch loop behind the timed region (profiling passes: only the K-step kernels)")
     ap.add_argument("--cpu-rows", type=int, default=2400, help="rows of the same workload used for the bounded CPU baseline")
     ap.add_argument("--cpu-steps", type=int, default=12, help="timed steps of the CPU baseline (min / median / max reported)")
     return ap.parse_args()
@@ -388,7 +389,7 @@ def main():
     # only on the epochs that log it -- every 5th, neural_admixture.py:416) over whole epochs of the resident matrix.  Reported beside
     # the K-step figure, which stays the headline (`value`): that one computes the loss value on EVERY step like the reference does.
     full_run = None
-    if world == 1 and not snp and args.emulate_world is None and not args.force_ddp:
+    if world == 1 and not snp and args.emulate_world is None and not args.force_ddp and not args.no_epoch_loop:
         from neural_admixture_amd.model import _EpochOrders
         n_ep = 5                                                            # epochs 0..4: one logged epoch in five, like a default run
         orders = _EpochOrders(torch.Generator().manual_seed(42), rows_local, dev)

@@ -31,7 +31,7 @@ import json
 for f in ("default", "noloss", "ddp1", "ddp1_emul8", "b100", "ddp1_b100", "ddp1_b100_emul8", "c2", "c3", "c5_1gpu", "snp1_b6400"):
     d = json.loads(open(f"gpurun_out/r05_bench_{f}.json").read().strip().splitlines()[-1])
     r = d["roofline"]
-    print(f, round(d["ms_per_step"], 4), "host", round(d["host_queue_ms_per_step"], 4), "%.4g" % d["value"], {k: round(v * 1e3, 1) for k, v in r["kernel_ms"].items()}, round(r["frac_8d"], 4),
+    print(f, round(d["ms_per_step"], 4), "host", round(d["host_queue_ms_per_step"], 4), "%.4g" % d["value"], {k: (round(v * 1e3, 1) if not isinstance(v, list) else [round(x * 1e3, 1) for x in v]) for k, v in r["kernel_ms"].items()}, round(r["frac_8d"], 4),
           round(r["frac_min"], 4), r["traffic"], r.get("issue_frac"), r.get("valu_busy_frac"), r.get("mfma_busy_frac"),
           (r["issue"] or {}).get("valu_insts_per_genotype"))
 for l in open("gpurun_out/r05_full_runs.txt"):
