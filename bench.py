@@ -197,7 +197,7 @@ def cpu_baseline_reference_shaped(eng, args, dev):
     del Gd
     sm = eng.small.cpu().numpy()
     h, K = L.heads, L.ks[0]
-    cores = os.cpu_count() or 1
+    cores = max(1, (os.cpu_count() or 2) // 2)      # one thread per physical core (the elementwise chain is memory-bound: SMT siblings add nothing)
     prev = torch.get_num_threads()
     torch.set_num_threads(cores)
     torch.set_float32_matmul_precision("highest")
@@ -206,7 +206,7 @@ def cpu_baseline_reference_shaped(eng, args, dev):
                              sm[h.b1_off:h.b1_off + L.Hd], [sm[h.wk_off[0]:h.wk_off[0] + K * L.Hd].reshape(K, L.Hd)], [sm[h.bk_off[0]:h.bk_off[0] + K]], 2e-3)
         m.step(G[:b])                                  # warm-up (thread pool, allocator)
         times = []
-        for s_ in range(3):
+        for s_ in range(2):
             t0 = time.perf_counter()
             m.step(G[(s_ % (n // b)) * b:(s_ % (n // b) + 1) * b])
             times.append(time.perf_counter() - t0)
@@ -215,7 +215,7 @@ def cpu_baseline_reference_shaped(eng, args, dev):
     return {"value": b * L.M / float(np.median(times)), "unit": "genotypes/s", "cores": cores, "kind": "port",
             "shape": "the reference's operator sequence on torch CPU ops, fp32 (oracle/torch_shape.py)",
             "step_s": {"min": float(np.min(times)), "median": float(np.median(times)), "max": float(np.max(times)), "n": len(times)},
-            "sample": f"3 timed steps (after 1 warm-up) of {b} rows x {L.M} SNPs, torch {torch.__version__} CPU, {cores} threads",
+            "sample": f"2 timed steps (after 1 warm-up) of {b} rows x {L.M} SNPs, torch {torch.__version__} CPU, {cores} threads",
             "reference_itself_in_the_survey_container": {"value": 9.2e7, "cores": 8, "source": "BASELINE.md section 2: the unmodified reference, "
                                                          "8 Xeon cores (AMX bf16 matmuls), 8000 x 50000, K=8 -- another machine, quoted for scale"}}
 
