@@ -15,9 +15,17 @@ def fit_means(X_pca: np.ndarray, k: int, seed: int) -> np.ndarray:
     limit = None
     try:                                    # the matrices are [N, n_components <= 8]: a BLAS/OpenMP pool of 64-256 threads only
         from threadpoolctl import threadpool_info, threadpool_limits     # adds overhead (2x on a 256-thread host, identical means)
-        pools = threadpool_info()
-        if pools and max(p_["num_threads"] for p_ in pools) > 4:         # only ever LOWER the count: raising a pool that was
-            limit = threadpool_limits(limits=4)                           # started with OMP_NUM_THREADS=1 crashes OpenBLAS
+        # only ever LOWER a pool: raising one that came up with fewer threads (OPENBLAS_NUM_THREADS=1 in the environment, which the CLI
+        # sets like the reference's does, entry.py:138-146) crashes OpenBLAS inside the fit.  threadpoolctl limits per API, so the
+        # API's limit is the smallest of 4 and what any of its libraries has now (r05: scipy's OpenBLAS, first loaded here, started with 1
+        # while numpy's had 64 -- "limits=4" raised it and the fit died in trtrs)
+        per_api = {}
+        for p_ in threadpool_info():
+            api, n = p_.get("user_api"), p_.get("num_threads")
+            if api and n:
+                per_api[api] = min(per_api.get(api, 4), n, 4)
+        if per_api:
+            limit = threadpool_limits(limits=per_api)
     except ImportError:
         pass
     try:

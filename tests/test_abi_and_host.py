@@ -454,6 +454,25 @@ def test_native_savetxt_matches_numpy_bytes(tmp_path):
     assert np.allclose(np.loadtxt(tmp_path / "f64.txt"), Q)
 
 
+def test_library_fit_never_raises_a_thread_pool(tmp_path):
+    """r05 crash: the CLI exports OPENBLAS_NUM_THREADS / OMP_NUM_THREADS = --threads (default 1) like the reference's (entry.py:138-146);
+    scipy's OpenBLAS, first loaded by the library fit AFTER that, comes up with one thread, and "limit every pool to 4" RAISED it -- the
+    fit then segfaults inside trtrs.  _gmm_fit.fit_means only ever lowers.  In a child process: the libraries must load in that order."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np\n"
+        "np.linalg.qr(np.random.rand(300, 20))\n"                         # numpy's OpenBLAS is up with the host's thread count
+        "os.environ['OPENBLAS_NUM_THREADS'] = '1'; os.environ['OMP_NUM_THREADS'] = '1'\n"
+        f"sys.path.insert(0, {repr(os.path.join(ROOT, 'neural-admixture_amd'))})\n"
+        "import _gmm_fit\n"                                               # (stand-alone module: numpy + sklearn only)
+        "X = np.random.default_rng(0).standard_normal((3000, 8))\n"
+        "m = _gmm_fit.fit_means(X, 6, 1)\n"
+        "print('means', m.shape)\n")
+    r = subprocess.run([sys.executable, "-W", "ignore", "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "means (6, 8)" in r.stdout, (r.returncode, r.stderr[-500:])
+
+
 def test_parallel_gmm_fits_equal_sequential_ones():
     """Multi-head init: one sklearn GMM per K (train.py:65-67) fitted in concurrent child processes (_gmm_fit.py) gives
     exactly the means of the in-process sequential fits."""
