@@ -392,6 +392,8 @@ def main():
     if world == 1 and not snp and args.emulate_world is None and not args.force_ddp and not args.no_epoch_loop:
         from neural_admixture_amd.model import _EpochOrders
         n_ep = 5                                                            # epochs 0..4: one logged epoch in five, like a default run
+        host_threads = torch.get_num_threads()
+        torch.set_num_threads(1)                                            # like the trainer: the loop is launches only (model.launch_training)
         orders = _EpochOrders(torch.Generator().manual_seed(42), rows_local, dev)
         torch.cuda.synchronize()
         t_e = time.perf_counter()
@@ -407,6 +409,7 @@ def main():
         eng.sync()
         torch.cuda.synchronize()
         ep_s = (time.perf_counter() - t_e) / n_ep
+        torch.set_num_threads(host_threads)
         full_run = {"epoch_ms_full_run": ep_s * 1e3, "genotypes_per_s": rows_local * M / ep_s, "epochs_timed": n_ep,
                     "steps_per_epoch": (rows_local + b - 1) // b,
                     "note": "production epoch loop, loss value on logged epochs only (1 in 5); `value` above computes it on every step"}
