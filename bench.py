@@ -74,7 +74,6 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true",
                     help="functional check of the N>1 flow on a ONE-GPU box: all ranks use cuda:0 and gloo carries the tensors "
                          "(RCCL refuses two ranks per device); not a measurement")
-    ap.add_argument("--no-v-image", action="store_true", help="A/B: pass 1 on the bf16 instruction from V itself instead of the FP4 x FP6 instruction on V's operand image")
     ap.add_argument("--no-epoch-loop", action="store_true", help="skip the production epoch loop behind the timed region (profiling passes: only the K-step kernels)")
     ap.add_argument("--cpu-rows", type=int, default=2400, help="rows of the same workload used for the bounded CPU baseline")
     ap.add_argument("--cpu-steps", type=int, default=12, help="timed steps of the CPU baseline (min / median / max reported)")
@@ -314,7 +313,7 @@ def main():
             comm_a = nacomm.emulated_comm(args.emulate_world) if args.emulate_world is not None else nacomm.make_comm(dev, rank, world)
         n_buckets = args.buckets if args.buckets is not None else na.NeuralAdmixture.dp_buckets
         eng = na.Engine(M, 8, args.hidden, ks, dev, b, mode="dp" if ddp else "single", comm=comm if ddp else None,
-                        n_buckets=n_buckets if ddp else 1, comm_a=comm_a, p3_whole=args.p3_whole, pass1_image=not args.no_v_image)
+                        n_buckets=n_buckets if ddp else 1, comm_a=comm_a, p3_whole=args.p3_whole)
         eng.set_packed(make_dataset(eng, rows_local, rank * rows_local, K, dev))
         gperm = torch.Generator(device="cpu").manual_seed(1000 + rank)
     eng.load_params(V0, P0, init_encoder_weights(42, 8, args.hidden, ks))

@@ -202,8 +202,7 @@ typedef struct {
 } nadm_mlp_weights_t;
 int nadm_encode_bwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                          const float* dZ, const void* dzimg, int32_t CP, float* V, float* dV, const nadm_adam_t* adam,
-                         const nadm_mlp_weights_t* weights, int32_t flags /* NADM_X_CLEAN, see nadm_encode_bwd */,
-                         void* vimg /* may be NULL; with adam: the updated rows also as pass 1's operand image, nadm_v_image */, void* stream);
+                         const nadm_mlp_weights_t* weights, int32_t flags /* NADM_X_CLEAN, see nadm_encode_bwd */, void* stream);
 int nadm_small_grads(const float* small_part, int32_t splits, int32_t n_small, float* grad_small, float* small,
                      const nadm_adam_t* adam, void* stream);
 /* nadm_encode_fwd of the NEXT step with nadm_small_grads of this one riding in the same launch as side blocks (pass 1 reads
@@ -391,8 +390,6 @@ typedef struct nadm_plan_desc {
     void* qimg; int64_t qimg_head_bytes;  /* nadm_mlp_fwd_images (zero-filled once)                                            */
     void* dzimg; int32_t* dzcnt;          /* nadm_mlp_bwd_image  (C <= 8; counters zero-filled once)                            */
     uint8_t* xg;                          /* nadm_batch_copy_bytes(bmax, M) (C <= 8)                                            */
-    void* vimg;                           /* nadm_v_image_bytes(M) (C <= 8; NULL: pass 1 on the bf16 instruction): V as pass 1's
-                                           * operand image, kept current by pass 3's epilogue / behind message B's all-gather    */
     double* loss_acc;                     /* [2]: running sum, last step                                                        */
     const nadm_comm_t* comm;              /* NULL: one rank.  Must outlive the plan                                             */
     const nadm_comm_t* comm_a;            /* DP mode: a second communicator for message A (NULL: `comm` carries both)           */

@@ -56,7 +56,7 @@ class PlanDesc(C.Structure):
     _fields_ = ([("mode", C.c_int32), ("bmax", C.c_int32), ("M", C.c_int64), ("ld", C.c_int64), ("heads", Heads), ("xp", C.c_void_p)]
                 + [(n, C.c_void_p) for n in ("params", "grads", "m", "v", "zpart", "Z", "rinv", "Zn", "H", "Q", "dL", "dHpre", "dgp", "dZ",
                                              "dqpart", "losspart", "small_part", "zsum", "dqsum", "qimg")]
-                + [("qimg_head_bytes", C.c_int64), ("dzimg", C.c_void_p), ("dzcnt", C.c_void_p), ("xg", C.c_void_p), ("vimg", C.c_void_p), ("loss_acc", C.c_void_p),
+                + [("qimg_head_bytes", C.c_int64), ("dzimg", C.c_void_p), ("dzcnt", C.c_void_p), ("xg", C.c_void_p), ("loss_acc", C.c_void_p),
                    ("comm", C.POINTER(CommStruct)), ("comm_a", C.POINTER(CommStruct)), ("n_buckets", C.c_int32), ("p3_whole", C.c_int32),
                    ("debug", C.c_int32), ("reserved", C.c_int32)])
 
@@ -112,7 +112,7 @@ def _load():
         "nadm_mlp_fwd_images": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, i64, vp]),
         "nadm_q_image_bytes": (C.c_int64, [i32]),
         "nadm_encode_fwd_small": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp]),
-        "nadm_encode_bwd_step": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp]),
+        "nadm_encode_bwd_step": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, i32, vp, vp, vp, vp, i32, vp]),
         "nadm_small_grads": (C.c_int, [vp, i32, i32, vp, vp, vp, vp]),
         "nadm_mlp_bwd": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]),
         "nadm_mlp_bwd_image": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]),

@@ -82,8 +82,8 @@ __device__ __forceinline__ float adam_element(float p, float g, float& m, float&
     if (clamp01) np_ = fminf(fmaxf(np_, 0.f), 1.f);
     return np_;
 }
-__device__ __forceinline__ float4 adam_float4(float* __restrict__ p, const float4 G4, float* __restrict__ m, float* __restrict__ v,
-                                              float step_size, float inv_bc2, float grad_scale, bool clamp01) {       // returns the updated parameters
+__device__ __forceinline__ void adam_float4(float* __restrict__ p, const float4 G4, float* __restrict__ m, float* __restrict__ v,
+                                            float step_size, float inv_bc2, float grad_scale, bool clamp01) {
     const float4 P4 = *reinterpret_cast<const float4*>(p);
     const float4 M4 = *reinterpret_cast<const float4*>(m);
     const float4 V4 = *reinterpret_cast<const float4*>(v);
@@ -94,7 +94,6 @@ __device__ __forceinline__ float4 adam_float4(float* __restrict__ p, const float
     *reinterpret_cast<float4*>(p) = make_float4(pp[0], pp[1], pp[2], pp[3]);
     *reinterpret_cast<float4*>(m) = make_float4(mm[0], mm[1], mm[2], mm[3]);
     *reinterpret_cast<float4*>(v) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-    return make_float4(pp[0], pp[1], pp[2], pp[3]);
 }
 
 // ---- bf16 pieces of an fp32 value (round-to-nearest-even conversions, v_cvt_pk_bf16_f32) ----
@@ -194,20 +193,21 @@ constexpr int VI_SLICE = 256;
 __host__ __device__ constexpr int vi_snp(int j, int q, int e) {
     return 64 * q + 32 * j + 16 * (e >> 4) + 4 * ((e & 7) >> 1) + 2 * (e & 1) + ((e >> 3) & 1);
 }
-// one thread: pieces p0 .. p0 + NP - 1 of column c of K-block q of tile tl (0..3) of a 512-SNP chunk whose V rows sit in LDS (sv [512][CP],
-// rows past M zeroed): v_image_kernel's staging buffer, or the rows pass 3's Adam epilogue has just updated
-template <int CP, int NP>
-__device__ __forceinline__ void vi_build_pieces_lds(const float* sv, uint4* img_chunk, int tl, int q, int c, int p0) {
+// one thread: piece p of column c of K-block q of tile T of the image of V [M, CP] (global memory; SNPs past M and columns past CP are 0)
+__device__ __forceinline__ void vi_build_piece(const float* __restrict__ V, int64_t M, int CP, uint4* img, int64_t T, int q, int c, int p) {
     float v[32];
+    const int64_t m0 = (T >> 1) * VI_SLICE;
+    const int j = (int)(T & 1);
 #pragma unroll
-    for (int e = 0; e < 32; ++e) v[e] = c < CP ? sv[((tl >> 1) * VI_SLICE + vi_snp(tl & 1, q, e)) * CP + c] : 0.f;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        u32x6_t codes;
-        int sb;
-        fp6_piece(v, p0 + p, codes, sb);
-        fp6_piece_store(img_chunk + tl * DZI_TILE_U4, q, c, p0 + p, codes, sb);
+    for (int e = 0; e < 32; ++e) {
+        const int64_t m = m0 + vi_snp(j, q, e);
+        const float x = V[(m < M ? m : M - 1) * CP + (c < CP ? c : 0)];
+        v[e] = (m < M && c < CP) ? x : 0.f;
     }
+    u32x6_t codes;
+    int sb;
+    fp6_piece(v, p, codes, sb);
+    fp6_piece_store(img + T * DZI_TILE_U4, q, c, p, codes, sb);
 }
 
 // ---- Q as the MFMA operand images of the bf16 pass 2 (K <= 16), one image per head and 64-sample tile --------------------------

@@ -1275,23 +1275,10 @@ __global__ __launch_bounds__(256) void dz_image_kernel(const float* __restrict__
     dzi_build_piece<false>(dZ, b, CP, img, blockIdx.x, tid >> 6, (tid >> 3) & 7, tid & 7);
 }
 
-// the image of V [M, CP] for pass 1 on the same instruction (nadm_common.h): a block = 512 SNPs = 4 tiles, staged through LDS with full
-// 16-byte lines and cut by the function pass 3's Adam epilogue uses on the rows it has just updated (same arithmetic, same bits)
-template <int CP>
-__global__ __launch_bounds__(256) void v_image_kernel(const float* __restrict__ V, int64_t M, uint4* __restrict__ img) {
-    __shared__ __attribute__((aligned(16))) float s_v[2 * VI_SLICE * CP];
+// the image of V [M, CP] for pass 1 on the same instruction (nadm_common.h, vi_build_piece): grid = tiles of 128 SNPs, 256 threads
+__global__ __launch_bounds__(256) void v_image_kernel(const float* __restrict__ V, int64_t M, int CP, uint4* __restrict__ img) {
     const int tid = threadIdx.x;
-    const int64_t m0 = (int64_t)blockIdx.x * (2 * VI_SLICE);
-    constexpr int ROW4 = CP / 4;
-    for (int e = tid; e < 2 * VI_SLICE * ROW4; e += 256) {
-        const int64_t m = m0 + e / ROW4;
-        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M) v4 = *reinterpret_cast<const float4*>(V + m * CP + 4 * (e % ROW4));
-        *reinterpret_cast<float4*>(s_v + 4 * e) = v4;
-    }
-    __syncthreads();
-    const int grp = tid >> 1, half = tid & 1;
-    vi_build_pieces_lds<CP, 4>(s_v, img + (int64_t)blockIdx.x * 4 * DZI_TILE_U4, grp >> 5, (grp >> 3) & 3, grp & 7, 4 * half);
+    vi_build_piece(V, M, CP, img, (int64_t)blockIdx.x, tid >> 6, (tid >> 3) & 7, tid & 7);
 }
 
 // =================================================================================================
@@ -1422,8 +1409,7 @@ template <int CP, bool CLEAN_SRC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void encode_bwd_fp4_kernel(const uint8_t* __restrict__ xp, int64_t ld,
                                                               const int32_t* __restrict__ idx, int b, int64_t M,
                                                               const uint4* __restrict__ dzimg, float* __restrict__ dV,
-                                                              uint32_t missing_bf16, float* __restrict__ Vrw, AdamFused ad, MlpSide side,
-                                                              uint4* __restrict__ vimg) {
+                                                              uint32_t missing_bf16, float* __restrict__ Vrw, AdamFused ad, MlpSide side) {
     static_assert(CP <= 8, "rows of the instruction: piece parity x 8 columns");
     {   // blocks past the SNP chunks: the MLP weight-gradient partials (independent of pass 3; see mlp_bwd_b_block)
         const int64_t nchunks = (M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS;
@@ -1609,26 +1595,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     {
         constexpr int ROW4 = CP / 4;
         const int64_t m0 = chunk * EB_CHUNK_SNPS;
-        const bool image = vimg != nullptr && ad.m != nullptr;      // (block-uniform)
         for (int e = tid; e < EB_CHUNK_SNPS * ROW4; e += 256) {
             const int64_t m = m0 + e / ROW4;
-            float4 vnew = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < M) {
                 const float4 g4 = *reinterpret_cast<const float4*>(s_dv + 4 * e);
                 const int64_t o = m * CP + 4 * (e % ROW4);
-                if (ad.m != nullptr) vnew = adam_float4(Vrw + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.inv_bc2, ad.grad_scale, false);
+                if (ad.m != nullptr) adam_float4(Vrw + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.inv_bc2, ad.grad_scale, false);
                 else *reinterpret_cast<float4*>(dV + o) = g4;
             }
-            if (image) *reinterpret_cast<float4*>(s_dv + 4 * e) = vnew;        // the updated rows take the gradient's place (rows past M: zeros)
-        }
-        // ---- r05: the updated V rows as pass 1's operand image (nadm_common.h: the block's 512 SNPs = 4 tiles of 128).  The next step's
-        // pass 1 then needs neither V itself nor the per-block split of its slice into matrix operands ----
-        if (image) {
-            __syncthreads();
-            static_assert(EB_CHUNK_SNPS == 2 * VI_SLICE, "a block's chunk = two image slices");
-            uint4* const img_chunk = vimg + chunk * 4 * DZI_TILE_U4;
-            const int grp = tid >> 1, half = tid & 1;                 // 128 (tile, K-block, column) groups x two halves of the eight pieces
-            vi_build_pieces_lds<CP, 4>(s_dv, img_chunk, grp >> 5, (grp >> 3) & 3, grp & 7, 4 * half);
         }
     }
 }
@@ -1846,18 +1820,14 @@ extern "C" int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx
     return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0u);
 }
 
-extern "C" int64_t nadm_v_image_bytes(int64_t M) {      // whole 512-SNP chunks (the builders write four tiles at a time)
-    return 4 * ((M + 2 * nadm::VI_SLICE - 1) / (2 * nadm::VI_SLICE)) * (int64_t)nadm::DZI_TILE_U4 * 16;
-}
+extern "C" int64_t nadm_v_image_bytes(int64_t M) { return 2 * ((M + nadm::VI_SLICE - 1) / nadm::VI_SLICE) * (int64_t)nadm::DZI_TILE_U4 * 16; }
 
 extern "C" int nadm_v_image(const float* V, int64_t M, int32_t CP, void* vimg, void* stream) {
     if (!V || !vimg) return fail("nadm_v_image: null pointer");
     if (M <= 0 || CP <= 0 || CP > 8) return fail("nadm_v_image: M > 0 and 0 < CP <= 8 (the matrix-core pass 1)");
     if ((uintptr_t)vimg & 15) return fail("nadm_v_image: the image must be 16-byte aligned");
-    if (CP != 4 && CP != 8) return fail("nadm_v_image: CP is the padded width (4 or 8)");
-    const dim3 grid((unsigned)((M + 2 * VI_SLICE - 1) / (2 * VI_SLICE)));
-    if (CP == 4) hipLaunchKernelGGL((v_image_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, V, M, (uint4*)vimg);
-    else hipLaunchKernelGGL((v_image_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, V, M, (uint4*)vimg);
+    const int64_t tiles = 2 * ((M + VI_SLICE - 1) / VI_SLICE);
+    hipLaunchKernelGGL(v_image_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, V, M, (int)CP, (uint4*)vimg);
     return check_launch("v_image");
 }
 
@@ -1985,7 +1955,7 @@ extern "C" int nadm_dz_image(const float* dZ, int32_t b, int32_t CP, void* dzimg
 static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                            const float* dZ, const void* dzimg, int32_t CP, float* dV, void* stream, uint32_t missing_bf16, int32_t flags = 0,
                            float* Vrw = nullptr, AdamFused ad = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f},
-                           const nadm_mlp_weights_t* mw = nullptr, void* vimg = nullptr) {
+                           const nadm_mlp_weights_t* mw = nullptr) {
     if (!xp || !idx || !dZ || !dV) return fail("nadm_encode_bwd: null pointer");
     if (CP > 8 && (flags & NADM_X_CLEAN)) return fail("nadm_encode_bwd: the batch copy (NADM_X_CLEAN) is tiled for the matrix-core pass, C <= 8");
     if (CP <= 8 && (!dzimg || ((uintptr_t)dzimg & 15)))
@@ -2004,8 +1974,7 @@ static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
             extra = (int64_t)side.gx * nadm_sample_splits(b);
         }
         dim3 g2((unsigned)((M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS + extra));
-        if (vimg && (((uintptr_t)vimg & 15) || !ad.m)) return fail("nadm_encode_bwd_step: the image of V is written by the Adam epilogue (adam != NULL), 16-byte aligned");
-#define NADM_P3_LAUNCH(CPV, CL) hipLaunchKernelGGL((encode_bwd_fp4_kernel<CPV, CL>), g2, block, 0, st, xp, ld, idx, b, M, (const uint4*)dzimg, dV, missing_bf16, Vrw, ad, side, (uint4*)vimg)
+#define NADM_P3_LAUNCH(CPV, CL) hipLaunchKernelGGL((encode_bwd_fp4_kernel<CPV, CL>), g2, block, 0, st, xp, ld, idx, b, M, (const uint4*)dzimg, dV, missing_bf16, Vrw, ad, side)
         const bool clean = (flags & NADM_X_CLEAN) != 0 && missing_bf16 == 0u;
         if (CP == 4) { if (clean) NADM_P3_LAUNCH(4, true); else NADM_P3_LAUNCH(4, false); }
         else { if (clean) NADM_P3_LAUNCH(8, true); else NADM_P3_LAUNCH(8, false); }
@@ -2026,14 +1995,13 @@ static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
 
 extern "C" int nadm_encode_bwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                                     const float* dZ, const void* dzimg, int32_t CP, float* V, float* dV, const nadm_adam_t* adam,
-                                    const nadm_mlp_weights_t* weights, int32_t flags, void* vimg, void* stream) {
+                                    const nadm_mlp_weights_t* weights, int32_t flags, void* stream) {
     AdamFused ad;
     if (adam_fused_args(adam, "nadm_encode_bwd_step: Adam state is NULL", &ad)) return 1;
     if (ad.m && (!V || ((uintptr_t)V & 15))) return fail("nadm_encode_bwd_step: V must be non-NULL and 16-byte aligned");
     if (weights && (!weights->hd || !weights->Zn || !weights->H || !weights->dL || !weights->dHpre || !weights->dgp || !weights->small_part))
         return fail("nadm_encode_bwd_step: null pointer in the MLP weight-gradient arguments");
-    if (vimg && CP > 8) return fail("nadm_encode_bwd_step: the image of V exists for C <= 8");
-    return encode_bwd_impl(xp, ld, idx, b, M, dZ, dzimg, CP, dV, stream, 0u, flags, V, ad, weights, vimg);
+    return encode_bwd_impl(xp, ld, idx, b, M, dZ, dzimg, CP, dV, stream, 0u, flags, V, ad, weights);
 }
 
 extern "C" int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,

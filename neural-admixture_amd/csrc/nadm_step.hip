@@ -286,7 +286,6 @@ struct nadm_plan {
     int pend_splits = 0, pend_step = 0;
     float pend_lr = 0.f, pend_scale = 1.f;
     bool a_pending = false, b_pending = false;
-    bool vimg_valid = false;                                     // d.vimg holds the image of the CURRENT V (pass 3's epilogue / nadm_v_image behind message B keep it so)
     int last_b = 0;                                              // batch size of the previous step (dZ image hygiene, see nadm_step)
     // DP: message A on `side`, message B bucket by bucket on `side_b`; the parts 1.. of a pass 1 launched in parts on `fan`
     int nb = 1;                                                  // buckets of message B
@@ -337,13 +336,6 @@ struct Timed {                                                   // RAII-free: b
 
 float* P_of(nadm_plan* p, float* flat, int h) { return flat + p->lay.off_p[h]; }
 
-// V as pass 1's operand image (C <= 8 and the caller gave the buffer): the part of it that belongs to the SNPs from m0 on (m0 a multiple of 512)
-bool use_vimg(const nadm_plan* p) { return p->d.vimg != nullptr && p->d.heads.CP <= 8; }
-char* vimg_at(const nadm_plan* p, int64_t m0) { return (char*)p->d.vimg + nadm_v_image_bytes(m0); }
-int build_vimg(nadm_plan* p, int64_t m0, int64_t m1, void* stream) {
-    return nadm_v_image(p->d.params + p->lay.off_v + m0 * p->d.heads.CP, m1 - m0, p->d.heads.CP, vimg_at(p, m0), stream);
-}
-
 nadm_adam_t adam_at(nadm_plan* p, int64_t off, float lr, int step, float scale) {
     return nadm_adam_t{p->d.m + off, p->d.v + off, lr, step, scale, 0};
 }
@@ -369,12 +361,7 @@ int encode_fwd_parts(nadm_plan* p, const int32_t* idx, int b, hipStream_t st) {
         if (j > 0) HIP_OK(hipStreamWaitEvent(fs, p->ev_fork1, 0), "hipStreamWaitEvent");
         if (p->b_pending) HIP_OK(hipStreamWaitEvent(fs, p->ev_g[j], 0), "hipStreamWaitEvent");
         const int64_t m0 = p->lay.bkt_m0[j], m1 = p->lay.bkt_m0[j + 1];
-        if (use_vimg(p)) {               // (the image is rebuilt behind every all-gather of a bucket; here only after parameters came from outside)
-            if (!p->vimg_valid && build_vimg(p, m0, m1, fs)) return 1;
-            if (nadm_encode_fwd_img(d.xp + m0 / 4, d.ld, idx, b, m1 - m0, vimg_at(p, m0), hd.CP, d.zpart + nadm_encode_chunks(m0) * (int64_t)b * hd.CP,
-                                    p->nb > 1 ? p->enc_chunks : 0, nullptr, 0, 0, nullptr, nullptr, nullptr, fs))
-                return 1;
-        } else if (p->nb == 1) {
+        if (p->nb == 1) {
             if (nadm_encode_fwd(d.xp, d.ld, idx, b, d.M, V, hd.CP, d.zpart, fs)) return 1;
         } else if (nadm_encode_fwd_part(d.xp + m0 / 4, d.ld, idx, b, m1 - m0, V + m0 * hd.CP, hd.CP, d.zpart + nadm_encode_chunks(m0) * (int64_t)b * hd.CP,
                                         p->enc_chunks, fs)) {
@@ -383,7 +370,6 @@ int encode_fwd_parts(nadm_plan* p, const int32_t* idx, int b, hipStream_t st) {
         if (j > 0) HIP_OK(hipEventRecord(p->ev_p1[j], fs), "hipEventRecord");
     }
     for (int j = 1; j < p->nb; ++j) HIP_OK(hipStreamWaitEvent(st, p->ev_p1[j], 0), "hipStreamWaitEvent");
-    if (use_vimg(p)) p->vimg_valid = true;
     p->b_pending = false;                                        // the compute stream has (transitively) waited for every bucket
     return 0;
 }
@@ -397,18 +383,6 @@ int forward(nadm_plan* p, const int32_t* idx, int b, void* stream) {
     if (t1.begin()) return 1;
     if (d.mode == NADM_MODE_DP) {
         if (encode_fwd_parts(p, idx, b, (hipStream_t)stream)) return 1;
-    } else if (use_vimg(p)) {
-        // pass 1 on the FP4 x FP6 instruction: V as the operand image pass 3's Adam epilogue left (built here after parameters came from
-        // outside); the small update the previous step left rides as side blocks like in the bf16 pass
-        if (!p->vimg_valid) {
-            if (build_vimg(p, 0, d.M, stream)) return 1;
-            p->vimg_valid = true;
-        }
-        const nadm_adam_t sa = adam_at(p, 0, p->pend_lr, p->pend_step, p->pend_scale);
-        if (nadm_encode_fwd_img(d.xp, d.ld, idx, b, d.M, d.vimg, hd.CP, d.zpart, 0, p->small_pending ? d.small_part : nullptr, p->pend_splits, hd.n_small,
-                                p->small_pending ? d.grads : nullptr, p->small_pending ? d.params : nullptr, p->small_pending ? &sa : nullptr, stream))
-            return 1;
-        p->small_pending = false;
     } else if (p->small_pending && hd.CP <= 8) {
         const nadm_adam_t sa = adam_at(p, 0, p->pend_lr, p->pend_step, p->pend_scale);
         if (nadm_encode_fwd_small(d.xp, d.ld, idx, b, d.M, V, hd.CP, d.zpart, d.small_part, p->pend_splits, hd.n_small, d.grads, d.params, &sa, stream))
@@ -596,7 +570,6 @@ extern "C" int nadm_plan_set_state(nadm_plan_t* p, int32_t step_count, int32_t p
     if (!p || step_count < 0) return fail("nadm_plan_set_state: null pointer or negative step count");
     p->step_count = step_count;
     p->p_unit = p_in_unit_range != 0;
-    p->vimg_valid = false;                                       // (parameters came from outside: the image of V is rebuilt before the next pass 1)
     return 0;
 }
 
@@ -724,7 +697,7 @@ static int step_impl(nadm_plan_t* p, const int32_t* idx, int32_t b, float lr, in
                 const int64_t m0 = parts ? p->lay.bkt_m0[j] : 0, m1 = parts ? p->lay.bkt_m0[j + 1] : d.M;
                 const uint8_t* xsrc = image ? d.xg + (m0 / 4) * (int64_t)b : d.xp + m0 / 4;
                 if (nadm_encode_bwd_step(xsrc, d.ld, idx, b, m1 - m0, d.dZ, image ? d.dzimg : nullptr, hd.CP, V + m0 * hd.CP, dV + m0 * hd.CP, nullptr,
-                                         j == 0 ? &mw : nullptr, p3_flags, nullptr, stream))
+                                         j == 0 ? &mw : nullptr, p3_flags, stream))
                     return 1;
                 if (!parts || j == p->nb - 1) { if (t4.end()) return 1; }
                 if (p->nb > 1)
@@ -738,7 +711,6 @@ static int step_impl(nadm_plan_t* p, const int32_t* idx, int32_t b, float lr, in
             if (msg_reduce(p, d.comm, p->lay.bkt_off[j], p->lay.bkt_slice[j], sb)) return 1;
             if (msg_update(p, p->lay.bkt_off[j], p->lay.bkt_slice[j], p->lay.bkt_mom[j], false, lr, sb)) return 1;
             if (msg_gather(p, d.comm, p->lay.bkt_off[j], p->lay.bkt_slice[j], sb)) return 1;
-            if (use_vimg(p) && build_vimg(p, p->lay.bkt_m0[j], p->lay.bkt_m0[j + 1], sb)) return 1;     // the gathered range as pass 1's operand image
             if (tj.end()) return 1;
             if (p->nb > 1) HIP_OK(hipEventRecord(p->ev_g[j], sb), "hipEventRecord");
         }
@@ -753,9 +725,7 @@ static int step_impl(nadm_plan_t* p, const int32_t* idx, int32_t b, float lr, in
     Timed t4{p, NADM_T_ENCODE_BWD, st};
     if (t4.begin()) return 1;
     const nadm_adam_t av = adam_at(p, p->lay.off_v, lr, p->step_count, scale);
-    if (nadm_encode_bwd_step(image ? d.xg : d.xp, d.ld, idx, b, d.M, d.dZ, image ? d.dzimg : nullptr, hd.CP, V, dV, &av, &mw, p3_flags,
-                             use_vimg(p) ? d.vimg : nullptr, stream))
-        return 1;
+    if (nadm_encode_bwd_step(image ? d.xg : d.xp, d.ld, idx, b, d.M, d.dZ, image ? d.dzimg : nullptr, hd.CP, V, dV, &av, &mw, p3_flags, stream)) return 1;
     if (t4.end()) return 1;
 
     // ---- the small parameters

@@ -44,8 +44,7 @@ class Engine:
         return device.type == "cuda"
 
     def __init__(self, M: int, C_: int, Hd: int, ks: Sequence[int], device: torch.device, max_batch: int,
-                 mode: str = "single", comm=None, n_buckets: int = 1, comm_a=None, p3_whole: bool = False, debug: bool = False,
-                 pass1_image: bool = True):
+                 mode: str = "single", comm=None, n_buckets: int = 1, comm_a=None, p3_whole: bool = False, debug: bool = False):
         if not self.supports(device):
             raise RuntimeError("neural_admixture_amd.Engine needs a ROCm GPU device (no CPU fallback)")
         if mode not in _MODES:
@@ -90,9 +89,6 @@ class Engine:
         self._dzcnt = torch.zeros((b + 31) // 32, dtype=torch.int32, device=device)      # group counters of nadm_mlp_bwd_image
         self._xg = torch.empty(int(lib.nadm_batch_copy_bytes(b, self.M)), dtype=torch.uint8, device=device) if tiled else None
         self._iota = torch.arange(b, dtype=torch.int32, device=device) if tiled else None
-        # V as the FP6 operand image of pass 1 (C <= 8): kept current by pass 3's Adam epilogue / behind message B's all-gather (nadm_step);
-        # pass1_image=False runs pass 1 on the bf16 instruction from V itself (A/B, bench.py --no-v-image)
-        self._vimg = (torch.empty(int(lib.nadm_v_image_bytes(self.M)), dtype=torch.uint8, device=device) if tiled and pass1_image else None)
         # validity of the three by-products for the plain phases below (the plan's own step always produces what it consumes)
         self._qimg_b = self._dzimg_b = -1
         self._dz_last_b = 0
@@ -115,7 +111,7 @@ class Engine:
                         ("Z", self.Z), ("rinv", self.rinv), ("Zn", self.Zn), ("H", self.H), ("Q", self._Q), ("dL", self.dL),
                         ("dHpre", self.dHpre), ("dgp", self.dgp), ("dZ", self._dZ), ("dqpart", self.dqpart), ("losspart", self.losspart),
                         ("small_part", self.small_part), ("zsum", self._zsum), ("dqsum", self._dqsum), ("qimg", self.qimg),
-                        ("dzimg", self._dzimg), ("dzcnt", self._dzcnt), ("xg", self._xg), ("vimg", self._vimg), ("loss_acc", self.loss_acc)):
+                        ("dzimg", self._dzimg), ("dzcnt", self._dzcnt), ("xg", self._xg), ("loss_acc", self.loss_acc)):
             setattr(d, name, None if t is None else t.data_ptr())
         d.qimg_head_bytes = self._qimg_head
         d.n_buckets, d.p3_whole, d.debug = L.n_buckets, int(self.p3_whole), int(self.debug)
@@ -335,11 +331,6 @@ class Engine:
         L = self.lay
         if b > self.bmax:
             raise RuntimeError("batch larger than the engine was sized for")
-        if self._vimg is not None:       # the production pass 1: V as its operand image (built here; the step keeps it current by itself)
-            check(lib.nadm_v_image(ptr(self.big[: L.M * L.CP]), L.M, L.CP, ptr(self._vimg), _stream()), "v_image")
-            check(lib.nadm_encode_fwd_img(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self._vimg), L.CP, ptr(self.zpart), 0, None, 0, 0, None, None,
-                                          None, _stream()), "encode_fwd_img")
-            return
         check(lib.nadm_encode_fwd(ptr(self.xp), self.ld, ptr(idx), b, L.M, ptr(self.big[: L.M * L.CP]), L.CP, ptr(self.zpart), _stream()), "encode_fwd")
 
     def mlp_forward(self, b: int, z_src: Optional[torch.Tensor] = None, n_chunks: Optional[int] = None) -> None:

@@ -1,8 +1,7 @@
 """The single-GPU training step as its UNFUSED launch sequence, straight on the C ABI (TEST INFRASTRUCTURE).
 
 The production step (Engine.train_step) hands Q to pass 2 as ready-made operand images, lets the MLP backward's last blocks build
-pass 3's operand image of dZ, lets pass 3's Adam epilogue build pass 1's operand image of V, and leaves the small-parameter update to
-side blocks of the NEXT step's pass 1.  Here every one of
+pass 3's operand image of dZ, and leaves the small-parameter update to side blocks of the NEXT step's pass 1.  Here every one of
 those is a plain launch of its own at the place the arithmetic belongs: nadm_mlp_fwd (no images), nadm_mlp_bwd (no image) +
 nadm_dz_image, nadm_small_grads right behind pass 3.  Same element functions, same reduction orders: the two sequences must
 leave the same bits in every parameter and moment (tests/test_soak_handoffs.py)."""
@@ -21,12 +20,7 @@ def unfused_step(e, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True
     L = e.lay
     big, mbig, vbig, gbig, small = e.big, e.mbig, e.vbig, e.gbig, e.small      # (the accessors settle what the last step still owes)
     msmall, vsmall, gsmall = e.msmall, e.vsmall, e.gsmall
-    if e._vimg is not None:              # C <= 8: pass 1 on V's operand image -- built here by a launch of its own, by pass 3's epilogue in production
-        check(lib.nadm_v_image(ptr(big), L.M, L.CP, ptr(e._vimg), st), "v_image")
-        check(lib.nadm_encode_fwd_img(ptr(e.xp), e.ld, ptr(idx), b, L.M, ptr(e._vimg), L.CP, ptr(e.zpart), 0, None, 0, 0, None, None, None, st),
-              "encode_fwd_img")
-    else:
-        check(lib.nadm_encode_fwd(ptr(e.xp), e.ld, ptr(idx), b, L.M, ptr(big), L.CP, ptr(e.zpart), st), "encode_fwd")
+    check(lib.nadm_encode_fwd(ptr(e.xp), e.ld, ptr(idx), b, L.M, ptr(big), L.CP, ptr(e.zpart), st), "encode_fwd")
     check(lib.nadm_mlp_fwd(C.byref(L.heads), ptr(small), ptr(e.zpart), L.enc_chunks, b, ptr(e.Z), ptr(e.rinv), ptr(e.Zn), ptr(e.H),
                            ptr(e._Q), st), "mlp_fwd")
     e.step_count += 1
@@ -58,7 +52,7 @@ def unfused_step(e, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True
     av = AdamArgs(mbig.data_ptr(), vbig.data_ptr(), lr, e.step_count, 1.0, 0)
     src, rows, flags = (xg, e._iota, NADM_X_CLEAN) if tiled else (e.xp, idx, 0)
     check(lib.nadm_encode_bwd_step(ptr(src), e.ld, ptr(rows), b, L.M, ptr(e._dZ), dzimg, L.CP, ptr(big), ptr(gbig), C.byref(av), C.byref(mw),
-                                   flags, None, st), "encode_bwd_step")
+                                   flags, st), "encode_bwd_step")
     sa = AdamArgs(msmall.data_ptr(), vsmall.data_ptr(), lr, e.step_count, 1.0, 0)
     check(lib.nadm_small_grads(ptr(e.small_part), int(lib.nadm_sample_splits(b)), L.n_small, ptr(gsmall), ptr(small), C.byref(sa), st),
           "small_grads")
