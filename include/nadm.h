@@ -41,7 +41,7 @@ extern "C" {
 #define NADM_MAX_HEADS 32
 #define NADM_MAX_K 64
 #define NADM_MAX_BUCKETS 8
-#define NADM_ABI_VERSION 11  /* 11: V as the operand image of pass 1 on the FP4 x FP6 instruction (nadm_v_image(_bytes), nadm_encode_fwd_img, nadm_plan_desc_t.vimg, nadm_encode_bwd_step writes it); 10: message B of the sample-sharded step in SNP-range buckets (nadm_flat_layout takes n_buckets, nadm_flat_layout_t.bkt_*, nadm_plan_desc_t.n_buckets / p3_whole / comm_a / debug, nadm_encode_fwd_part, nadm_plan_bucket_ms), nadm_comm_t.async_error, nadm_comm_rccl_probe, nadm_comm_rccl with a watchdog (timeout_ms), a failed step poisons its plan; 9: nadm_step / nadm_plan_* / nadm_comm_* / nadm_flat_layout (the step as one call, sharded optimizer), nadm_test_force_generic_mlp; 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
+#define NADM_ABI_VERSION 10  /* 10: message B of the sample-sharded step in SNP-range buckets (nadm_flat_layout takes n_buckets, nadm_flat_layout_t.bkt_*, nadm_plan_desc_t.n_buckets / p3_whole / comm_a / debug, nadm_encode_fwd_part, nadm_plan_bucket_ms), nadm_comm_t.async_error, nadm_comm_rccl_probe, nadm_comm_rccl with a watchdog (timeout_ms), a failed step poisons its plan; 9: nadm_step / nadm_plan_* / nadm_comm_* / nadm_flat_layout (the step as one call, sharded optimizer), nadm_test_force_generic_mlp; 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
@@ -211,21 +211,6 @@ int nadm_small_grads(const float* small_part, int32_t splits, int32_t n_small, f
 int nadm_encode_fwd_small(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                           const float* V, int32_t CP, float* zpart, const float* small_part, int32_t splits, int32_t n_small,
                           float* grad_small, float* small, const nadm_adam_t* adam, void* stream);
-
-/* ---- a4/a5 on the FP4 x FP6 matrix instruction (r05): V as an OPERAND IMAGE -------------------------------------------------------------
- * nadm_encode_fwd splits every block's slice of V into bf16 operands (as much work as 11 of its sample tiles) and converts 64 codes per
- * lane and tile; with V handed over as an image -- FP6 pieces + E8M0 scales per 32 SNPs x column, laid out per lane of
- * v_mfma_scale_f32_16x16x128_f8f6f4 like the image of dZ pass 3 consumes (below), built ONCE per step -- the 2-bit codes enter as FP4
- * numbers without a conversion.  vimg: nadm_v_image_bytes(M) bytes, 16-byte aligned; nadm_v_image builds it from V [M, CP] (CP <= 8);
- * nadm_encode_bwd_step builds it for the rows it updates when handed the buffer (the Adam epilogue has them in registers).
- * nadm_encode_fwd_img = nadm_encode_fwd (+ _part's total_chunks, 0 = this launch's own; + _small's side work when small_part != NULL)
- * on the image: same partial-sum layout; results agree with nadm_encode_fwd to fp32 rounding (products exact, 32 bits below the block
- * maximum of V), not bit for bit.  A sub-range launch passes vimg + (m0 / 256) * 2 tiles of 7168 bytes. */
-int64_t nadm_v_image_bytes(int64_t M);
-int nadm_v_image(const float* V, int64_t M, int32_t CP, void* vimg, void* stream);
-int nadm_encode_fwd_img(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M, const void* vimg, int32_t CP,
-                        float* zpart, int64_t total_chunks, const float* small_part, int32_t splits, int32_t n_small, float* grad_small,
-                        float* small, const nadm_adam_t* adam, void* stream);
 
 /* ---- a11: MLP backward (softmax, Linear, ReLU, RMSNorm) ---------------------------------- */
 /* Reduces dqpart (the heads' slabs laid back to back in head order, head h holding

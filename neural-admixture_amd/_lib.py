@@ -95,9 +95,6 @@ def _load():
         "nadm_bed_to_packed_dev": (C.c_int, [vp, i64, i64, vp, i64, vp, i32, vp, vp]),
         "nadm_encode_fwd": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp]),
         "nadm_encode_fwd_part": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i64, vp]),
-        "nadm_v_image_bytes": (i64, [i64]),
-        "nadm_v_image": (C.c_int, [vp, i64, i32, vp, vp]),
-        "nadm_encode_fwd_img": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i64, vp, i32, i32, vp, vp, vp, vp]),
         "nadm_pca_project": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp]),
         "nadm_pca_project_t": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, i32, vp, vp]),
         "nadm_loglik_blocks": (i64, [i64]),
@@ -154,7 +151,7 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.nadm_abi_version() != 11:
+    if lib.nadm_abi_version() != 10:
         raise RuntimeError("neural_admixture_amd: libnadm.so ABI version mismatch")
     return lib, tuple(sig)
 

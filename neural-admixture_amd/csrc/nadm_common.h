@@ -182,34 +182,6 @@ __device__ __forceinline__ void dzi_build_piece(const float* dZ, int b, int CP, 
     fp6_piece_store(img + (int64_t)T * DZI_TILE_U4, q, c, p, codes, sb);
 }
 
-// ---- V as the operand image of pass 1 on the FP4 x FP6 matrix instruction (C <= 8, r05; encode_fwd_fp4_kernel) ------------------------
-// The dZ image's tile format with K = SNPs: one tile (7 x 64 uint4; lanes = (K-block q, piece parity, column c); fp6_piece /
-// fp6_piece_store above) per 128 SNPs of V [M, CP]; tiles 2 s and 2 s + 1 belong to the 256-SNP slice s that one wave of pass 1 owns.
-// Which SNP is element e of K-block q of tile 2 s + j follows from how pass 1 makes its FP4 operand: a lane loads the 16 packed bytes =
-// 64 SNPs 64 q .. 64 q + 63 of its sample's row; bytes 8 j .. 8 j + 7 (two dwords w0, w1) are tile j's K-block q; operand registers
-// 0 / 1 = the codes 0, 2 / 1, 3 of every byte of w0 (w0 & 0x33333333, (w0 >> 2) & 0x33333333), registers 2 / 3 the same of w1 -- a nibble
-// 00cc IS the FP4 number c / 2, no conversion.  Element e sits in register e >> 3, nibble e & 7.
-constexpr int VI_SLICE = 256;
-__host__ __device__ constexpr int vi_snp(int j, int q, int e) {
-    return 64 * q + 32 * j + 16 * (e >> 4) + 4 * ((e & 7) >> 1) + 2 * (e & 1) + ((e >> 3) & 1);
-}
-// one thread: piece p of column c of K-block q of tile T of the image of V [M, CP] (global memory; SNPs past M and columns past CP are 0)
-__device__ __forceinline__ void vi_build_piece(const float* __restrict__ V, int64_t M, int CP, uint4* img, int64_t T, int q, int c, int p) {
-    float v[32];
-    const int64_t m0 = (T >> 1) * VI_SLICE;
-    const int j = (int)(T & 1);
-#pragma unroll
-    for (int e = 0; e < 32; ++e) {
-        const int64_t m = m0 + vi_snp(j, q, e);
-        const float x = V[(m < M ? m : M - 1) * CP + (c < CP ? c : 0)];
-        v[e] = (m < M && c < CP) ? x : 0.f;
-    }
-    u32x6_t codes;
-    int sb;
-    fp6_piece(v, p, codes, sb);
-    fp6_piece_store(img + T * DZI_TILE_U4, q, c, p, codes, sb);
-}
-
 // ---- Q as the MFMA operand images of the bf16 pass 2 (K <= 16), one image per head and 64-sample tile --------------------------
 // Every block of pass 2 (1954 of them at M = 500k) needs the batch's Q as bf16 pieces laid out as its MFMA operands; built
 // from the fp32 Q inside pass 2 that is two split3 and 16 two-byte LDS stores per thread and tile, 3.5 % of the kernel without

@@ -172,28 +172,6 @@ __device__ __forceinline__ int64_t xcd_chunk(const unsigned bid, const unsigned 
     return (int64_t)(x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / NX;
 }
 
-// the side work of a pass-1 launch (block `blk` of it): 512 elements of the small parameters -- the sum of the previous step's
-// weight-gradient partials and, with Adam state, their update
-__device__ __forceinline__ void small_side_block(const SmallSide& ss, int blk) {
-    const int e = blk * 512 + (int)threadIdx.x;
-    if (e >= ss.n) return;
-    float mq = 0.f, vq = 0.f, pq = 0.f;
-    if (ss.m != nullptr) { mq = ss.m[e]; vq = ss.v[e]; pq = ss.p[e]; }
-    float a = 0.f;                                       // the order of additions of sum_splits() (nadm_small_kernels.hip)
-    for (int j0 = 0; j0 < ss.splits; j0 += 32) {
-        float v[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = ss.part[(int64_t)(j0 + u < ss.splits ? j0 + u : ss.splits - 1) * ss.n + e];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) if (j0 + u < ss.splits) a += v[u];
-    }
-    ss.out[e] = a;
-    if (ss.m != nullptr) {
-        ss.p[e] = adam_element(pq, a, mq, vq, ss.step_size, ss.inv_bc2, ss.grad_scale, false);
-        ss.m[e] = mq; ss.v[e] = vq;
-    }
-}
-
 template <int CP>
 __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __restrict__ xp, int64_t ld,
                                                               const int32_t* __restrict__ idx, int b, int64_t M,
@@ -204,7 +182,23 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
     // the slots the partly filled last round leaves empty instead of pushing main blocks of the first round back
     const int n_main = n_chunks * n_splits;
     if ((int)blockIdx.x >= n_main) {
-        small_side_block(ss, (int)blockIdx.x - n_main);
+        const int e = ((int)blockIdx.x - n_main) * 512 + (int)threadIdx.x;
+        if (e >= ss.n) return;
+        float mq = 0.f, vq = 0.f, pq = 0.f;
+        if (ss.m != nullptr) { mq = ss.m[e]; vq = ss.v[e]; pq = ss.p[e]; }
+        float a = 0.f;                                       // the order of additions of sum_splits() (nadm_small_kernels.hip)
+        for (int j0 = 0; j0 < ss.splits; j0 += 32) {
+            float v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] = ss.part[(int64_t)(j0 + u < ss.splits ? j0 + u : ss.splits - 1) * ss.n + e];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) if (j0 + u < ss.splits) a += v[u];
+        }
+        ss.out[e] = a;
+        if (ss.m != nullptr) {
+            ss.p[e] = adam_element(pq, a, mq, vq, ss.step_size, ss.inv_bc2, ss.grad_scale, false);
+            ss.m[e] = mq; ss.v[e] = vq;
+        }
         return;
     }
     static_assert(EM_D * 128 == 64 * EM_WAVES, "one output element per thread in the cross-wave combine");
@@ -1275,133 +1269,6 @@ __global__ __launch_bounds__(256) void dz_image_kernel(const float* __restrict__
     dzi_build_piece<false>(dZ, b, CP, img, blockIdx.x, tid >> 6, (tid >> 3) & 7, tid & 7);
 }
 
-// the image of V [M, CP] for pass 1 on the same instruction (nadm_common.h, vi_build_piece): grid = tiles of 128 SNPs, 256 threads
-__global__ __launch_bounds__(256) void v_image_kernel(const float* __restrict__ V, int64_t M, int CP, uint4* __restrict__ img) {
-    const int tid = threadIdx.x;
-    vi_build_piece(V, M, CP, img, (int64_t)blockIdx.x, tid >> 6, (tid >> 3) & 7, tid & 7);
-}
-
-// =================================================================================================
-// pass 1 on the FP4 x FP6 matrix instruction (CP <= 8, r05): Z = X.V on v_mfma_scale_f32_16x16x128_f8f6f4.
-//   The bf16 kernel above spends its time on two things this one does not do: every block first splits its 2048 x CP slice of V into
-//   bf16 operands (as much work as 11 of its sample tiles), and every tile converts 64 codes per lane to bf16 (32 conversions) for 16
-//   MFMAs.  Here V arrives as an OPERAND IMAGE built once per step (v_image_kernel, or pass 3's Adam epilogue, which has the new V rows
-//   in its hands): FP6 pieces -- the eight hexadecimal digits of |V| below the maximum of 32 SNPs x one column, exact products with the
-//   2-bit codes, 32 bits below that maximum (the dZ image's format, nadm_common.h) -- and the codes enter as FP4 numbers after two mask
-//   operations per 16 SNPs.  D = (piece parity, column) x samples; 8 instructions of K = 128 SNPs per 16 samples x 256 SNPs.
-//   Block shape, row loads, cross-wave combine and the side blocks are the bf16 kernel's.
-// =================================================================================================
-template <int CP>
-__global__ __launch_bounds__(512) void encode_fwd_fp4_kernel(const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b,
-                                                             int64_t M, const uint4* __restrict__ vimg, float* __restrict__ zpart,
-                                                             int tiles_per_block, uint32_t missing_bf16, int n_chunks, int n_splits, SmallSide ss) {
-    static_assert(CP <= 8, "rows of the instruction: piece parity x 8 columns");
-    const int n_main = n_chunks * n_splits;
-    if ((int)blockIdx.x >= n_main) {
-        small_side_block(ss, (int)blockIdx.x - n_main);
-        return;
-    }
-    static_assert(EM_D * 128 == 64 * EM_WAVES && EM_SLICE == VI_SLICE, "one output element per thread in the cross-wave combine; a wave owns one image slice");
-    __shared__ __attribute__((aligned(16))) float s_z[2][EM_WAVES][EM_D][16 * 8];
-    __shared__ __attribute__((aligned(16))) float s_out[EM_TILES_PER_BLOCK][16 * 8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 15, q = lane >> 4;
-    const int64_t vwork = xcd_chunk(blockIdx.x, (unsigned)n_main);
-    const int64_t chunk = vwork / n_splits;
-    const int tile_begin = (int)(vwork % n_splits) * tiles_per_block;
-    const int tile_end = min((b + 15) / 16, tile_begin + tiles_per_block);
-    const uint32_t kmiss = missing_bf16 == 0u ? 0x55555555u : 0u;        // model: code 3 -> 0; init-time products: 1.5 = the nibble's own FP4 value
-    // ---- A operands: the two image tiles of this wave's 256-SNP slice, 2 x (24 dwords + a word of four scale bytes) per lane ----
-    const int64_t slice = chunk * EM_WAVES + wave;
-    const bool slice_ok = slice * VI_SLICE < M;                          // (a chunk past M has no image)
-    uint32_t za[2][24];
-    int zs[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const uint4* zi = vimg + ((slice_ok ? slice : 0) * 2 + j) * DZI_TILE_U4 + lane;
-        uint4 z[7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) z[k] = zi[64 * k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { za[j][4 * k] = z[k].x; za[j][4 * k + 1] = z[k].y; za[j][4 * k + 2] = z[k].z; za[j][4 * k + 3] = z[k].w; }
-        zs[j] = (int)z[6].x;
-    }
-    const int64_t byte_off = chunk * (EM_CHUNK_SNPS / 4) + wave * (EM_SLICE / 4) + 16 * q;
-    const bool col_ok = byte_off * 4 < M;          // not `< ld`: on an SNP sub-range launch the bytes past M belong to the next range
-    const int64_t byte_off_c = col_ok ? byte_off : 0;
-    // (SNPs past M inside the last piece: their image entries are zero, whatever the codes say)
-    auto row_of = [&](int tile) -> int32_t {
-        const int smp = tile * 16 + i;
-        return idx[smp < b ? smp : b - 1];
-    };
-    auto load_row = [&](int32_t row) -> uint4 { return *reinterpret_cast<const uint4*>(xp + (int64_t)row * ld + byte_off_c); };
-    uint4 st[EM_D];
-    int32_t rown[EM_D];
-#pragma unroll
-    for (int d = 0; d < EM_D - 1; ++d) rown[d] = row_of(tile_begin + d);
-#pragma unroll
-    for (int d = 0; d < EM_D - 1; ++d) {
-        st[d] = load_row(rown[d]);
-        rown[(d + EM_D - 1) % EM_D] = row_of(tile_begin + d + EM_D - 1);
-    }
-    for (int tile0 = tile_begin; tile0 < tile_end; tile0 += EM_D) {
-        const int buf = ((tile0 - tile_begin) / EM_D) & 1;
-#pragma unroll
-        for (int u = 0; u < EM_D; ++u) {
-            const int tile = tile0 + u;
-            if (tile < tile_end) {                                // block-uniform
-                st[(u + EM_D - 1) % EM_D] = load_row(rown[(u + EM_D - 1) % EM_D]);
-                rown[(u + 2 * EM_D - 2) % EM_D] = row_of(tile + 2 * EM_D - 2);
-                const uint32_t okm = (col_ok && slice_ok) ? lt_mask(tile * 16 + i, b) : 0u;
-                const uint4 cur = st[u];
-                uint32_t r[4] = {cur.x & okm, cur.y & okm, cur.z & okm, cur.w & okm};
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const uint32_t m3 = r[w] & (r[w] >> 1) & kmiss;          // low bit of every code that is 3
-                    r[w] ^= m3 | (m3 << 1);
-                }
-                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const i32x8_t bx = {(int)(r[2 * j] & 0x33333333u), (int)((r[2 * j] >> 2) & 0x33333333u), (int)(r[2 * j + 1] & 0x33333333u),
-                                        (int)((r[2 * j + 1] >> 2) & 0x33333333u), 0, 0, 0, 0};
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) {
-                        const i32x8_t az = {(int)za[j][6 * rg], (int)za[j][6 * rg + 1], (int)za[j][6 * rg + 2], (int)za[j][6 * rg + 3], (int)za[j][6 * rg + 4],
-                                            (int)za[j][6 * rg + 5], 0, 0};
-                        switch (rg) {      // (the byte of the scale word is an immediate of the instruction)
-                            case 0: acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(az, bx, acc, 2, 4, 0, zs[j], 0, 127); break;
-                            case 1: acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(az, bx, acc, 2, 4, 1, zs[j], 0, 127); break;
-                            case 2: acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(az, bx, acc, 2, 4, 2, zs[j], 0, 127); break;
-                            default: acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(az, bx, acc, 2, 4, 3, zs[j], 0, 127); break;
-                        }
-                    }
-                }
-                // D rows 4 q + r = (piece parity q >> 1, column 4 (q & 1) + r), column i = sample: fold the parities (32 lanes apart)
-                float o[4];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) o[rr] = acc[rr] + __shfl_xor(acc[rr], 32, 64);
-                if (q < 2) *reinterpret_cast<float4*>(&s_z[buf][wave][u][i * 8 + 4 * q]) = make_float4(o[0], o[1], o[2], o[3]);
-            }
-        }
-        __syncthreads();
-        {
-            const int u = tid >> 7, e = tid & 127;
-            if (tile0 + u < tile_end) {
-                float sum = 0.f;
-#pragma unroll
-                for (int w = 0; w < EM_WAVES; ++w) sum += s_z[buf][w][u][e];
-                s_out[tile0 + u - tile_begin][e] = sum;
-            }
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < (tile_end - tile_begin) * 128; e += 512) {
-        const int smp = tile_begin * 16 + (e >> 3), c = e & 7;
-        if (smp < b && c < CP) zpart[(chunk * b + smp) * CP + c] = (&s_out[0][0])[e];
-    }
-}
-
 constexpr int EB4_XS = 132;               // bytes per byte column of the LDS tile: 128 samples + 4 (dword stride 33: the loader's 4-byte
                                           // stores of 32 consecutive column quads and the 4-byte column reads spread over the banks)
 // CLEAN_SRC: xp is pass 2's copy of the batch (xg_piece: tiled by this kernel's chunks, rows in batch order, missing calls already 0)
@@ -1721,10 +1588,8 @@ static int enc_rows_per_block(int b) {
 
 static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                            const float* V, int32_t CP, float* zpart, void* stream, uint32_t missing_bf16,
-                           SmallSide ss = SmallSide{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f}, int64_t total_chunks = 0,
-                           const uint4* vimg = nullptr) {
-    if (!xp || !idx || (!V && !vimg) || !zpart) return fail("nadm_encode_fwd: null pointer");
-    if (vimg && (CP > 8 || ((uintptr_t)vimg & 15))) return fail("nadm_encode_fwd_img: the image of V exists for C <= 8 and is 16-byte aligned");
+                           SmallSide ss = SmallSide{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f}, int64_t total_chunks = 0) {
+    if (!xp || !idx || !V || !zpart) return fail("nadm_encode_fwd: null pointer");
     if (b <= 0 || M <= 0) return fail("nadm_encode_fwd: empty batch or M");
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_encode_fwd: ld must be a multiple of 16 and >= ceil(M/4)");
     const int rpb = enc_rows_per_block(b);
@@ -1756,10 +1621,8 @@ static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
         const int64_t fill_chunks = total_chunks > chunks ? total_chunks : chunks;
         int64_t gy = 1;
         double best = 1e30;
-        // (with the image of V a block's prologue is 14 loads per lane instead of the operand build, and a tile costs ~0.6 of a bf16 tile)
-        const double prologue = vimg ? 2.5 : 11.3;
         for (int64_t g = 1; g <= 64 && g <= (ntiles + 3) / 4; ++g) {
-            const double cost = rounds_eff((double)(fill_chunks * g) / slots) * (prologue + (double)((ntiles + g - 1) / g));
+            const double cost = rounds_eff((double)(fill_chunks * g) / slots) * (11.3 + (double)((ntiles + g - 1) / g));
             if (cost < best) { best = cost; gy = g; }
         }
         int tpb = (int)((ntiles + gy - 1) / gy);
@@ -1767,11 +1630,6 @@ static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
         gy = (ntiles + tpb - 1) / tpb;
         const int side_blocks = ss.part ? (ss.n + 511) / 512 : 0;
         dim3 g2((unsigned)(chunks * gy + side_blocks)), b2(512);
-        if (vimg) {
-            if (CP == 4) hipLaunchKernelGGL((encode_fwd_fp4_kernel<4>), g2, b2, 0, st, xp, ld, idx, b, M, vimg, zpart, tpb, missing_bf16, (int)chunks, (int)gy, ss);
-            else hipLaunchKernelGGL((encode_fwd_fp4_kernel<8>), g2, b2, 0, st, xp, ld, idx, b, M, vimg, zpart, tpb, missing_bf16, (int)chunks, (int)gy, ss);
-            return check_launch("encode_fwd_fp4");
-        }
         if (CP == 4) hipLaunchKernelGGL((encode_fwd_mfma_kernel<4>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16, (int)chunks, (int)gy, ss);
         else hipLaunchKernelGGL((encode_fwd_mfma_kernel<8>), g2, b2, 0, st, xp, ld, idx, b, M, V, zpart, tpb, missing_bf16, (int)chunks, (int)gy, ss);
         return check_launch("encode_fwd_mfma");
@@ -1818,35 +1676,6 @@ static int adam_fused_args(const nadm_adam_t* adam, const char* who, AdamFused* 
 extern "C" int nadm_encode_fwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                                const float* V, int32_t CP, float* zpart, void* stream) {
     return encode_fwd_impl(xp, ld, idx, b, M, V, CP, zpart, stream, 0u);
-}
-
-extern "C" int64_t nadm_v_image_bytes(int64_t M) { return 2 * ((M + nadm::VI_SLICE - 1) / nadm::VI_SLICE) * (int64_t)nadm::DZI_TILE_U4 * 16; }
-
-extern "C" int nadm_v_image(const float* V, int64_t M, int32_t CP, void* vimg, void* stream) {
-    if (!V || !vimg) return fail("nadm_v_image: null pointer");
-    if (M <= 0 || CP <= 0 || CP > 8) return fail("nadm_v_image: M > 0 and 0 < CP <= 8 (the matrix-core pass 1)");
-    if ((uintptr_t)vimg & 15) return fail("nadm_v_image: the image must be 16-byte aligned");
-    const int64_t tiles = 2 * ((M + VI_SLICE - 1) / VI_SLICE);
-    hipLaunchKernelGGL(v_image_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, V, M, (int)CP, (uint4*)vimg);
-    return check_launch("v_image");
-}
-
-extern "C" int nadm_encode_fwd_img(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M, const void* vimg, int32_t CP,
-                                   float* zpart, int64_t total_chunks, const float* small_part, int32_t splits, int32_t n_small, float* grad_small,
-                                   float* small, const nadm_adam_t* adam, void* stream) {
-    if (!vimg) return fail("nadm_encode_fwd_img: vimg is NULL (use nadm_encode_fwd)");
-    SmallSide ss{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0.f, 0.f, 0.f};
-    if (small_part) {
-        if (!grad_small || splits <= 0 || n_small <= 0) return fail("nadm_encode_fwd_img: the small-parameter side work needs grad_small, splits, n_small");
-        ss = SmallSide{small_part, grad_small, small, nullptr, nullptr, splits, n_small, 0.f, 0.f, 0.f};
-        if (adam) {
-            if (!adam->m || !adam->v || !small) return fail("nadm_encode_fwd_img: Adam state / parameters are NULL");
-            if (adam->step < 1) return fail("nadm_encode_fwd_img: Adam step is 1-based");
-            ss.m = adam->m; ss.v = adam->v; ss.grad_scale = adam->grad_scale;
-            adam_scalars(adam->lr, adam->step, &ss.step_size, &ss.inv_bc2);
-        }
-    }
-    return encode_fwd_impl(xp, ld, idx, b, M, nullptr, CP, zpart, stream, 0u, ss, total_chunks, static_cast<const uint4*>(vimg));
 }
 
 extern "C" int nadm_encode_fwd_part(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,

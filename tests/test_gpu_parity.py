@@ -802,41 +802,6 @@ def test_train_boundary_supervised_vs_reference():
         na.train(1, 100, 2e-3, K + 1, 1, data, dev, 1, Hd, True, d["Vt"], pops, None, None, 8)
 
 
-@pytest.mark.parametrize("b,M,C_", [(37, 2301, 8), (800, 70_001, 8), (130, 4096, 4), (16, 255, 3), (257, 20_480, 8), (800, 500_000, 8)])
-def test_pass1_on_the_image_of_v_against_float64(b, M, C_):
-    """r05: pass 1 on the FP4 x FP6 matrix instruction -- V as an operand image (nadm_v_image: FP6 pieces + block scales per 32 SNPs x
-    column), the 2-bit codes as FP4 numbers -- against a float64 product, next to the bf16 kernel (nadm_encode_fwd).  V's rows span six
-    decades so that the block scales matter; missing calls, a ragged last byte, a partly filled last 256-SNP slice, batch splits."""
-    import ctypes as C
-    import neural_admixture_amd as na
-    from neural_admixture_amd._lib import lib, check, ptr
-    dev = _dev()
-    rng = np.random.default_rng(b + M)
-    e = na.Engine(M, C_, 64, [3], dev, b)
-    L = e.lay
-    Gm = rng.integers(0, 4, size=(b, M), dtype=np.uint8)
-    V = (rng.standard_normal((M, C_)) * 10.0 ** rng.uniform(-3, 3, size=(M, 1))).astype(np.float32)
-    V[rng.integers(0, M, size=max(1, M // 50))] = 0.0                          # all-zero rows (dead blocks when 32 of them meet)
-    e.load_params(V, np.full((3, M), 0.5, np.float32), na.model.init_encoder_weights(1, C_, 64, [3]))
-    e.pack_from_host(torch.from_numpy(Gm))
-    idx = torch.randperm(b, device=dev).to(torch.int32)
-    X = torch.from_numpy(np.where(Gm == 3, 0.0, Gm / 2.0)).to(dev)[idx.long()]
-    Z64 = X @ torch.from_numpy(V.astype(np.float64)).to(dev)
-    e.encode_partial(idx, b)                                                      # the bf16 kernel
-    Zb = e.zpart[: L.enc_chunks * b * L.CP].view(L.enc_chunks, b, L.CP).double().sum(0)[:, :C_]
-    vimg = torch.empty(int(lib.nadm_v_image_bytes(M)), dtype=torch.uint8, device=dev)
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    check(lib.nadm_v_image(ptr(e.big[: M * L.CP]), M, L.CP, ptr(vimg), st), "v_image")
-    e.zpart.fill_(float("nan"))
-    check(lib.nadm_encode_fwd_img(ptr(e.xp), e.ld, ptr(idx), b, M, ptr(vimg), L.CP, ptr(e.zpart), 0, None, 0, 0, None, None, None, st), "encode_fwd_img")
-    Zi = e.zpart[: L.enc_chunks * b * L.CP].view(L.enc_chunks, b, L.CP).double().sum(0)
-    assert torch.isfinite(Zi).all() and float(Zi[:, C_:].abs().max() if C_ < L.CP else 0.0) == 0.0
-    Zi = Zi[:, :C_]
-    scale = float(Z64.abs().max())
-    err_i, err_b = float((Zi - Z64).abs().max()) / scale, float((Zb - Z64).abs().max()) / scale
-    assert err_i < 2e-6 and err_i < 4 * err_b + 1e-7, (err_i, err_b)
-
-
 def test_pca_projection_on_gpu_counts_missing_as_one_and_a_half():
     """train.pca_project_gpu (nadm_pca_project) = (G/2) @ V.T on the raw codes, missing (3) -> 1.5, as the reference's
     init-time projection (train.py:49-55); from a uint8 matrix and from PackedGenotypes, several row chunks."""
