@@ -292,7 +292,7 @@ struct Fit {
     }
 };
 
-void run_restart(const double* X, int64_t N, int d, int K, const int32_t* picks, double tol, int max_iter, double reg, int workers, Restart* out) {
+void run_restart(const double* X, int64_t N, int d, int K, const int32_t* picks, double tol, int max_iter, double reg, int workers, Restart* out) try {
     Fit f(X, N, d, K, workers);
     for (int k = 0; k < K; ++k) f.resp[(size_t)picks[k] * K + k] = 1.0;
     double bound = -std::numeric_limits<double>::infinity();
@@ -304,6 +304,8 @@ void run_restart(const double* X, int64_t N, int d, int K, const int32_t* picks,
         if (std::fabs(bound - prev) < tol) { ++it; break; }
     }
     out->bound = bound; out->iters = it; out->means = f.m.mu;
+} catch (...) {                                                 // (no memory, no thread: reported by the caller, never thrown through the C ABI)
+    out->status = 2;
 }
 
 }  // namespace
@@ -316,6 +318,7 @@ extern "C" int nadm_gmm_fit_means(const double* X, int64_t N, int32_t d, int32_t
         if (picks[j] < 0 || picks[j] >= N) return fail("nadm_gmm_fit_means: a seed index lies outside the samples");
     std::vector<Restart> res(n_init);
     std::vector<std::thread> th;
+    try {
     // worker threads per restart: the restarts run side by side, and the barriers spin -- never more threads than the host has
     // (at most 8 each: the parts are ~2048 samples, a sweep is tens of microseconds per part, and a GPU host is shared -- 5 x 8 threads
     // is the measured sweet spot on a 256-thread host: 51 each spent their time spinning on each other's hyperthreads)
@@ -325,9 +328,14 @@ extern "C" int nadm_gmm_fit_means(const double* X, int64_t N, int32_t d, int32_t
     if (workers > 8) workers = 8;
     for (int r = 1; r < n_init; ++r) th.emplace_back(run_restart, X, N, (int)d, (int)K, picks + (int64_t)r * K, tol, (int)max_iter, reg_covar, workers, &res[r]);
     run_restart(X, N, d, K, picks, tol, max_iter, reg_covar, workers, &res[0]);
+    } catch (...) {                                             // a restart's thread could not be started: the others are joined, the fit fails
+        for (auto& t : th) t.join();
+        return fail("nadm_gmm_fit_means: out of memory or threads");
+    }
     for (auto& t : th) t.join();
     double top = -std::numeric_limits<double>::infinity();
     for (int r = 0; r < n_init; ++r) {
+        if (res[r].status == 2) return fail("nadm_gmm_fit_means: out of memory or threads");
         if (res[r].status)        // (the library raises from inside the restart that hits it; here every restart has run, the outcome is the same)
             return fail("Fitting the mixture model failed because some components have ill-defined empirical covariance (for instance caused by "
                         "singleton or collapsed samples). Try to decrease the number of components, increase reg_covar, or scale the input data.");

@@ -227,7 +227,14 @@ def RSVD(A_uint8, N: int, M: int, k: int = 8, seed: int = 42, oversampling: int 
             mark("qr_small")
             Bt = src.qt_times(Q, keep_on_device=True)                      # B^T [M,k']
             mark("products")
-            R2 = np.linalg.cholesky(gram64(Bt).cpu().numpy()).T            # upper triangular, B^T = Q2 R2
+            try:
+                R2 = np.linalg.cholesky(gram64(Bt).cpu().numpy()).T        # upper triangular, B^T = Q2 R2
+            except np.linalg.LinAlgError:
+                # B without full row rank (fewer samples than k', constant data): no Cholesky factor -- the reference's own last two lines
+                # on the host (src/svd.py:79-82; 96 MB at M = 600k, rare)
+                Ut, St, Vt_h = np.linalg.svd(Bt.cpu().numpy().astype(np.float64).T, full_matrices=False)
+                log.info(f"    Total time SVD: {time.time() - t0:.4f}s")
+                return np.ascontiguousarray(svd_flip(Vt_h, Ut)[:k].astype(np.float32))
             Ut, St, Wt = np.linalg.svd(R2.T, full_matrices=False)
             signs = np.sign(Ut[np.argmax(np.abs(Ut), axis=0), np.arange(Ut.shape[1])])     # svd_flip on U (svd.py:16-37)
             T = (signs[:, None] * np.linalg.solve(R2, Wt.T).T)[:k]          # rows of W^T R2^-T, sign-flipped: Vt = T B

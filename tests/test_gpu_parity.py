@@ -802,6 +802,19 @@ def test_train_boundary_supervised_vs_reference():
         na.train(1, 100, 2e-3, K + 1, 1, data, dev, 1, Hd, True, d["Vt"], pops, None, None, 8)
 
 
+def test_rsvd_on_the_gpu_with_fewer_samples_than_sketch_columns():
+    """svd.RSVD's GPU path takes the SVD of the wide factor from the Cholesky factor of its Gram matrix; with N < k' = 20 samples that
+    matrix is singular and the path falls back to the reference's own host SVD -- same subspace as the all-host path."""
+    from neural_admixture_amd.svd import RSVD
+    dev = _dev()
+    Gm = O.synth_genotypes(12, 3000, 3, seed=8, missing=0.01)
+    Vg = RSVD(Gm, 12, 3000, 8, 5, device=dev)
+    Vh = RSVD(Gm, 12, 3000, 8, 5, device=None)
+    assert Vg.shape == Vh.shape == (8, 3000) and np.isfinite(Vg).all()
+    for r in range(4):                                     # the leading directions (the trailing ones of a rank-12 matrix are noise)
+        assert abs(float(np.dot(Vg[r], Vh[r]))) / (np.linalg.norm(Vg[r]) * np.linalg.norm(Vh[r])) > 0.999
+
+
 def test_pca_projection_on_gpu_counts_missing_as_one_and_a_half():
     """train.pca_project_gpu (nadm_pca_project) = (G/2) @ V.T on the raw codes, missing (3) -> 1.5, as the reference's
     init-time projection (train.py:49-55); from a uint8 matrix and from PackedGenotypes, several row chunks."""
