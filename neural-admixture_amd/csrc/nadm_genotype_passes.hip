@@ -786,9 +786,12 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
     static_assert(KP <= 16, "one or two 8-wide k slots");
     // W (KP 9..16): k spans two 8-wide MFMA slots.  The pieces can no longer share an MFMA's 16 rows / columns, so
     //   R^T  = [Ph Ph' Ph Ph'].[Qh Qh' Qm Qm'] + [Pm Pm' Pm Pm'].[Qh Qh' Qm Qm'] + [Ph Ph' Pl Pl'].[Ql Ql' Qh Qh']   (X' = k 8..15)
-    //   dQ^T = (Ph + Pm).(dRh + dRl)      rows = the 16 k, four MFMAs into one accumulator, no fold
-    //   dP   = (dRh + dRl).(Qh + Qm)      columns = the 16 k, four MFMAs, no fold
-    // = 7 MFMAs per 16 x 16 tile instead of 4; everything else is shared with the K <= 8 path.
+    //   dQ^T = Ph.(dRh + dRl) + Pm.dRh    rows = the 16 k, three MFMAs (per two tiles) into one accumulator, no fold
+    //   dP   = (dRh + dRl).Qh + dRh.Qm    columns = the 16 k, three MFMAs, no fold
+    // = 6 MFMAs per 16 x 16 tile instead of 4; everything else is shared with the K <= 8 path.  (r05: the mid x lo products -- 2^-16 of
+    // the product, at the level of dR's own 16-17 bits -- cost a seventh MFMA here, where the pieces cannot share an instruction's rows;
+    // against float64 at b = 800, M = 500k, K = 16 the gradients err by 7.6e-7 of their maximum with them and 8.8e-7 without, for
+    // 3 % of the kernel: profiles/r05_ablations.txt item 7.  K <= 8 carries them for free.)
     constexpr bool W = KP > 8;
     constexpr int KW = W ? 16 : 8;                       // k columns of the operand images
     static_assert(BF_NTW == 4 || BF_NTW == 2, "tile bits are read as one 32- or 16-bit word");
@@ -1100,7 +1103,9 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                         dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q1[tp]), bl, dq[s2], 0, 0, 0);
                         if constexpr (W) {
                             dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q2[tp]), bh, dq[s2], 0, 0, 0);
+#ifdef NADM_W_KEEP_MIDLO       // A/B builds only (profiles/r05_ablations.txt item 7): the P_mid x dR_lo term, 2^-16 of the product
                             dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q2[tp]), bl, dq[s2], 0, 0, 0);
+#endif
                         }
                     }
                     // dP: per SNP tile, read dR (hi, lo) of the 32 samples back transposed, then 2 (W: 4) MFMAs
@@ -1123,7 +1128,9 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                         dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(qd1), dpacc[t], 0, 0, 0);
                         if constexpr (W) {
                             dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd2), dpacc[t], 0, 0, 0);
+#ifdef NADM_W_KEEP_MIDLO
                             dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(qd2), dpacc[t], 0, 0, 0);
+#endif
                         }
                     }
                 }
