@@ -261,6 +261,19 @@ def main():
             os.close(saved_fd)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
+    hang_guard = None
+    if use_dist:
+        # several ranks: a collective that never completes (a peer gone, a link down) would keep this process until the driver's own limit;
+        # say so and leave after 15 minutes instead (cancelled once the line is printed)
+        import threading
+
+        def _give_up():
+            sys.stderr.write(f"[bench] rank {rank}: no result after 900 s -- a collective or a peer is stuck; aborting\n")
+            sys.stderr.flush()
+            os._exit(3)
+        hang_guard = threading.Timer(900.0, _give_up)
+        hang_guard.daemon = True
+        hang_guard.start()
     import neural_admixture_amd as na
     from neural_admixture_amd.model import init_encoder_weights
 
@@ -522,6 +535,8 @@ def main():
             out["cpu_baseline_reference_shaped"] = cpu_baseline_reference_shaped(eng, args, dev)
         print(json.dumps(out))
         sys.stdout.flush()
+    if hang_guard is not None:
+        hang_guard.cancel()
     comm_a2 = eng.comm_a
     if comm is not None:                                                # every rank gets here: the communicator goes down together
         del eng
