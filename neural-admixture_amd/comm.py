@@ -171,11 +171,19 @@ class _TorchTransport:
                 return t.view(-1)[off // 4: off // 4 + n]
         raise RuntimeError("collective on a buffer that was not registered with the transport")
 
+    @staticmethod
+    def torch_stream(stream: Optional[int], dev: torch.device) -> "torch.cuda.Stream":
+        """The torch stream object for a raw HIP stream handle.  Handle 0 is the device's default stream and must be named as such:
+        ``ExternalStream(0)`` does NOT wrap the null stream -- torch reads a zero pointer as "no pointer given" and hands out a fresh
+        pool stream, on which a collective is ordered against nothing the step launched (r05: the reduce-scatter of message B read
+        gradients pass 3 had not finished and the optimizer ran before the sums were back, at 4+ ranks sharing one GPU)."""
+        return torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)
+
     def _on(self, stream: Optional[int], fn) -> int:
         try:
             dev = self.buffers[0].device
             if dev.type == "cuda":
-                with torch.cuda.stream(torch.cuda.ExternalStream(stream or 0, device=dev)):
+                with torch.cuda.stream(self.torch_stream(stream, dev)):
                     fn()
             else:
                 fn()

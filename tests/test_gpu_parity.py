@@ -1143,7 +1143,22 @@ def _wN_gpu_worker(rank, world, port, out_path, buckets, second_comm, N, M, K, H
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,buckets,second_comm", [(8, 1, False), (4, 3, True)])
+def test_torch_transport_names_the_null_stream_as_the_default_stream():
+    """A zero stream handle (the step was called on the default stream: what Engine.train_step passes unless the caller set another
+    current stream) must map to torch's default stream.  ExternalStream(0) is a POOL stream -- torch takes the zero for "no pointer" --
+    and a collective issued there is ordered against nothing the step launched: 4 and 8 ranks sharing a GPU applied stale or
+    half-summed gradients to message B that way (2 ranks passed by timing)."""
+    from neural_admixture_amd.comm import _TorchTransport
+    dev = torch.device("cuda", 0)
+    s0 = _TorchTransport.torch_stream(0, dev)
+    assert s0.cuda_stream == 0 and s0 == torch.cuda.default_stream(dev)
+    assert _TorchTransport.torch_stream(None, dev).cuda_stream == 0
+    side = torch.cuda.Stream(dev)
+    assert _TorchTransport.torch_stream(side.cuda_stream, dev).cuda_stream == side.cuda_stream
+    print("ExternalStream(0).cuda_stream =", torch.cuda.ExternalStream(0, device=dev).cuda_stream)
+
+
+@pytest.mark.parametrize("world,buckets,second_comm", [(8, 1, False), (4, 3, True), (4, 1, False)])
 def test_worldN_real_engine_on_one_gpu_at_the_reference_batch_semantics(tmp_path, world, buckets, second_comm):
     """configs[3]'s 8-GPU FORM with the real HIP engine: --batch_size 800 over W ranks = 800 // W rows per rank and step (100 at W = 8,
     neural_admixture.py:287), N = 1003 not a multiple of W (the DistributedSampler wraps), a ragged second step, every message cut into W
