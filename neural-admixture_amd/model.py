@@ -18,7 +18,6 @@ import numpy as np
 import torch
 
 from .engine import Engine
-from .layout import ModelLayout
 
 logging.basicConfig(stream=sys.stdout, level=logging.INFO, format="%(message)s")
 log = logging.getLogger(__name__)
@@ -339,7 +338,6 @@ class NeuralAdmixture:
         (src/loaders.py:25-27), in rank order -- so the trajectory is the sample-sharded one up to summation order."""
         import torch.distributed as dist
         from torch.utils.data.distributed import DistributedSampler
-        from .snp_parallel import SnpShardedEngine
         dev = self.device
         infer_b = min(N, 1024)
         b_local = self.batch_size                                  # batch_size // num_gpus (:287)

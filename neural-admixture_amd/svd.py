@@ -13,7 +13,6 @@ same algorithm runs through torch/numpy on the host (unpacked chunks)."""
 from __future__ import annotations
 
 import logging
-import sys
 import time
 
 import numpy as np
