@@ -436,10 +436,11 @@ int32_t nadm_plan_poisoned(const nadm_plan_t* plan);
 void nadm_test_force_generic_mlp(int32_t on);
 
 /* ---- 8(f)-3: log-likelihood report from the packed matrix (src/utils_c/utils.pyx:15-40, called train.py:134-146) -----
- * partial[b] (b < nadm_loglik_blocks(M), double, device) = sum over the block's 1024 SNPs and all `rows` rows of
- * g*log(rec) + (2-g)*log1p(-rec) over non-missing calls, rec = clip(Q_i.P_j, eps, 1-eps), g = clip(code, eps, 2-eps), all
+ * partial[b] (b < nadm_loglik_blocks(M) = 8 row slices x ceil(M / 1024), double, device) = sum over the block's 1024 SNPs and
+ * its slice of the `rows` rows of g*log(rec) + (2-g)*log1p(-rec) over non-missing calls, rec = clip(Q_i.P_j, eps, 1-eps), g = clip(code, eps, 2-eps), all
  * in float64 like the reference.  P [M,K] float32 (unpadded, the returned Ps[i]), Q [rows, >=K] float32 with row stride
- * q_stride, both on the device; K <= 16.  The caller adds the partials (fixed order). */
+ * q_stride, both on the device; K <= 16; eps in [1e-9, 0.5) (the reference's: 1e-6).  The caller adds the partials (fixed order).
+ * (The logarithms are taken of products over 16 genotypes: the same float64 sum to ~1e-15 relative.) */
 int64_t nadm_loglik_blocks(int64_t M);
 int nadm_loglik(const uint8_t* xp, int64_t ld, int64_t rows, int64_t M, const float* P, const float* Q, int32_t K,
                 int32_t q_stride, double eps, double* partial, void* stream);

@@ -809,7 +809,10 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
 //   widened, train.py:137-139).  block = 256 threads = 256 byte columns = 1024 SNPs; thread t keeps the K
 //   frequencies of its 4 SNPs in registers (doubles), rows stream through with Q tiles broadcast from LDS.
 //   Per-thread double accumulators, fixed-order block reduction, one partial per block (summed by the caller).
+//   blockIdx.y = one of LOGLIK_ROW_SLICES slices of the rows (whole Q tiles): M / 1024 blocks alone are two blocks per CU at
+//   500k SNPs, two waves per SIMD for a loop whose every genotype waits for two software float64 logarithms (r05).
 // =================================================================================================
+constexpr int LOGLIK_ROW_SLICES = 8;
 template <int KP>
 __global__ __launch_bounds__(256) void loglik_kernel(const uint8_t* __restrict__ xp, int64_t ld, int64_t rows, int64_t M,
                                                      const float* __restrict__ P, const float* __restrict__ Q, int K, int qstride,
@@ -827,10 +830,19 @@ __global__ __launch_bounds__(256) void loglik_kernel(const uint8_t* __restrict__
 #pragma unroll
         for (int k = 0; k < KP; ++k) p[j][k] = (m < M && k < K) ? (double)P[m * K + k] : 0.0;
     }
-    const double gval[3] = {eps, 1.0, 2.0 - eps};
-    double acc = 0.0;
-    for (int64_t r0 = 0; r0 < rows; r0 += RT) {
-        const int nr = (int)(rows - r0 < RT ? rows - r0 : RT);
+    // The sum of logarithms as the logarithm of products (r05).  With c the code and s = 1 - rec, the term of a genotype is
+    //   c = 0: eps*log r + (2 - eps)*log s      c = 1: log r + log s      c = 2: (2 - eps)*log r + eps*log s
+    //   = log f + eps * (log bn - log bd),   f = s*s | r*s | r*r,   bn / bd = r / s | 1 | s / r.
+    // f, bn and bd are multiplied up over 4 rows x 4 SNPs (every factor lies in [eps, 1], eps = 1e-6: the products stay above 1e-192)
+    // and ONE triple of float64 logarithms is taken per 16 genotypes instead of 32 -- the software logarithms were nine tenths of
+    // this kernel's arithmetic.  Same float64 quantities as the Cython loop up to the rounding of the products (1e-15 relative);
+    // log s stands in for log1p(-r): s = 1 - r is exact to 1e-16 absolute and >= eps.
+    double acc = 0.0, pf = 1.0, pn = 1.0, pd = 1.0;
+    const int64_t tiles = (rows + RT - 1) / RT, tps = (tiles + gridDim.y - 1) / gridDim.y;
+    const int64_t row_lo = (int64_t)blockIdx.y * tps * RT;
+    const int64_t row_hi = row_lo + tps * RT < rows ? row_lo + tps * RT : rows;
+    for (int64_t r0 = row_lo; r0 < row_hi; r0 += RT) {
+        const int nr = (int)(row_hi - r0 < RT ? row_hi - r0 : RT);
         __syncthreads();
         for (int e = tid; e < nr * KP; e += 256) {
             const int r = e / KP, k = e % KP;
@@ -852,9 +864,15 @@ __global__ __launch_bounds__(256) void loglik_kernel(const uint8_t* __restrict__
                     const uint32_t c = (byte >> (2 * j)) & 3u;
                     if (c != 3u && col * 4 + j < M) {
                         const double rr = fmax(eps, fmin(rec[j], 1.0 - eps));
-                        const double g = gval[c];
-                        acc += g * log(rr) + (2.0 - g) * log1p(-rr);
+                        const double om = 1.0 - rr;
+                        pf *= (c >= 1u ? rr : om) * (c == 2u ? rr : om);
+                        pn *= c == 0u ? rr : (c == 2u ? om : 1.0);
+                        pd *= c == 0u ? om : (c == 2u ? rr : 1.0);
                     }
+                }
+                if ((r & 3) == 3 || r == nr - 1) {
+                    acc += log(pf) + eps * (log(pn) - log(pd));
+                    pf = pn = pd = 1.0;
                 }
             }
         }
@@ -862,7 +880,7 @@ __global__ __launch_bounds__(256) void loglik_kernel(const uint8_t* __restrict__
     acc = wave_sum_all_f64(acc);
     if ((tid & 63) == 0) s_red[tid >> 6] = acc;
     __syncthreads();
-    if (tid == 0) partial[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (tid == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
 // =================================================================================================
@@ -1682,7 +1700,7 @@ extern "C" int nadm_savetxt_f32(const char* path, const float* a, int64_t rows, 
     return ok ? 0 : fail("nadm_savetxt_f32: write failed");
 }
 
-extern "C" int64_t nadm_loglik_blocks(int64_t M) { return (M + 1023) / 1024; }
+extern "C" int64_t nadm_loglik_blocks(int64_t M) { return (M + 1023) / 1024 * LOGLIK_ROW_SLICES; }
 
 extern "C" int nadm_loglik(const uint8_t* xp, int64_t ld, int64_t rows, int64_t M, const float* P, const float* Q, int32_t K,
                            int32_t q_stride, double eps, double* partial, void* stream) {
@@ -1691,7 +1709,8 @@ extern "C" int nadm_loglik(const uint8_t* xp, int64_t ld, int64_t rows, int64_t 
     if (K <= 0 || K > 16) return fail("nadm_loglik: K must be in 1..16");
     if (q_stride < K) return fail("nadm_loglik: q_stride < K");
     if (rows <= 0 || M <= 0) return fail("nadm_loglik: empty matrix");
-    dim3 grid((unsigned)nadm_loglik_blocks(M)), block(256);
+    if (!(eps >= 1e-9 && eps < 0.5)) return fail("nadm_loglik: eps must be in [1e-9, 0.5) (the reference's is 1e-6; products of 32 factors >= eps must stay normal)");
+    dim3 grid((unsigned)((M + 1023) / 1024), LOGLIK_ROW_SLICES), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (K <= 4) hipLaunchKernelGGL((loglik_kernel<4>), grid, block, 0, st, xp, ld, rows, M, P, Q, K, q_stride, eps, partial);
     else if (K <= 8) hipLaunchKernelGGL((loglik_kernel<8>), grid, block, 0, st, xp, ld, rows, M, P, Q, K, q_stride, eps, partial);

@@ -91,7 +91,7 @@ def test_argument_validation_of_the_round1_additions(tmp_path):
     for kp in (24, 48):
         c = lib.nadm_decode_chunk_snps(kp)
         assert c > 0 and lib.nadm_decode_chunks(10 * c + 1, kp) == 11
-    assert lib.nadm_loglik_blocks(1) == 1 and lib.nadm_loglik_blocks(1025) == 2
+    assert lib.nadm_loglik_blocks(1) == 8 and lib.nadm_loglik_blocks(1025) == 16          # 8 row slices x 1024-SNP blocks
 
 
 def test_engine_refuses_cpu_device():

@@ -871,7 +871,7 @@ def test_loglikelihood_kernel_matches_float64_oracle():
     from neural_admixture_amd.layout import ModelLayout
     dev = _dev()
     rng = np.random.default_rng(4)
-    for N, M, K in ((70, 1500, 3), (33, 4099, 7), (20, 700, 12), (5, 3, 1)):
+    for N, M, K in ((70, 1500, 3), (33, 4099, 7), (20, 700, 12), (5, 3, 1), (1101, 300, 5)):      # last: every row slice of the grid has rows
         Gm = O.synth_genotypes(N, M, max(K, 2), seed=K, missing=0.05)
         P = rng.uniform(0, 1, size=(M, K)).astype(np.float32)
         P[rng.uniform(size=P.shape) < 0.05] = 0.0                     # clamped entries -> rec hits eps
