@@ -41,7 +41,7 @@ extern "C" {
 #define NADM_MAX_HEADS 32
 #define NADM_MAX_K 64
 #define NADM_MAX_BUCKETS 8
-#define NADM_ABI_VERSION 10  /* 10: message B of the sample-sharded step in SNP-range buckets (nadm_flat_layout takes n_buckets, nadm_flat_layout_t.bkt_*, nadm_plan_desc_t.n_buckets / p3_whole / comm_a / debug, nadm_encode_fwd_part, nadm_plan_bucket_ms), nadm_comm_t.async_error, nadm_comm_rccl_probe, nadm_comm_rccl with a watchdog (timeout_ms), a failed step poisons its plan; 9: nadm_step / nadm_plan_* / nadm_comm_* / nadm_flat_layout (the step as one call, sharded optimizer), nadm_test_force_generic_mlp; 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
+#define NADM_ABI_VERSION 11  /* 11: nadm_gmm_fit_means_dev, nadm_loglik_blocks counts 8 row slices per 1024-SNP block; 10: message B of the sample-sharded step in SNP-range buckets (nadm_flat_layout takes n_buckets, nadm_flat_layout_t.bkt_*, nadm_plan_desc_t.n_buckets / p3_whole / comm_a / debug, nadm_encode_fwd_part, nadm_plan_bucket_ms), nadm_comm_t.async_error, nadm_comm_rccl_probe, nadm_comm_rccl with a watchdog (timeout_ms), a failed step poisons its plan; 9: nadm_step / nadm_plan_* / nadm_comm_* / nadm_flat_layout (the step as one call, sharded optimizer), nadm_test_force_generic_mlp; 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
@@ -453,6 +453,13 @@ int nadm_loglik(const uint8_t* xp, int64_t ld, int64_t rows, int64_t M, const fl
  * NULL) = the winning restart's objective and iteration count.  Host code, one thread per restart, synchronous. */
 int nadm_gmm_fit_means(const double* X, int64_t N, int32_t d, int32_t K, const int32_t* picks, int32_t n_init, double tol,
                        int32_t max_iter, double reg_covar, double* means, double* lower_bound, int32_t* n_iter);
+/* The same fit with the sums over the samples on the device (csrc/nadm_gmm_dev.hip: the restarts side by side in one grid, five small
+ * launches per EM iteration, float64, fixed summation order): for inputs where the host form is a visible part of a run (0.77 s at
+ * N = 100k, here ~0.03 s).  d == 8 (the reference's --pca_components default) and K <= 16 only.  X, picks, means are HOST pointers
+ * like above (X is uploaded: 64 B per sample); synchronous; work is queued on `stream`.  Equal to the host form up to the order of
+ * the sums (means to ~1e-12). */
+int nadm_gmm_fit_means_dev(const double* X, int64_t N, int32_t d, int32_t K, const int32_t* picks, int32_t n_init, double tol,
+                           int32_t max_iter, double reg_covar, double* means, double* lower_bound, int32_t* n_iter, void* stream);
 
 /* ---- VCF genotypes (src/snp_reader.py:73-87: scikit-allel read_vcf, calldata/GT as int8 with -1 fills, summed over the two
  * alleles, negative sums -> 3).  buf = the whole decompressed file; out == NULL only counts samples and variant lines;

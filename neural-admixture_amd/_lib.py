@@ -101,6 +101,7 @@ def _load():
         "nadm_loglik": (C.c_int, [vp, i64, i64, i64, vp, vp, i32, i32, C.c_double, vp, vp]),
         "nadm_savetxt_f32": (C.c_int, [C.c_char_p, vp, i64, i64, i64]),
         "nadm_gmm_fit_means": (C.c_int, [vp, i64, i32, i32, vp, i32, C.c_double, i32, C.c_double, vp, C.POINTER(C.c_double), C.POINTER(i32)]),
+        "nadm_gmm_fit_means_dev": (C.c_int, [vp, i64, i32, i32, vp, i32, C.c_double, i32, C.c_double, vp, C.POINTER(C.c_double), C.POINTER(i32), vp]),
         "nadm_mlp_fwd": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp]),
         "nadm_decode_bce": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
         "nadm_decode_bce_gather": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp]),
@@ -151,7 +152,7 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.nadm_abi_version() != 10:
+    if lib.nadm_abi_version() != 11:
         raise RuntimeError("neural_admixture_amd: libnadm.so ABI version mismatch")
     return lib, tuple(sig)
 

@@ -53,9 +53,20 @@ def kmeanspp_picks(X: np.ndarray, k: int, rs: np.random.RandomState) -> np.ndarr
     return picks
 
 
+DEVICE_MIN_SAMPLES = 20_000      # (0.82 s on host threads against 0.033 s at N = 100k; at N = 2504 a warm call is 0.009 against 0.021 s, but the
+                                 # first call's allocation and code loading make a default run no faster: profiles/r05_gmm_timing.txt, r05_full_runs.txt)
+
+
+def device_form_applies(N: int, d: int, k: int) -> bool:
+    """The shapes csrc/nadm_gmm_dev.hip is built for (the reference's 8 PCA components, K <= 16) at sizes where it pays."""
+    return d == 8 and 1 <= k <= 16 and N >= DEVICE_MIN_SAMPLES
+
+
 def fit_means(X_pca: np.ndarray, k: int, seed: int, n_init: int = 5, tol: float = 1e-4, max_iter: int = 100,
-              reg_covar: float = 1e-6) -> np.ndarray:
-    """means_ [k, d] (float64) of the reference's GaussianMixture call on X_pca [N, d]."""
+              reg_covar: float = 1e-6, stream: int | None = None) -> np.ndarray:
+    """means_ [k, d] (float64) of the reference's GaussianMixture call on X_pca [N, d].  ``stream`` (a HIP stream handle, 0 = the
+    default stream): run the EM sums on the GPU (nadm_gmm_fit_means_dev; d = 8, k <= 16 -- see ``device_form_applies``) instead of
+    on host threads; the seeding draws are the same either way."""
     X = np.ascontiguousarray(X_pca, dtype=np.float64)
     N, d = X.shape
     if N < k:
@@ -64,11 +75,16 @@ def fit_means(X_pca: np.ndarray, k: int, seed: int, n_init: int = 5, tol: float 
     picks = np.ascontiguousarray(np.stack([kmeanspp_picks(X, k, rs) for _ in range(n_init)]), dtype=np.int32)
     means = np.empty((k, d), dtype=np.float64)
     bound, iters = C.c_double(0.0), C.c_int32(0)
-    rc = lib.nadm_gmm_fit_means(X.ctypes.data, N, d, k, picks.ctypes.data, n_init, tol, max_iter, reg_covar, means.ctypes.data,
-                                C.byref(bound), C.byref(iters))
+    if stream is not None:
+        rc = lib.nadm_gmm_fit_means_dev(X.ctypes.data, N, d, k, picks.ctypes.data, n_init, tol, max_iter, reg_covar, means.ctypes.data,
+                                        C.byref(bound), C.byref(iters), C.c_void_p(stream))
+    else:
+        rc = lib.nadm_gmm_fit_means(X.ctypes.data, N, d, k, picks.ctypes.data, n_init, tol, max_iter, reg_covar, means.ctypes.data,
+                                    C.byref(bound), C.byref(iters))
     if rc:
         msg = (lib.nadm_last_error() or b"").decode()
         if "ill-defined empirical covariance" in msg:
             raise ValueError(msg)                            # the library's own error for this input
         check(rc, "gmm_fit_means")
+    fit_means.last = {"lower_bound": bound.value, "n_iter": iters.value, "device": stream is not None}
     return means

@@ -52,8 +52,9 @@ def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_comp
     ``data_np``: uint8 [N,M] array or an io.PackedGenotypes.  With a GPU ``device`` and n_components <= 8 the
     projection runs on the GPU (pca_project_gpu); otherwise on the host, 1024 rows at a time like the reference.
     The mixture fit (``fit``): "sklearn" = the reference's scikit-learn call, "em" = its float64 restatement in device ops
-    (_gmm_em.py), "native" = "auto" = the same on the host (gmm.py + csrc/nadm_gmm.cpp) -- all three give the library's means to
-    1e-10."""
+    (_gmm_em.py), "native" = the same on host threads (gmm.py + csrc/nadm_gmm.cpp), "device" = the same with the sums over the samples
+    in HIP kernels (csrc/nadm_gmm_dev.hip: 8 components, K <= 16), "auto" = "device" where it applies and pays (a GPU run with
+    N >= 20000), else "native" -- all give the library's means to 1e-10 (the device form to 1e-9)."""
     N = data_np.shape[0]
     if device is not None and device.type == "cuda" and n_components <= 8:
         X_pca = pca_project_gpu(data_np, V_CM, device)
@@ -65,6 +66,7 @@ def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_comp
     X_pca = X_pca.astype("float64")
     ks = [K] if K is not None else list(range(min_k, max_k + 1))
     how = fit
+    from . import gmm as _gmm
     # "auto" / "native": the library's algorithm restated on the host (gmm.py + csrc/nadm_gmm.cpp: same seeding draws, same EM, means equal
     # to 1e-10 -- tests/test_abi_and_host.py): ~0.05 s at N = 2504 where the library takes 0.55 s + a 1.0 s import, ~0.2 s at N = 100k
     # (restarts and sample ranges on threads) where it takes 22-45 s; several K run concurrently.  "em": the same in float64 device ops
@@ -72,6 +74,10 @@ def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_comp
     if how == "em":
         from ._gmm_em import fit_means as fit_means_device
         means = [fit_means_device(X_pca, k, seed, device) for k in ks]
+    elif how == "device" or (how == "auto" and device is not None and device.type == "cuda"
+                             and all(_gmm.device_form_applies(N, n_components, k) for k in ks)):
+        with torch.cuda.device(device):                            # (a few launches per iteration: the K of a multi-head run one after the other)
+            means = [_gmm.fit_means(X_pca, k, seed, stream=torch.cuda.current_stream().cuda_stream) for k in ks]
     elif how in ("auto", "native"):
         from .gmm import fit_means as fit_means_host
         if len(ks) > 1:

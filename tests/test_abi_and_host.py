@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in nadm.h but not exported"
     assert declared == set(_lib.EXPORTS)               # the Python binding covers the whole header
-    assert _lib.lib.nadm_abi_version() == 10
+    assert _lib.lib.nadm_abi_version() == 11
 
 
 def test_argument_validation_without_gpu():

@@ -1338,7 +1338,46 @@ def test_mixture_means_on_the_gpu_equal_the_library_fit():
         res[how] = gmm_p_init(Gm, V, None, 2, 4, 8, 42, dev, fit=how)
     a, b = res["em"], res["sklearn"]
     assert a.shape == b.shape == (9, 4000) and np.abs(a - b).max() < 1e-6
-    assert np.array_equal(res["auto"], res["native"]) and np.abs(res["native"] - b).max() < 1e-6      # the default: the host restatement (r05)
+    assert np.array_equal(res["auto"], res["native"]) and np.abs(res["native"] - b).max() < 1e-6      # N = 300: "auto" is the host restatement (r05)
+
+
+def test_mixture_fit_with_the_sums_on_the_device_equals_the_host_form_and_the_library():
+    """csrc/nadm_gmm_dev.hip (the EM of the reference's GaussianMixture call, model/train.py:61-66, with its sums over the samples in
+    HIP kernels) against csrc/nadm_gmm.cpp (host threads) on the same seeding draws: same winner, same iteration count, means to 1e-9;
+    against scikit-learn itself on a small case; the library's error for a collapsed input; what "auto" picks."""
+    from neural_admixture_amd import gmm
+    from neural_admixture_amd._gmm_fit import fit_means as sk
+    from neural_admixture_amd.train import gmm_p_init
+    _dev()
+    rng = np.random.default_rng(11)
+    st = torch.cuda.current_stream().cuda_stream
+    for N, k, seed, spread in ((30_000, 8, 42, 0.05), (21_001, 5, 3, 0.25), (2504, 7, 42, 0.25), (700, 16, 1, 0.3), (64, 1, 5, 0.3)):
+        cent = rng.standard_normal((k, 8))
+        X = (rng.dirichlet(np.full(k, 0.3), N) @ cent + spread * rng.standard_normal((N, 8))).astype(np.float32).astype(np.float64)
+        host = gmm.fit_means(X, k, seed)
+        h = dict(gmm.fit_means.last)
+        dev_m = gmm.fit_means(X, k, seed, stream=st)
+        d = dict(gmm.fit_means.last)
+        assert d["device"] and not h["device"]
+        assert d["n_iter"] == h["n_iter"] and abs(d["lower_bound"] - h["lower_bound"]) < 1e-10
+        assert np.abs(dev_m - host).max() < 1e-9, (N, k)
+        if N <= 2504:
+            assert np.abs(dev_m - sk(X, k, seed)).max() < 1e-9
+        again = gmm.fit_means(X, k, seed, stream=st)
+        assert np.array_equal(again, dev_m)                                            # fixed summation order: the same bits every time
+    Xc = np.zeros((500, 8))                                                            # every sample the same point: no covariance is positive definite
+    Xc[:, 0] = 1.0
+    with pytest.raises(ValueError, match="ill-defined empirical covariance"):
+        gmm.fit_means(Xc, 3, 0, reg_covar=0.0, stream=st)
+    with pytest.raises(RuntimeError, match="d must be 8"):
+        gmm.fit_means(np.zeros((50, 4)), 2, 0, stream=st)
+    assert gmm.device_form_applies(100_000, 8, 8) and not gmm.device_form_applies(2504, 8, 7)
+    assert not gmm.device_form_applies(100_000, 8, 17) and not gmm.device_form_applies(100_000, 6, 8)
+    Gm = O.synth_genotypes(300, 4000, 3, seed=2)
+    V = np.linalg.svd(Gm.astype(np.float32), full_matrices=False)[2][:8].astype(np.float32)
+    a = gmm_p_init(Gm, V, 3, None, None, 8, 42, torch.device("cuda:0"), fit="device")
+    b = gmm_p_init(Gm, V, 3, None, None, 8, 42, torch.device("cuda:0"), fit="native")
+    assert a.shape == b.shape and np.abs(a - b).max() < 1e-7
 
 
 @pytest.mark.parametrize("K", [5, 13, 20])
