@@ -288,6 +288,9 @@ def main():
         b = args.batch
     snp = args.parallelism == "snp"
     ddp = not snp and (world > 1 or args.force_ddp)
+    if os.environ.get("NADM_FORCE_SLICES"):               # A/B of pass 2's sample slices (tools): 1 = never, n = n slices, unset / 0 = the library's choice
+        from neural_admixture_amd._lib import lib as _nlib
+        _nlib.nadm_test_force_slices(int(os.environ["NADM_FORCE_SLICES"]))
     from neural_admixture_amd import comm as nacomm
     comm = None
     if args.emulate_world is not None:

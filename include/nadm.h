@@ -41,7 +41,8 @@ extern "C" {
 #define NADM_MAX_HEADS 32
 #define NADM_MAX_K 64
 #define NADM_MAX_BUCKETS 8
-#define NADM_ABI_VERSION 11  /* 11: nadm_gmm_fit_means_dev, nadm_loglik_blocks counts 8 row slices per 1024-SNP block; 10: message B of the sample-sharded step in SNP-range buckets (nadm_flat_layout takes n_buckets, nadm_flat_layout_t.bkt_*, nadm_plan_desc_t.n_buckets / p3_whole / comm_a / debug, nadm_encode_fwd_part, nadm_plan_bucket_ms), nadm_comm_t.async_error, nadm_comm_rccl_probe, nadm_comm_rccl with a watchdog (timeout_ms), a failed step poisons its plan; 9: nadm_step / nadm_plan_* / nadm_comm_* / nadm_flat_layout (the step as one call, sharded optimizer), nadm_test_force_generic_mlp; 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
+#define NADM_MAX_P2_SLICES 8   /* sample slices of pass 2 (nadm_decode_bce_sliced) */
+#define NADM_ABI_VERSION 11  /* 11: nadm_gmm_fit_means_dev, nadm_loglik_blocks counts 8 row slices per 1024-SNP block, nadm_decode_bce_sliced / nadm_decode_slices / nadm_decode_slab_floats / nadm_test_force_slices + nadm_plan_desc_t.p2_slab / p2_cnt (pass 2 in sample slices when the SNP chunks alone do not fill the chip); 10: message B of the sample-sharded step in SNP-range buckets (nadm_flat_layout takes n_buckets, nadm_flat_layout_t.bkt_*, nadm_plan_desc_t.n_buckets / p3_whole / comm_a / debug, nadm_encode_fwd_part, nadm_plan_bucket_ms), nadm_comm_t.async_error, nadm_comm_rccl_probe, nadm_comm_rccl with a watchdog (timeout_ms), a failed step poisons its plan; 9: nadm_step / nadm_plan_* / nadm_comm_* / nadm_flat_layout (the step as one call, sharded optimizer), nadm_test_force_generic_mlp; 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
@@ -191,6 +192,26 @@ int nadm_decode_bce_images(const uint8_t* xp, int64_t ld, const int32_t* idx, in
                            float* P, int32_t kp, const float* Q, int32_t SP,
                            float* dP, float* dqpart, float* losspart, int32_t with_loss,
                            uint8_t* xg, const nadm_adam_t* adam, const void* qimg, void* stream);
+/* The same kernel (qimg may be NULL) with the batch's 64-sample tiles dealt to n_slices blocks per SNP chunk: below ~330k SNPs the chunks
+ * alone are fewer blocks than the chip holds (977 chunks at M = 500k fill it; 98 at M = 50k leave 60 % of the CUs idle and pass 2 runs
+ * at a third of its rate).  dQ rows, the batch copy and everything else per sample are written by the slice that owns the sample; every
+ * slice parks its partial of dP (and of the loss value) in `slab`, and the block that is counted last in `counters` adds the
+ * partials in slice order and runs the epilogue -- no block waits for another, the result is reproducible bit for bit, and it differs
+ * from the n_slices = 1 result by the rounding of that sum only.  n_slices: take nadm_decode_slices(b, M, kp) (1 for kp > 16 and
+ * wherever the chunks suffice) -- the plan (nadm_step) and every caller that wants its bits use that function; slab: at least
+ * nadm_decode_slab_floats(M, kp, n_slices) floats, 16-byte aligned; counters: one int32 per chunk (nadm_decode_chunks), ZERO-FILLED
+ * ONCE by the caller (a launch returns them to zero).  Concurrent launches (heads on two streams) need regions of their own. */
+int32_t nadm_decode_slices(int32_t b, int64_t M, int32_t kp);
+int32_t nadm_decode_slices_max(int32_t bmax, int64_t M, int32_t kp);   /* the largest value over batches of 1..bmax rows: what sizes a slab */
+int64_t nadm_decode_slab_floats(int64_t M, int32_t kp, int32_t n_slices);
+int nadm_decode_bce_sliced(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                           float* P, int32_t kp, const float* Q, int32_t SP,
+                           float* dP, float* dqpart, float* losspart, int32_t with_loss,
+                           uint8_t* xg, const nadm_adam_t* adam, const void* qimg,
+                           int32_t n_slices, float* slab, int32_t* counters, void* stream);
+/* tests and experiments: n > 0 makes nadm_decode_slices return n (capped by the number of tiles) for every kp <= 16 shape, 0 = the
+ * library's choice.  Process-wide; set it before the buffers of a plan are sized. */
+void nadm_test_force_slices(int32_t n);
 /* `weights` (may be NULL): the MLP weight-gradient partials -- the first half of nadm_mlp_bwd_weights, which like pass 3
  * depends only on the outputs of nadm_mlp_bwd(grad_small = NULL) -- are computed by extra blocks of the same launch (they
  * fill the under-occupied last round of pass 3) into small_part [nadm_sample_splits(b), n_small]; nadm_small_grads then
@@ -384,6 +405,10 @@ typedef struct nadm_plan_desc {
                                            * all start behind it; only the next pass 1 is pipelined against them)                */
     int32_t debug;                        /* != 0: every step asks the communicators for asynchronous errors (a host call each)  */
     int32_t reserved;                     /* 0 */
+    float* p2_slab;                       /* pass 2 in sample slices (nadm_decode_bce_sliced): head h's region starts at the sum over the
+                                           * heads before it of nadm_decode_slab_floats(M, kp, nadm_decode_slices_max(bmax, M, kp)); NULL (with
+                                           * p2_cnt): pass 2 is never sliced                                                        */
+    int32_t* p2_cnt;                      /* the heads' counters back to back, nadm_decode_chunks(M, kp) each, zero-filled once    */
 } nadm_plan_desc_t;
 typedef struct nadm_plan nadm_plan_t;
 int  nadm_plan_create(const nadm_plan_desc_t* desc, nadm_plan_t** out);

@@ -58,7 +58,7 @@ class PlanDesc(C.Structure):
                                              "dqpart", "losspart", "small_part", "zsum", "dqsum", "qimg")]
                 + [("qimg_head_bytes", C.c_int64), ("dzimg", C.c_void_p), ("dzcnt", C.c_void_p), ("xg", C.c_void_p), ("loss_acc", C.c_void_p),
                    ("comm", C.POINTER(CommStruct)), ("comm_a", C.POINTER(CommStruct)), ("n_buckets", C.c_int32), ("p3_whole", C.c_int32),
-                   ("debug", C.c_int32), ("reserved", C.c_int32)])
+                   ("debug", C.c_int32), ("reserved", C.c_int32), ("p2_slab", C.c_void_p), ("p2_cnt", C.c_void_p)])
 
 
 MODE_SINGLE, MODE_DP, MODE_SNP = 0, 1, 2
@@ -107,6 +107,11 @@ def _load():
         "nadm_decode_bce_gather": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp]),
         "nadm_decode_bce_step": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
         "nadm_decode_bce_images": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+        "nadm_decode_bce_sliced": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp]),
+        "nadm_decode_slices": (i32, [i32, i64, i32]),
+        "nadm_decode_slices_max": (i32, [i32, i64, i32]),
+        "nadm_decode_slab_floats": (i64, [i64, i32, i32]),
+        "nadm_test_force_slices": (None, [i32]),
         "nadm_mlp_fwd_images": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, i64, vp]),
         "nadm_q_image_bytes": (C.c_int64, [i32]),
         "nadm_encode_fwd_small": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp]),

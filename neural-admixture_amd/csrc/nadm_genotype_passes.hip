@@ -19,6 +19,7 @@ extern "C" int nadm_mlp_bwd_weight_parts(const nadm_heads_t* hd, int32_t b, cons
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <atomic>
 
 namespace nadm {
 
@@ -772,6 +773,9 @@ __device__ __forceinline__ f32x2_t fp4_pair_x2(const uint32_t w, const int sel) 
 }
 
 constexpr int BF_WAVES = NADM_BF_WAVES;
+// floats one (sample slice, SNP chunk) block of pass 2 parks for the block that adds the slices up: the chunk's [SNPs x KP] partial of dP +
+// its loss partial (+ 3 pad)
+constexpr int p2_slab_floats(int kp) { return NADM_BF_WAVES * 16 * NADM_BF_NTW * kp + 4; }
 constexpr int BF_NTW = NADM_BF_NTW;     // 16-SNP tiles per wave
 constexpr int BF_TS = NADM_BF_TS;       // samples per LDS tile
 
@@ -782,8 +786,16 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
     const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
     float* P, const float* __restrict__ Q, int SP,
     float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart, uint8_t* __restrict__ xg, AdamFused ad,
-    const uint4* __restrict__ qimg) {
+    const uint4* __restrict__ qimg, float* slab, int* slice_cnt) {
     static_assert(KP <= 16, "one or two 8-wide k slots");
+    // gridDim.y = S sample SLICES (r05): with few SNP chunks (M below ~330k: fewer blocks than the chip holds at three per CU) the batch's
+    // sample tiles are dealt to S blocks per chunk.  Everything a block writes is per sample (dQ slab rows, the batch copy) except dP and
+    // the loss value: every slice parks its partial [chunk SNPs x KP] sum (+ its loss partial) in `slab`, is counted, and the block that
+    // is counted LAST adds the S partials in slice order and runs the epilogue (Adam or the gradient store) -- the hand-off idiom of
+    // the MLP backward's dZ image (nadm_small_kernels.hip: write-through stores, vmcnt(0), device-scope counter, device-scope loads;
+    // DESIGN 4.3), no block ever waits for another.  The sum's order is fixed, so a step is reproducible bit for bit; it is NOT the
+    // S = 1 kernel's order (one accumulator over all tiles), which is why the slicing is decided inside the library from (b, M) alone
+    // (nadm_decode_slices) and every path to this kernel takes the same decision.
     // W (KP 9..16): k spans two 8-wide MFMA slots.  The pieces can no longer share an MFMA's 16 rows / columns, so
     //   R^T  = [Ph Ph' Ph Ph'].[Qh Qh' Qm Qm'] + [Pm Pm' Pm Pm'].[Qh Qh' Qm Qm'] + [Ph Ph' Pl Pl'].[Ql Ql' Qh Qh']   (X' = k 8..15)
     //   dQ^T = Ph.(dRh + dRl) + Pm.dRh    rows = the 16 k, three MFMAs (per two tiles) into one accumulator, no fold
@@ -1005,9 +1017,14 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
         }
     };
 
+    const int n_slices = (int)gridDim.y, slice = (int)blockIdx.y;
+    const int ntiles = (b + MF_TS - 1) / MF_TS;
+    const int tps = (ntiles + n_slices - 1) / n_slices;      // (the host picks S so that no slice is empty)
+    const int tl0 = slice * tps, tl1 = min(ntiles, tl0 + tps);
+    row_pref = row_index(tl0 * MF_TS);
     __syncthreads();                                        // zero fill visible before the first commit
-    issue(0);
-    commit(0);
+    issue(tl0 * MF_TS);
+    commit(tl0 * MF_TS);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 
@@ -1043,11 +1060,10 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
     };
     uint16_t* const tw = &s_t[wave][0][0][0];
     const int wchunk = SWZ ? ((a + (n >> 2)) & 3) : a;      // where this lane's 8-byte chunk of row 16*s2 + n goes
-    const int ntiles = (b + MF_TS - 1) / MF_TS;
-    for (int tl = 0; tl < ntiles; ++tl) {
+    for (int tl = tl0; tl < tl1; ++tl) {
         const int i0 = tl * MF_TS;
         const int nt = min(MF_TS, b - i0);
-        if (tl + 1 < ntiles) issue(i0 + MF_TS);
+        if (tl + 1 < tl1) issue(i0 + MF_TS);
 
 #pragma unroll 1
         for (int p = 0; p < MF_TS / 32; ++p) {
@@ -1187,7 +1203,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
             *reinterpret_cast<float4*>(dqpart + (chunk * b + i0) * KP + 4 * e4) =
                 make_float4(sm.x * scale_back, sm.y * scale_back, sm.z * scale_back, sm.w * scale_back);
         }
-        if (tl + 1 < ntiles) commit(i0 + MF_TS);
+        if (tl + 1 < tl1) commit(i0 + MF_TS);
         __syncthreads();
     }
 
@@ -1206,29 +1222,72 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
             if (n < KP) s_dp[(int)(snp_of(t, a, r) - snp_blk0) * KP + n] = v * scale_back;
         }
     }
-    __syncthreads();
-    {
-        constexpr int ROW4 = KP / 4;                                  // float4 per SNP row
-        for (int e = tid; e < MF_WAVES * 16 * NTW * ROW4; e += NTHR) {
-            const int64_t m = snp_blk0 + e / ROW4;
-            if (m < M) {
-                const float4 g4 = *reinterpret_cast<const float4*>(s_dp + 4 * e);
-                const int64_t o = m * KP + 4 * (e % ROW4);
-                // single-GPU step: the gradient of these rows is final here and nothing else in the step reads P again, so
-                // Adam + clamp is applied on the spot (no dP round trip through HBM, no separate launch for the P matrices)
-                if (ad.m != nullptr) adam_float4(P + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.inv_bc2, ad.grad_scale, true);
-                else *reinterpret_cast<float4*>(dP + o) = g4;
-            }
-        }
-    }
+    float my_loss = 0.f;
     if constexpr (LOSS) {
         const float sl = wave_sum_lane63(-0.69314718055994530942f * (lossacc.x + lossacc.y));
         if (lane == 63) s_loss[wave] = sl;
-        __syncthreads();
+    }
+    __syncthreads();
+    if constexpr (LOSS) {
+        if (tid == 0) {
+#pragma unroll
+            for (int w = 0; w < MF_WAVES; ++w) my_loss += s_loss[w];
+        }
+    }
+    constexpr int ROW4 = KP / 4;                                      // float4 per SNP row
+    constexpr int CH_F4 = MF_WAVES * 16 * NTW * ROW4;                 // float4 of a chunk's [SNPs x KP] slab
+    auto finish = [&](int e, const float4 g4) {                       // row piece e of the chunk, gradient complete
+        const int64_t m = snp_blk0 + e / ROW4;
+        if (m < M) {
+            const int64_t o = m * KP + 4 * (e % ROW4);
+            // single-GPU step: the gradient of these rows is final here and nothing else in the step reads P again, so
+            // Adam + clamp is applied on the spot (no dP round trip through HBM, no separate launch for the P matrices)
+            if (ad.m != nullptr) adam_float4(P + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.inv_bc2, ad.grad_scale, true);
+            else *reinterpret_cast<float4*>(dP + o) = g4;
+        }
+    };
+    if (n_slices == 1) {
+        for (int e = tid; e < CH_F4; e += NTHR) finish(e, *reinterpret_cast<const float4*>(s_dp + 4 * e));
+        if constexpr (LOSS) { if (tid == 0) losspart[chunk] = my_loss; }
+        return;
+    }
+    // ---- S > 1: park the partial, be counted, the last one adds them up (see the head of the kernel)
+    constexpr int SLAB_F = p2_slab_floats(KP);                        // floats per (slice, chunk): the slab + 4 (the loss partial + pad)
+    float* const mine = slab + ((int64_t)slice * gridDim.x + chunk) * SLAB_F;
+    for (int e = tid; e < CH_F4; e += NTHR) {
+        const float4 g4 = *reinterpret_cast<const float4*>(s_dp + 4 * e);
+        __hip_atomic_store(mine + 4 * e + 0, g4.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // written THROUGH to memory: the block
+        __hip_atomic_store(mine + 4 * e + 1, g4.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // that adds the partials may sit on
+        __hip_atomic_store(mine + 4 * e + 2, g4.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // another XCD, behind another L2
+        __hip_atomic_store(mine + 4 * e + 3, g4.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) __hip_atomic_store(mine + 4 * CH_F4, my_loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ int s_last;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): this wave's stores have been acknowledged ...
+    __syncthreads();
+    if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(&slice_cnt[chunk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the block is counted
+        s_last = old == n_slices - 1;
+        if (s_last) __hip_atomic_store(&slice_cnt[chunk], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;                                              // block-uniform
+    for (int e = tid; e < CH_F4; e += NTHR) {
+        float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sl = 0; sl < n_slices; ++sl) {                       // slice order, whoever is last
+            const float* part = slab + ((int64_t)sl * gridDim.x + chunk) * SLAB_F + 4 * e;
+            g4.x += __hip_atomic_load(part + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g4.y += __hip_atomic_load(part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g4.z += __hip_atomic_load(part + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g4.w += __hip_atomic_load(part + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        finish(e, g4);
+    }
+    if constexpr (LOSS) {
         if (tid == 0) {
             float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < MF_WAVES; ++w) tot += s_loss[w];
+            for (int sl = 0; sl < n_slices; ++sl)
+                tot += __hip_atomic_load(slab + ((int64_t)sl * gridDim.x + chunk) * SLAB_F + 4 * CH_F4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             losspart[chunk] = tot;
         }
     }
@@ -1522,12 +1581,12 @@ static int launch_gather_rows(const uint8_t* xp, int64_t ld, const int32_t* idx,
 template <int KP>
 static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, float* P,
                               const float* Q, int SP, float* dP, float* dqpart, float* losspart, int with_loss,
-                              hipStream_t st, uint8_t* xg, AdamFused ad, const uint4* qimg) {
+                              hipStream_t st, uint8_t* xg, AdamFused ad, const uint4* qimg, int n_slices, float* slab, int* slice_cnt) {
     static_assert(KP <= 16 && mf_chunk_snps(KP) == BF_WAVES * 16 * BF_NTW, "chunking published by nadm_decode_chunk_snps");
     const int64_t chunks = (M + mf_chunk_snps(KP) - 1) / mf_chunk_snps(KP);
-    dim3 grid((unsigned)chunks), block(64 * BF_WAVES);
+    dim3 grid((unsigned)chunks, (unsigned)n_slices), block(64 * BF_WAVES);
     constexpr bool CAN_IMG = BF_TS == QI_TS;                 // (variant builds with another tile depth: decode_bce_impl refuses qimg)
-#define NADM_P2_LAUNCH(...) hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, __VA_ARGS__>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad, qimg)
+#define NADM_P2_LAUNCH(...) hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, __VA_ARGS__>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad, qimg, slab, slice_cnt)
     if (with_loss & 2) {        // loss value with P possibly outside [0, 1] (before the first restrict_P)
         if (qimg) NADM_P2_LAUNCH(true, false, CAN_IMG); else NADM_P2_LAUNCH(true, false, false);
     } else if (with_loss) {
@@ -1713,8 +1772,16 @@ extern "C" int nadm_pca_project(const uint8_t* xp, int64_t ld, const int32_t* id
 
 static int decode_bce_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                            float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
-                           float* losspart, int32_t with_loss, void* stream, uint8_t* xg, AdamFused ad, const uint4* qimg = nullptr) {
+                           float* losspart, int32_t with_loss, void* stream, uint8_t* xg, AdamFused ad, const uint4* qimg = nullptr,
+                           int32_t n_slices = 1, float* slab = nullptr, int32_t* slice_cnt = nullptr) {
     if (!xp || !idx || !P || !Q || !dP || !dqpart) return fail("nadm_decode_bce: null pointer");
+    if (n_slices < 1 || n_slices > NADM_MAX_P2_SLICES) return fail("nadm_decode_bce_sliced: n_slices must be in 1..8");
+    if (n_slices > 1) {
+        if (kp > 16) return fail("nadm_decode_bce_sliced: sample slices exist for padded K <= 16 only");
+        if (!slab || !slice_cnt || ((uintptr_t)slab & 15)) return fail("nadm_decode_bce_sliced: n_slices > 1 needs the slab (16-byte aligned) and the counters");
+        const int tiles = (b + NADM_BF_TS - 1) / NADM_BF_TS, tps = (tiles + n_slices - 1) / n_slices;
+        if ((int64_t)(n_slices - 1) * tps >= tiles) return fail("nadm_decode_bce_sliced: a slice would be empty (take n_slices from nadm_decode_slices)");
+    }
     if (qimg && (kp > 16 || NADM_BF_TS != nadm::QI_TS)) return fail("nadm_decode_bce_images: Q images exist for padded K <= 16 only");
     if ((uintptr_t)qimg & 15) return fail("nadm_decode_bce_images: qimg must be 16-byte aligned");
     if (with_loss < 0 || with_loss > 3) return fail("nadm_decode_bce: with_loss is a bit set (1: loss value, 2: P may lie outside [0,1])");
@@ -1725,10 +1792,10 @@ static int decode_bce_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
     hipStream_t st = (hipStream_t)stream;
     if (kp <= 16) {
         switch (kp) {
-            case 4: return launch_decode_mfma<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad, qimg);
-            case 8: return launch_decode_mfma<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad, qimg);
-            case 12: return launch_decode_mfma<12>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad, qimg);
-            case 16: return launch_decode_mfma<16>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad, qimg);
+            case 4: return launch_decode_mfma<4>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad, qimg, n_slices, slab, slice_cnt);
+            case 8: return launch_decode_mfma<8>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad, qimg, n_slices, slab, slice_cnt);
+            case 12: return launch_decode_mfma<12>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad, qimg, n_slices, slab, slice_cnt);
+            case 16: return launch_decode_mfma<16>(xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, with_loss, st, xg, ad, qimg, n_slices, slab, slice_cnt);
             default: return fail("nadm_decode_bce: unsupported padded K (use nadm_pad_k)");
         }
     }
@@ -1774,6 +1841,56 @@ extern "C" int nadm_decode_bce_images(const uint8_t* xp, int64_t ld, const int32
     if (ad.m && ((uintptr_t)P & 15)) return fail("nadm_decode_bce_images: P must be 16-byte aligned");
     if (!qimg) return fail("nadm_decode_bce_images: qimg is NULL (use nadm_decode_bce_step)");
     return decode_bce_impl(xp, ld, idx, b, M, P, kp, Q, SP, dP, dqpart, losspart, with_loss, stream, xg, ad, static_cast<const uint4*>(qimg));
+}
+
+// ---- pass 2 with the batch's sample tiles dealt to n_slices blocks per SNP chunk (see decode_bce_bf16_kernel)
+static std::atomic<int> g_force_slices{0};
+extern "C" void nadm_test_force_slices(int32_t n) { g_force_slices.store(n < 0 ? 0 : (n > NADM_MAX_P2_SLICES ? NADM_MAX_P2_SLICES : n)); }
+
+extern "C" int32_t nadm_decode_slices(int32_t b, int64_t M, int32_t kp) {
+    if (kp > 16 || b <= 0 || M <= 0) return 1;
+    const int64_t chunks = (M + mf_chunk_snps(8) - 1) / mf_chunk_snps(8);
+    const int tiles = (b + NADM_BF_TS - 1) / NADM_BF_TS;
+    int s = g_force_slices.load();
+    if (s == 0) {
+        // Measured (profiles/r05_ablations.txt item 11): below ~130k SNPs pass 2 is bound by the serial chain of ONE block -- its prologue
+        // (P rows into operands, ~1.5 tile-times) + 13 tiles at b = 800 = 49 us whether 98 or 196 blocks run -- not by the chip; slices of
+        // ~4-5 tiles shorten the chain (M = 25k: 49 -> 32 us, 50k: 50 -> 43, 100k: 73.5 -> 66.5; 6400 rows x 62.5k SNPs, the SNP-sharded
+        // rank of configs[3]: 326 -> 244).  A slice costs a prologue and the launch ~5 us for the hand-off: short batches (< 8 tiles: b = 400
+        // at M = 100k 44.4 -> 45.3, b = 200 at 50k 20.9 -> 23.6) and launches of more than ~1.7 rounds of blocks do not pay; from 150k SNPs
+        // on the chunks fill the chip and nothing changes.
+        if (chunks >= 512 || tiles < 8) return 1;
+        s = (int)((2 * tiles + 4) / 9);                             // round(tiles / 4.5)
+        const int64_t lim = 1280 / chunks;                           // blocks <= 1280 = 1.7 rounds of 768
+        if (s > lim) s = (int)lim;
+        if (s > NADM_MAX_P2_SLICES) s = NADM_MAX_P2_SLICES;
+    }
+    if (s > tiles) s = tiles;
+    if (s < 2) return 1;
+    const int tps = (tiles + s - 1) / s;
+    return (tiles + tps - 1) / tps;                                   // no empty slice
+}
+
+extern "C" int32_t nadm_decode_slices_max(int32_t bmax, int64_t M, int32_t kp) {       // the most slices any batch of up to bmax rows is cut into
+    int32_t mx = 1;
+    for (int32_t b = bmax; b > 0; b -= NADM_BF_TS) { const int32_t s = nadm_decode_slices(b, M, kp); if (s > mx) mx = s; }
+    return mx;
+}
+
+extern "C" int64_t nadm_decode_slab_floats(int64_t M, int32_t kp, int32_t n_slices) {
+    if (kp > 16 || n_slices < 2 || M <= 0) return 0;
+    return (int64_t)n_slices * ((M + mf_chunk_snps(8) - 1) / mf_chunk_snps(8)) * p2_slab_floats(kp);
+}
+
+extern "C" int nadm_decode_bce_sliced(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                                      float* P, int32_t kp, const float* Q, int32_t SP, float* dP, float* dqpart,
+                                      float* losspart, int32_t with_loss, uint8_t* xg, const nadm_adam_t* adam, const void* qimg,
+                                      int32_t n_slices, float* slab, int32_t* counters, void* stream) {
+    AdamFused ad;
+    if (adam_fused_args(adam, "nadm_decode_bce_sliced: Adam state is NULL", &ad)) return 1;
+    if (ad.m && ((uintptr_t)P & 15)) return fail("nadm_decode_bce_sliced: P must be 16-byte aligned");
+    return decode_bce_impl(xp, ld, idx, b, M, P, kp, Q, SP, dP, dqpart, losspart, with_loss, stream, xg, ad, static_cast<const uint4*>(qimg),
+                           n_slices, slab, counters);
 }
 
 extern "C" int64_t nadm_batch_copy_bytes(int32_t b, int64_t M) { return ((M + 4 * nadm::XG_TILE_COLS - 1) / (4 * nadm::XG_TILE_COLS)) * (int64_t)b * nadm::XG_TILE_COLS; }

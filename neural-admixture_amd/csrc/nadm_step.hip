@@ -303,7 +303,7 @@ struct nadm_plan {
     const int32_t* labels = nullptr;
     int n_classes = 0;
     float sup_weight = 0.f;
-    int64_t enc_chunks = 0, dec_chunks[NADM_MAX_HEADS] = {0}, loss_off[NADM_MAX_HEADS] = {0}, n_loss = 0;
+    int64_t enc_chunks = 0, dec_chunks[NADM_MAX_HEADS] = {0}, loss_off[NADM_MAX_HEADS] = {0}, slab_off[NADM_MAX_HEADS] = {0}, n_loss = 0;
     uint32_t tmask = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trec[NADM_T_COUNT], trec_bkt[NADM_MAX_BUCKETS];
     std::vector<hipEvent_t> pool;
@@ -433,9 +433,13 @@ int decode_heads(nadm_plan* p, const int32_t* idx, int b, int with_loss, const f
         const nadm_adam_t* adp = nullptr;
         if (lr_scale) { ad = adam_at(p, p->lay.off_p[h], lr_scale[0], p->step_count, lr_scale[1]); adp = &ad; }
         int rc;
-        if (d.qimg && kp <= 16)
-            rc = nadm_decode_bce_images(d.xp, d.ld, idx, b, d.M, Ph, kp, Qh, hd.SP, dPh, slab, lossp, flags, xg, adp,
-                                        (const char*)d.qimg + (int64_t)h * d.qimg_head_bytes, st);
+        const void* qi = (d.qimg && kp <= 16) ? (const char*)d.qimg + (int64_t)h * d.qimg_head_bytes : nullptr;
+        const int slices = d.p2_slab ? nadm_decode_slices(b, d.M, kp) : 1;     // sample slices where the SNP chunks alone leave CUs idle
+        if (slices > 1)
+            rc = nadm_decode_bce_sliced(d.xp, d.ld, idx, b, d.M, Ph, kp, Qh, hd.SP, dPh, slab, lossp, flags, xg, adp, qi, slices,
+                                        d.p2_slab + p->slab_off[h], d.p2_cnt + p->loss_off[h], st);
+        else if (qi)
+            rc = nadm_decode_bce_images(d.xp, d.ld, idx, b, d.M, Ph, kp, Qh, hd.SP, dPh, slab, lossp, flags, xg, adp, qi, st);
         else
             rc = nadm_decode_bce_step(d.xp, d.ld, idx, b, d.M, Ph, kp, Qh, hd.SP, dPh, slab, lossp, flags, xg, adp, st);
         if (rc) return 1;
@@ -496,6 +500,8 @@ extern "C" int nadm_plan_create(const nadm_plan_desc_t* desc, nadm_plan_t** out)
         return fail("nadm_plan_create: comm_a is the second communicator of the sample-sharded mode: same rank and world as comm");
     if (d.n_buckets < 0 || d.n_buckets > NADM_MAX_BUCKETS) return fail("nadm_plan_create: at most 8 buckets");
     if (d.reserved != 0) return fail("nadm_plan_create: nadm_plan_desc_t.reserved must be 0");
+    if ((d.p2_slab == nullptr) != (d.p2_cnt == nullptr) || ((uintptr_t)d.p2_slab & 15))
+        return fail("nadm_plan_create: p2_slab (16-byte aligned) and p2_cnt come together (both NULL: pass 2 is never sliced)");
     nadm_plan* p = new nadm_plan;
     p->d = d;
     p->world = d.comm ? d.comm->world : 1;
@@ -505,10 +511,13 @@ extern "C" int nadm_plan_create(const nadm_plan_desc_t* desc, nadm_plan_t** out)
     if (nadm_flat_layout(&hd, d.M, dp ? p->world : 1, dp ? d.n_buckets : 1, &p->lay)) { delete p; return 1; }
     p->nb = p->lay.n_buckets;
     p->enc_chunks = nadm_encode_chunks(d.M);
+    int64_t slab_floats = 0;
     for (int h = 0; h < hd.n_heads; ++h) {
         p->dec_chunks[h] = nadm_decode_chunks(d.M, hd.kp[h]);
-        p->loss_off[h] = p->n_loss;
+        p->loss_off[h] = p->n_loss;                              // (= the head's offset into the slice counters as well)
         p->n_loss += p->dec_chunks[h];
+        p->slab_off[h] = slab_floats;
+        slab_floats += nadm_decode_slab_floats(d.M, hd.kp[h], nadm_decode_slices_max(d.bmax, d.M, hd.kp[h]));
     }
     bool ok = true;
     auto stream_ok = [&](hipStream_t* s) { ok = ok && hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess; };

@@ -89,6 +89,13 @@ class Engine:
         self._dzcnt = torch.zeros((b + 31) // 32, dtype=torch.int32, device=device)      # group counters of nadm_mlp_bwd_image
         self._xg = torch.empty(int(lib.nadm_batch_copy_bytes(b, self.M)), dtype=torch.uint8, device=device) if tiled else None
         self._iota = torch.arange(b, dtype=torch.int32, device=device) if tiled else None
+        # pass 2 in sample slices (include/nadm.h, nadm_decode_bce_sliced): where the SNP chunks alone leave CUs idle (M below ~330k)
+        # every slice parks its partial of dP in a slab; one region per head, one counter per chunk
+        self._p2_slab_off = [0]
+        for kp in L.kp:
+            self._p2_slab_off.append(self._p2_slab_off[-1] + int(lib.nadm_decode_slab_floats(self.M, kp, int(lib.nadm_decode_slices_max(b, self.M, kp)))))
+        self._p2_slab = z(self._p2_slab_off[-1]) if gpu and self._p2_slab_off[-1] else None
+        self._p2_cnt = torch.zeros(L.n_loss, dtype=torch.int32, device=device) if self._p2_slab is not None else None
         # validity of the three by-products for the plain phases below (the plan's own step always produces what it consumes)
         self._qimg_b = self._dzimg_b = -1
         self._dz_last_b = 0
@@ -111,7 +118,8 @@ class Engine:
                         ("Z", self.Z), ("rinv", self.rinv), ("Zn", self.Zn), ("H", self.H), ("Q", self._Q), ("dL", self.dL),
                         ("dHpre", self.dHpre), ("dgp", self.dgp), ("dZ", self._dZ), ("dqpart", self.dqpart), ("losspart", self.losspart),
                         ("small_part", self.small_part), ("zsum", self._zsum), ("dqsum", self._dqsum), ("qimg", self.qimg),
-                        ("dzimg", self._dzimg), ("dzcnt", self._dzcnt), ("xg", self._xg), ("loss_acc", self.loss_acc)):
+                        ("dzimg", self._dzimg), ("dzcnt", self._dzcnt), ("xg", self._xg), ("loss_acc", self.loss_acc),
+                        ("p2_slab", self._p2_slab), ("p2_cnt", self._p2_cnt)):
             setattr(d, name, None if t is None else t.data_ptr())
         d.qimg_head_bytes = self._qimg_head
         d.n_buckets, d.p3_whole, d.debug = L.n_buckets, int(self.p3_whole), int(self.debug)
@@ -363,8 +371,13 @@ class Engine:
                     C.c_void_p(self._Q.data_ptr() + L.qoff[h] * fsz), L.SP, C.c_void_p(gbig.data_ptr() + L.p_off[h] * fsz),
                     C.c_void_p(self.dqpart.data_ptr() + dq_offs[h] * fsz), C.c_void_p(self.losspart.data_ptr() + loss_offs[h] * fsz), flags)
             xg = ptr(self._xg) if (h == 0 and self._xg is not None) else None     # head 0's launch leaves the batch copy for pass 3
-            if self.qimg is not None and self._qimg_b == b and kp <= 16:          # Q operands ready-made by this step's MLP forward
-                check(lib.nadm_decode_bce_images(*args, xg, None, C.c_void_p(self.qimg.data_ptr() + h * self._qimg_head), st), "decode_bce_images")
+            qi = C.c_void_p(self.qimg.data_ptr() + h * self._qimg_head) if (self.qimg is not None and self._qimg_b == b and kp <= 16) else None
+            slices = int(lib.nadm_decode_slices(b, L.M, kp)) if self._p2_slab is not None else 1
+            if slices > 1:                                                        # the library's cut of the batch, as in the step
+                check(lib.nadm_decode_bce_sliced(*args, xg, None, qi, slices, C.c_void_p(self._p2_slab.data_ptr() + self._p2_slab_off[h] * fsz),
+                                                 C.c_void_p(self._p2_cnt.data_ptr() + loss_offs[h] * 4), st), "decode_bce_sliced")
+            elif qi is not None:                                                  # Q operands ready-made by this step's MLP forward
+                check(lib.nadm_decode_bce_images(*args, xg, None, qi, st), "decode_bce_images")
             elif xg is not None:
                 check(lib.nadm_decode_bce_gather(*args, xg, st), "decode_bce_gather")
             else:

@@ -1380,6 +1380,58 @@ def test_mixture_fit_with_the_sums_on_the_device_equals_the_host_form_and_the_li
     assert a.shape == b.shape and np.abs(a - b).max() < 1e-7
 
 
+@pytest.mark.parametrize("ks,b,M", [([8], 800, 6200), ([5], 333, 3000), ([12], 400, 2301), ([3, 9], 800, 5000)])
+def test_pass2_in_sample_slices_gives_the_unsliced_gradients_and_is_reproducible(ks, b, M):
+    """nadm_decode_bce_sliced (the batch's sample tiles dealt to S blocks per SNP chunk, the partial dP sums added by the block counted
+    last): against the S = 1 kernel on the same inputs -- dQ-driven gradients and dP equal to rounding (the sum over the slices has an
+    order of its own), the loss value to 1e-6 -- for S = 2, 3, 4 and the library's own choice; the same bits call after call; counters
+    back at zero; the fused step (Adam in the last block's epilogue) against the unsliced step after three steps; ragged batches."""
+    from neural_admixture_amd._lib import lib
+    N = max(b + 40, 200)
+    Gm = O.synth_genotypes(N, M, max(ks), seed=31)
+    rng = np.random.default_rng(8)
+    Ps = [rng.uniform(0.02, 0.98, (k, M)).astype(np.float32) for k in ks]
+    Ps[0][:, ::7] = 0.0                                                    # clamped entries
+    p = O.make_params(5, (rng.standard_normal((M, 8)) / np.sqrt(M)).astype(np.float32), np.concatenate(Ps, 0), 64, ks)
+    idx = torch.from_numpy(rng.permutation(N)[:b].astype(np.int32)).to(_dev())
+
+    def run(force):
+        lib.nadm_test_force_slices(force)
+        try:
+            e = make_engine(Gm, p, b)
+            want = [int(lib.nadm_decode_slices(b, M, kp)) for kp in e.lay.kp]
+            e.forward(idx, b)
+            e.backward(idx, b)
+            torch.cuda.synchronize()
+            g = engine_grads(e)
+            loss = e.read_loss(reset=True)[0]
+            e.forward(idx, b)
+            e.backward(idx, b)
+            g2 = engine_grads(e)
+            assert all(np.array_equal(g[k_], g2[k_]) for k_ in g), "not reproducible"
+            assert e._p2_cnt is None or int(e._p2_cnt.abs().sum().item()) == 0
+            e.read_loss(reset=True)
+            for bb in (b, b - 37, b):                                       # the step: Adam in the epilogue of the block that is counted last
+                e.train_step(idx[:bb], bb, 2e-3, True)
+            torch.cuda.synchronize()
+            assert e._p2_cnt is None or int(e._p2_cnt.abs().sum().item()) == 0
+            return g, loss, e.pflat.clone(), want
+        finally:
+            lib.nadm_test_force_slices(0)
+
+    g1, loss1, p1, want1 = run(1)
+    assert want1 == [1] * len(ks)
+    for force in (2, 3, 4, 0):
+        g, loss, pf, want = run(force)
+        if force:
+            assert all(w == min(force, (b + 63) // 64) or w <= force for w in want) and max(want) > 1
+        for k_ in g1:
+            scale = np.abs(g1[k_]).max() + 1e-30
+            assert np.abs(g[k_] - g1[k_]).max() <= 2e-6 * scale, (force, k_)
+        assert abs(loss - loss1) <= 1e-6 * abs(loss1)
+        assert (pf - p1).abs().max().item() <= 2e-5               # three Adam steps on gradients equal to rounding (a flipped sign of a ~0 gradient moves lr)
+
+
 @pytest.mark.parametrize("K", [5, 13, 20])
 def test_pass2_gather_byproduct_and_pass3_on_the_compact_copy(K):
     """nadm_decode_bce_gather = nadm_decode_bce + the batch's rows written back to back: same gradients / loss bit for bit,

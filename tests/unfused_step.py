@@ -30,11 +30,16 @@ def unfused_step(e, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True
     xg = e._xg if tiled else None
     for h, kp in enumerate(L.kp):
         ad = AdamArgs(mbig.data_ptr() + L.p_off[h] * fsz, vbig.data_ptr() + L.p_off[h] * fsz, lr, e.step_count, 1.0, 0)
-        check(lib.nadm_decode_bce_step(ptr(e.xp), e.ld, ptr(idx), b, L.M, C.c_void_p(big.data_ptr() + L.p_off[h] * fsz), kp,
-                                       C.c_void_p(e._Q.data_ptr() + L.qoff[h] * fsz), L.SP, C.c_void_p(gbig.data_ptr() + L.p_off[h] * fsz),
-                                       C.c_void_p(e.dqpart.data_ptr() + dq_offs[h] * fsz), C.c_void_p(e.losspart.data_ptr() + loss_offs[h] * fsz),
-                                       ((1 if e.p_unit else 3) if with_loss else 0), ptr(xg) if (h == 0 and tiled) else None, C.byref(ad), st),
-              "decode_bce_step")
+        args = (ptr(e.xp), e.ld, ptr(idx), b, L.M, C.c_void_p(big.data_ptr() + L.p_off[h] * fsz), kp,
+                C.c_void_p(e._Q.data_ptr() + L.qoff[h] * fsz), L.SP, C.c_void_p(gbig.data_ptr() + L.p_off[h] * fsz),
+                C.c_void_p(e.dqpart.data_ptr() + dq_offs[h] * fsz), C.c_void_p(e.losspart.data_ptr() + loss_offs[h] * fsz),
+                ((1 if e.p_unit else 3) if with_loss else 0), ptr(xg) if (h == 0 and tiled) else None, C.byref(ad))
+        slices = int(lib.nadm_decode_slices(b, L.M, kp)) if e._p2_slab is not None else 1
+        if slices > 1:                          # the library's cut of the batch into sample slices (the sum over them has an order of its own)
+            check(lib.nadm_decode_bce_sliced(*args, None, slices, C.c_void_p(e._p2_slab.data_ptr() + e._p2_slab_off[h] * fsz),
+                                             C.c_void_p(e._p2_cnt.data_ptr() + loss_offs[h] * 4), st), "decode_bce_sliced")
+        else:
+            check(lib.nadm_decode_bce_step(*args, st), "decode_bce_step")
     n_loss = L.n_loss
     if e.labels is not None:
         check(lib.nadm_supervised_ce(ptr(e._Q), L.SP, L.ks[0], L.kp[0], ptr(e.labels), ptr(idx), b, e.n_classes, e.sup_weight, ptr(e.dqpart),
