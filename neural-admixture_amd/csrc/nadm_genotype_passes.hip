@@ -781,7 +781,9 @@ constexpr int BF_TS = NADM_BF_TS;       // samples per LDS tile
 
 // QIMG: the Q operands come ready-made from `qimg` (this head's tile images written by the MLP forward, nadm_common.h) instead
 // of being split from the fp32 Q by every block: same bf16 pieces, same results.
-template <int KP, bool LOSS, bool UNIT_P = true, bool QIMG = false>
+// SLICED: the sample-slice form (gridDim.y slices, see the head of the body); false compiles the S = 1 kernel exactly as it stood before
+// the slices existed (the headline shape's launch: on an A/B box the merged form cost it 1.2 %, profiles/r05_ablations.txt item 11)
+template <int KP, bool LOSS, bool UNIT_P = true, bool QIMG = false, bool SLICED = false>
 __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(bf_wpe(KP), bf_wpe(KP)))) void decode_bce_bf16_kernel(
     const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
     float* P, const float* __restrict__ Q, int SP,
@@ -1017,11 +1019,11 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
         }
     };
 
-    const int n_slices = (int)gridDim.y, slice = (int)blockIdx.y;
+    const int n_slices = SLICED ? (int)gridDim.y : 1, slice = SLICED ? (int)blockIdx.y : 0;
     const int ntiles = (b + MF_TS - 1) / MF_TS;
     const int tps = (ntiles + n_slices - 1) / n_slices;      // (the host picks S so that no slice is empty)
-    const int tl0 = slice * tps, tl1 = min(ntiles, tl0 + tps);
-    row_pref = row_index(tl0 * MF_TS);
+    const int tl0 = SLICED ? slice * tps : 0, tl1 = SLICED ? min(ntiles, tl0 + tps) : ntiles;
+    if constexpr (SLICED) row_pref = row_index(tl0 * MF_TS);
     __syncthreads();                                        // zero fill visible before the first commit
     issue(tl0 * MF_TS);
     commit(tl0 * MF_TS);
@@ -1222,18 +1224,6 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
             if (n < KP) s_dp[(int)(snp_of(t, a, r) - snp_blk0) * KP + n] = v * scale_back;
         }
     }
-    float my_loss = 0.f;
-    if constexpr (LOSS) {
-        const float sl = wave_sum_lane63(-0.69314718055994530942f * (lossacc.x + lossacc.y));
-        if (lane == 63) s_loss[wave] = sl;
-    }
-    __syncthreads();
-    if constexpr (LOSS) {
-        if (tid == 0) {
-#pragma unroll
-            for (int w = 0; w < MF_WAVES; ++w) my_loss += s_loss[w];
-        }
-    }
     constexpr int ROW4 = KP / 4;                                      // float4 per SNP row
     constexpr int CH_F4 = MF_WAVES * 16 * NTW * ROW4;                 // float4 of a chunk's [SNPs x KP] slab
     auto finish = [&](int e, const float4 g4) {                       // row piece e of the chunk, gradient complete
@@ -1246,10 +1236,33 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
             else *reinterpret_cast<float4*>(dP + o) = g4;
         }
     };
-    if (n_slices == 1) {
+    if constexpr (!SLICED) {
+        __syncthreads();
         for (int e = tid; e < CH_F4; e += NTHR) finish(e, *reinterpret_cast<const float4*>(s_dp + 4 * e));
-        if constexpr (LOSS) { if (tid == 0) losspart[chunk] = my_loss; }
+        if constexpr (LOSS) {
+            const float sl = wave_sum_lane63(-0.69314718055994530942f * (lossacc.x + lossacc.y));
+            if (lane == 63) s_loss[wave] = sl;
+            __syncthreads();
+            if (tid == 0) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < MF_WAVES; ++w) tot += s_loss[w];
+                losspart[chunk] = tot;
+            }
+        }
         return;
+    }
+    float my_loss = 0.f;
+    if constexpr (LOSS) {
+        const float sl = wave_sum_lane63(-0.69314718055994530942f * (lossacc.x + lossacc.y));
+        if (lane == 63) s_loss[wave] = sl;
+    }
+    __syncthreads();
+    if constexpr (LOSS) {
+        if (tid == 0) {
+#pragma unroll
+            for (int w = 0; w < MF_WAVES; ++w) my_loss += s_loss[w];
+        }
     }
     // ---- S > 1: park the partial, be counted, the last one adds them up (see the head of the kernel)
     constexpr int SLAB_F = p2_slab_floats(KP);                        // floats per (slice, chunk): the slab + 4 (the loss partial + pad)
@@ -1586,7 +1599,15 @@ static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx,
     const int64_t chunks = (M + mf_chunk_snps(KP) - 1) / mf_chunk_snps(KP);
     dim3 grid((unsigned)chunks, (unsigned)n_slices), block(64 * BF_WAVES);
     constexpr bool CAN_IMG = BF_TS == QI_TS;                 // (variant builds with another tile depth: decode_bce_impl refuses qimg)
-#define NADM_P2_LAUNCH(...) hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, __VA_ARGS__>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart, losspart, xg, ad, qimg, slab, slice_cnt)
+#define NADM_P2_LAUNCH(...)                                                                                                                     \
+    do {                                                                                                                                       \
+        if (n_slices > 1)                                                                                                                      \
+            hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, __VA_ARGS__, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart,   \
+                               losspart, xg, ad, qimg, slab, slice_cnt);                                                                      \
+        else                                                                                                                                   \
+            hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, __VA_ARGS__, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart,  \
+                               losspart, xg, ad, qimg, slab, slice_cnt);                                                                      \
+    } while (0)
     if (with_loss & 2) {        // loss value with P possibly outside [0, 1] (before the first restrict_P)
         if (qimg) NADM_P2_LAUNCH(true, false, CAN_IMG); else NADM_P2_LAUNCH(true, false, false);
     } else if (with_loss) {
