@@ -5,7 +5,7 @@
 // published algorithm it runs for exactly that call -- EM for a full-covariance mixture (Dempster, Laird & Rubin 1977; Bishop, PRML
 // 9.2) with the library's conventions -- in float64 on the host.  On a 1000-Genomes-sized input the library's fit is ~480 EM iterations of
 // numpy calls on a [2504, 8] matrix, 0.55 s of a 1.9 s default run whose 250 epochs take 0.34 s, plus a 1.0 s import
-// (profiles/r05_init_profile_c2.txt); here 0.02 s.  At N = 100k the library takes 22-45 s, this 0.8 s (tools/gmm_timing.py).  Host code
+// (profiles/r05_init_profile_before.txt); here 0.02 s.  At N = 100k the library takes 22-45 s, this 0.8 s (tools/gmm_timing.py).  Host code
 // only; _gmm_em.py holds the same algorithm in device ops (train.gmm_p_init(fit="em")).
 //
 //   seeding   the only random draws are the k-means++ picks of K samples per restart; the CALLER makes them (gmm.kmeanspp_picks:

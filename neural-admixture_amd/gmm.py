@@ -11,7 +11,7 @@ max_iter=100, random_state=seed).fit(X_pca).means_``) from
 * ``nadm_gmm_fit_means`` (csrc/nadm_gmm.cpp) -- the EM iterations of the five restarts, float64, one thread per restart.
 
 Why: on a 2504 x 600k run the library fit is 0.55 s and its import 1.0 s of a 1.9 s default run whose 250 epochs take 0.34 s
-(profiles/r05_init_profile_c2.txt); this path takes ~0.05 s and the same means to 1e-12."""
+(profiles/r05_init_profile_before.txt); this path takes ~0.05 s and the same means to 1e-12."""
 from __future__ import annotations
 
 import ctypes as C

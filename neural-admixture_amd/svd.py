@@ -105,7 +105,7 @@ class _Rows:
 def gram64(A: torch.Tensor, chunk: int = 32768) -> torch.Tensor:
     """A^T A in float64 for a tall, narrow A [n, c] (c <= ~32) on its own device, from elementwise products and sums -- no BLAS call.
     The first GEMM / solver call of a process loads hipBLASLt / rocBLAS / rocSOLVER: 0.15-0.2 s each on this stack, a third of a
-    default run on a 1000-Genomes-sized matrix (profiles/r05_init_profile_c2.txt), for products a few reductions do in a millisecond."""
+    default run on a 1000-Genomes-sized matrix (profiles/r05_init_profile_before.txt), for products a few reductions do in a millisecond."""
     n, c = A.shape
     G = torch.zeros((c, c), dtype=torch.float64, device=A.device)
     for s in range(0, n, chunk):
