@@ -94,6 +94,37 @@ def test_argument_validation_of_the_round1_additions(tmp_path):
     assert lib.nadm_loglik_blocks(1) == 8 and lib.nadm_loglik_blocks(1025) == 16          # 8 row slices x 1024-SNP blocks
 
 
+def test_pass2_sample_slice_rule_and_slab_sizes():
+    """nadm_decode_slices is a function of (b, M, kp) alone -- every path to pass 2 takes the same cut, so the rounding of the sum
+    over the slices is the same everywhere: never for the BASELINE shapes (the S = 1 kernel is their launch), never for fewer than 8
+    tiles or 131k+ SNPs or the generic kernel (kp > 16), no empty slice, at most 8; nadm_decode_slices_max bounds every shorter batch
+    (it sizes the slab); the force hook of the tests overrides the rule and is capped by the tile count."""
+    from neural_admixture_amd._lib import lib
+    for b, M in ((800, 500_000), (800, 600_000), (800, 1_000_000), (100, 500_000), (800, 131_072), (400, 50_000), (448, 100_000)):
+        assert lib.nadm_decode_slices(b, M, 8) == 1, (b, M)
+    assert lib.nadm_decode_slices(800, 50_000, 24) == 1 and lib.nadm_decode_slab_floats(50_000, 24, 4) == 0
+    assert lib.nadm_decode_slices(800, 100_000, 8) == 3 and lib.nadm_decode_slices(800, 50_000, 8) == 3
+    assert lib.nadm_decode_slices(6400, 62_500, 8) == 5
+    for M in (2301, 6200, 25_000, 62_500, 100_000, 130_000):
+        for bmax in (449, 800, 1603, 6400):
+            mx = lib.nadm_decode_slices_max(bmax, M, 16)
+            assert 1 <= mx <= 8
+            for b in range(1, bmax + 1, 37):
+                s_ = lib.nadm_decode_slices(b, M, 16)
+                tiles = (b + 63) // 64
+                assert 1 <= s_ <= mx and (s_ == 1 or (s_ - 1) * ((tiles + s_ - 1) // s_) < tiles)      # no empty slice
+    chunks = lib.nadm_decode_chunks(50_000, 8)
+    assert lib.nadm_decode_slab_floats(50_000, 8, 3) == 3 * chunks * (256 * 8 + 4) and lib.nadm_decode_slab_floats(50_000, 8, 1) == 0
+    try:
+        lib.nadm_test_force_slices(4)
+        assert lib.nadm_decode_slices(800, 500_000, 8) == 4 and lib.nadm_decode_slices(100, 500_000, 8) == 2 and lib.nadm_decode_slices(800, 500_000, 32) == 1
+        lib.nadm_test_force_slices(1)
+        assert lib.nadm_decode_slices(800, 50_000, 8) == 1
+    finally:
+        lib.nadm_test_force_slices(0)
+    assert lib.nadm_decode_slices(800, 50_000, 8) == 3
+
+
 def test_engine_refuses_cpu_device():
     import neural_admixture_amd as na
     with pytest.raises(RuntimeError, match="GPU"):
