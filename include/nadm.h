@@ -192,9 +192,9 @@ int nadm_decode_bce_images(const uint8_t* xp, int64_t ld, const int32_t* idx, in
                            float* P, int32_t kp, const float* Q, int32_t SP,
                            float* dP, float* dqpart, float* losspart, int32_t with_loss,
                            uint8_t* xg, const nadm_adam_t* adam, const void* qimg, void* stream);
-/* The same kernel (qimg may be NULL) with the batch's 64-sample tiles dealt to n_slices blocks per SNP chunk: below ~330k SNPs the chunks
- * alone are fewer blocks than the chip holds (977 chunks at M = 500k fill it; 98 at M = 50k leave 60 % of the CUs idle and pass 2 runs
- * at a third of its rate).  dQ rows, the batch copy and everything else per sample are written by the slice that owns the sample; every
+/* The same kernel (qimg may be NULL) with the batch's 64-sample tiles dealt to n_slices blocks per 256-SNP chunk: below ~130k SNPs a
+ * launch lasts as long as ONE block's serial chain (prologue + 13 tiles at b = 800: 49 us whether 98 or 196 blocks run), not as long as
+ * the chip needs, and pass 2 runs at a third to a half of its rate (profiles/r05_ablations.txt item 11).  dQ rows, the batch copy and everything else per sample are written by the slice that owns the sample; every
  * slice parks its partial of dP (and of the loss value) in `slab`, and the block that is counted last in `counters` adds the
  * partials in slice order and runs the epilogue -- no block waits for another, the result is reproducible bit for bit, and it differs
  * from the n_slices = 1 result by the rounding of that sum only.  n_slices: take nadm_decode_slices(b, M, kp) (1 for kp > 16 and

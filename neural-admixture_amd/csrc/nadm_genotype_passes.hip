@@ -790,8 +790,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
     float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart, uint8_t* __restrict__ xg, AdamFused ad,
     const uint4* __restrict__ qimg, float* slab, int* slice_cnt) {
     static_assert(KP <= 16, "one or two 8-wide k slots");
-    // gridDim.y = S sample SLICES (r05): with few SNP chunks (M below ~330k: fewer blocks than the chip holds at three per CU) the batch's
-    // sample tiles are dealt to S blocks per chunk.  Everything a block writes is per sample (dQ slab rows, the batch copy) except dP and
+    // gridDim.y = S sample SLICES (r05): with few SNP chunks (M below ~130k) a launch lasts as long as one block's serial chain over all the
+    // sample tiles, not as long as the chip needs -- the batch's sample tiles are dealt to S blocks per chunk.  Everything a block writes is per sample (dQ slab rows, the batch copy) except dP and
     // the loss value: every slice parks its partial [chunk SNPs x KP] sum (+ its loss partial) in `slab`, is counted, and the block that
     // is counted LAST adds the S partials in slice order and runs the epilogue (Adam or the gradient store) -- the hand-off idiom of
     // the MLP backward's dZ image (nadm_small_kernels.hip: write-through stores, vmcnt(0), device-scope counter, device-scope loads;
