@@ -150,3 +150,11 @@ with tempfile.TemporaryDirectory() as td:
     print(f"b-2 .P writer [{M} x {K}]:                       {sz / t / 1e9:8.2f} GB/s of text   {t:.3f} s ({sz / 1e6:.0f} MB)")
     t = host_time(lambda: np.savetxt(os.path.join(td, "b.Q"), Q[:20000], delimiter=" "), reps=1)
     print(f"b-2 (numpy.savetxt, the reference's call, 20000 rows of Q: {t:.3f} s = {t * N / 20000:.2f} s for all)")
+
+# ---- a1 through the boundary: Engine.pack_from_host (pack on host threads, two pinned buffers, copies on a stream of their own) --------
+nb_rows = min(N, 32768)
+Gh = torch.randint(0, 3, (nb_rows, M), dtype=torch.uint8)
+eng.pack_from_host(Gh[:1024])
+torch.cuda.synchronize()
+t = host_time(lambda: (eng.pack_from_host(Gh), torch.cuda.synchronize()))
+print(f"a1  Engine.pack_from_host, {nb_rows} rows of uint8 from the host: {t:.3f} s = {nb_rows * M / t / 1e9:.1f} G genotypes/s ({t * N / nb_rows:.2f} s for all {N} rows)")
