@@ -927,6 +927,30 @@ def test_bed_to_packed_on_device_equals_the_host_converter(tmp_path):
     assert b2.packed.device.type == "cuda" and a.flipped == b2.flipped and np.array_equal(a.packed.numpy(), b2.packed.cpu().numpy())
 
 
+def test_bed_file_through_the_pinned_ring_equals_the_host_reader(tmp_path):
+    """io.read_bed_packed on a file above the ring's threshold (64 MB: 16 MB pieces read straight into two pinned buffers, each copied
+    to HBM while the next is read, a ragged last piece) against the host reader on the same file: the same packed rows, flip decision
+    and counts -- and below the threshold (the whole-file path) as well."""
+    from neural_admixture_amd.io import read_bed_packed
+    dev = _dev()
+    rng = np.random.default_rng(12)
+    for N, M in ((4099, 70_001), (803, 1501)):
+        nb = (N + 3) // 4
+        raw = rng.integers(0, 256, size=M * nb, dtype=np.uint8)
+        raw &= ~(raw & ~(raw >> 1) & 0x55)                              # no missing calls
+        raw[:nb] |= 0x03 * (rng.integers(0, 2, size=nb, dtype=np.uint8))   # (a SNP with plenty of homozygous-alt codes all the same)
+        with open(tmp_path / "x.bed", "wb") as f:
+            f.write(bytes([0x6C, 0x1B, 0x01]))
+            raw.tofile(f)
+        with open(tmp_path / "x.fam", "w") as f:
+            f.write("".join(f"f{i} i{i} 0 0 0 -9\n" for i in range(N)))
+        assert (M * nb >= (64 << 20)) == (N == 4099)
+        a = read_bed_packed(str(tmp_path / "x.bed"), dev, keep_on_device=True)
+        b = read_bed_packed(str(tmp_path / "x.bed"))
+        assert (a.N, a.M, a.flipped) == (b.N, b.M, b.flipped)
+        assert torch.equal(a.packed.cpu(), b.packed)
+
+
 def test_cli_train_and_infer_demo(tmp_path):
     """`python -m neural_admixture_amd train|infer` on the demo BED: RSVD (GPU, from packed) + GMM init + training +
     outputs in the reference's file formats; infer reproduces Q from the saved encoder."""
