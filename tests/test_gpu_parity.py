@@ -927,6 +927,24 @@ def test_bed_to_packed_on_device_equals_the_host_converter(tmp_path):
     assert b2.packed.device.type == "cuda" and a.flipped == b2.flipped and np.array_equal(a.packed.numpy(), b2.packed.cpu().numpy())
 
 
+def test_pack_from_host_in_many_chunks_and_with_a_row_selection():
+    """Engine.pack_from_host with the rows cut into many chunks (two pinned buffers alternate, the copies run on a stream of their own
+    while the next chunk is packed) and with a shard's row selection: the packed rows of the oracle, whatever the chunking."""
+    import neural_admixture_amd as na
+    dev = _dev()
+    N, M = 1003, 2301
+    Gm = O.synth_genotypes(N, M, 3, seed=9, missing=0.05)
+    want = O.pack2bit(Gm)
+    e = na.Engine(M, 8, 16, [3], dev, 64)
+    for cr in (None, 7, 64, 500, 2000):
+        e.pack_from_host(torch.from_numpy(Gm), chunk_rows=cr)
+        assert np.array_equal(e.xp.cpu().numpy()[:, : want.shape[1]], want), cr
+        assert not e.xp.cpu().numpy()[:, want.shape[1]:].any()
+    rows = np.random.default_rng(2).permutation(N)[:333]
+    e.pack_from_host(torch.from_numpy(Gm), rows=rows, chunk_rows=50)
+    assert np.array_equal(e.xp.cpu().numpy()[:, : want.shape[1]], want[rows]) and e.rows_are_sharded
+
+
 def test_bed_file_through_the_pinned_ring_equals_the_host_reader(tmp_path):
     """io.read_bed_packed on a file above the ring's threshold (64 MB: 16 MB pieces read straight into two pinned buffers, each copied
     to HBM while the next is read, a ragged last piece) against the host reader on the same file: the same packed rows, flip decision
