@@ -889,8 +889,8 @@ __global__ __launch_bounds__(256) void loglik_kernel(const uint8_t* __restrict__
 //   A 32-bit word made of the bytes of 4 consecutive SNPs at one byte column holds a 4 x 4 block (SNP r, sample i) of
 //   2-bit fields at bit 8r + 2i; two delta swaps transpose it to (sample i, SNP r) at bit 8i + 2r = one output byte per
 //   sample.  The recode is bitwise: g_hi = ~c_hi, g_lo = c_lo ^ c_hi.
-//   block = 256 threads, tile = 512 SNPs (128 output byte columns) x 128 samples (32 input byte columns): every thread
-//   transposes 16 words; the tile goes through LDS so that each sample row is written as 128 contiguous bytes.
+//   block = 256 threads, tile = 512 SNPs (128 output byte columns) x 256 samples (64 input byte columns); the tile goes
+//   through LDS so that each sample row is written as 128 contiguous bytes (bed_to_packed_kernel below).
 //   Code counts (for the reader's "flip if the mean code is >= 1" rule) are integer atomics: order-independent.
 // =================================================================================================
 __device__ __forceinline__ uint32_t transpose4x4_2bit(uint32_t w) {
@@ -900,43 +900,88 @@ __device__ __forceinline__ uint32_t transpose4x4_2bit(uint32_t w) {
     return w ^ t ^ (t << 12);
 }
 
+// 4 x 4 byte transpose: out[c] = byte c of in[0..3] (in[r] = one dword of row r)
+__device__ __forceinline__ void transpose4x4_bytes(const uint32_t (&in)[4], uint32_t (&out)[4]) {
+    const uint32_t t01l = __builtin_amdgcn_perm(in[1], in[0], 0x05010400u), t01h = __builtin_amdgcn_perm(in[1], in[0], 0x07030602u);
+    const uint32_t t23l = __builtin_amdgcn_perm(in[3], in[2], 0x05010400u), t23h = __builtin_amdgcn_perm(in[3], in[2], 0x07030602u);
+    out[0] = __builtin_amdgcn_perm(t23l, t01l, 0x05040100u);
+    out[1] = __builtin_amdgcn_perm(t23l, t01l, 0x07060302u);
+    out[2] = __builtin_amdgcn_perm(t23h, t01h, 0x05040100u);
+    out[3] = __builtin_amdgcn_perm(t23h, t01h, 0x07060302u);
+}
+
+// r05: tile = 512 SNPs x 256 samples (64 bytes of every SNP row in -- the tiles next to it in the grid read the rest of the line --
+// 128 bytes of every sample row out); a thread task = 16 SNP rows x one dword of sample bytes (16 samples): 16 dword loads whose
+// lanes run along the SNP row, a 16 x 16 transpose of 2-bit fields in registers (byte transposes by v_perm around the word-level
+// delta swaps), 16 dword stores into the LDS tile.  100k x 500k (25 GB moved): the first version, single bytes read and single
+// bytes stored to LDS, 14.5 ms (1.7 TB/s: bound by its instruction count); this one 6.9 ms (3.6 TB/s) with 256-sample tiles, 8.4
+// with 512 (68 KB of LDS: two blocks per CU), 13.0 with 128 (32-byte reads).  The flip pass, when the data ask for it, 4.5 ms.
+constexpr int BT_SNPS = 512, BT_JD = 16, BT_PITCH = 33;       // SNPs per tile, dword columns of sample bytes per tile, LDS row pitch (dwords)
 __global__ __launch_bounds__(256) void bed_to_packed_kernel(const uint8_t* __restrict__ bed, int64_t N, int64_t M, int64_t nb,
                                                             uint8_t* __restrict__ out, int64_t ld, unsigned long long* __restrict__ counts) {
-    constexpr int TG = 128, TJ = 32;                        // SNP groups (of 4) and sample byte columns per tile
-    __shared__ __attribute__((aligned(16))) uint8_t s_t[TJ * 4][TG + 16];
+    __shared__ uint32_t s_t[16 * BT_JD * BT_PITCH];            // row (s % 16) * 32 + s / 16 holds sample s of the tile: 32 dwords = 512 SNPs
     __shared__ unsigned int s_cnt[4];
     const int tid = threadIdx.x;
-    const int64_t g0 = (int64_t)blockIdx.x * TG, j0 = (int64_t)blockIdx.y * TJ;
+    const int64_t m0 = (int64_t)blockIdx.y * BT_SNPS, jd0 = (int64_t)blockIdx.x * BT_JD;      // (sample tiles run fastest over the grid)
     if (tid < 4) s_cnt[tid] = 0;
     unsigned int c1 = 0, c2 = 0, c3 = 0, cv = 0;
-    for (int e = tid; e < TG * TJ; e += 256) {
-        const int jj = e % TJ, gg = e / TJ;                  // lanes run along the sample byte columns: coalesced byte loads
-        const int64_t j = j0 + jj, m = 4 * (g0 + gg);
-        uint32_t w = 0, valid = 0;
-        if (j < nb) {
-            const int ns = (int)((N - 4 * j < 4) ? (N - 4 * j) : 4);       // samples in this byte
-            const uint32_t smask = ns == 4 ? 0xFFu : ((1u << (2 * ns)) - 1u);
+    for (int t = tid; t < (BT_SNPS / 16) * BT_JD; t += 256) {
+        const int jd = t % BT_JD, rg = t / BT_JD;
+        const int64_t j = 4 * (jd0 + jd), m = m0 + 16 * rg;      // first sample byte column, first SNP row of the task
+        uint32_t d[16];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (m + r < M) {
-                    w |= (uint32_t)bed[(m + r) * nb + j] << (8 * r);
-                    valid |= smask << (8 * r);
-                }
+        for (int r = 0; r < 16; ++r) {
+            d[r] = 0u;
+            if (m + r < M && j < nb) {
+                const uint8_t* src = bed + (m + r) * nb + j;
+                if (j + 4 <= nb) __builtin_memcpy(&d[r], src, 4);            // (rows start at any byte: an unaligned dword load)
+                else for (int c = 0; c < (int)(nb - j); ++c) d[r] |= (uint32_t)src[c] << (8 * c);
+            }
         }
-        const uint32_t hi = w & 0xAAAAAAAAu, lo = w & 0x55555555u;        // PLINK 00,01,10,11 -> 2,3,1,0
-        uint32_t g = ((~hi) & 0xAAAAAAAAu) | (lo ^ (hi >> 1));
-        g &= valid;                                          // padding samples / SNPs past M stay 0
-        const uint32_t gl = g & 0x55555555u, gh = (g >> 1) & 0x55555555u;
-        c3 += __popc(gl & gh); c2 += __popc(gh & ~gl); c1 += __popc(gl & ~gh); cv += __popc(valid & 0x55555555u);
-        const uint32_t t = transpose4x4_2bit(g);             // byte i = sample 4j+i, its 4 SNPs of group gg
+        // e[q][c]: the bytes of rows 4q..4q+3 at byte column c = one 4 SNP x 4 sample block of 2-bit fields
+        uint32_t e[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s_t[4 * jj + i][gg] = (uint8_t)(t >> (8 * i));
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t in[4] = {d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]};
+            transpose4x4_bytes(in, e[q]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t jc = j + c;
+            uint32_t smask = 0u;
+            if (jc < nb) {
+                const int ns = (int)((N - 4 * jc < 4) ? (N - 4 * jc) : 4);      // samples in this byte
+                smask = ns == 4 ? 0xFFu : ((1u << (2 * ns)) - 1u);
+            }
+            uint32_t tq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t valid = 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (m + 4 * q + r < M) valid |= smask << (8 * r);
+                const uint32_t w = e[q][c];
+                const uint32_t hi = w & 0xAAAAAAAAu, lo = w & 0x55555555u;        // PLINK 00,01,10,11 -> 2,3,1,0
+                uint32_t g = ((~hi) & 0xAAAAAAAAu) | (lo ^ (hi >> 1));
+                g &= valid;                                          // padding samples / SNPs past M stay 0
+                const uint32_t gl = g & 0x55555555u, gh = (g >> 1) & 0x55555555u;
+                c3 += __popc(gl & gh); c2 += __popc(gh & ~gl); c1 += __popc(gl & ~gh); cv += __popc(valid & 0x55555555u);
+                tq[q] = transpose4x4_2bit(g);                        // byte i = sample 4 jc + i, its 4 SNPs of rows 4q..4q+3
+            }
+            uint32_t o[4];                                           // o[i] = sample 4 jc + i: the 16 SNPs of the task
+            transpose4x4_bytes(tq, o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_t[((4 * c + i) * BT_JD + jd) * BT_PITCH + rg] = o[i];
+        }
     }
     __syncthreads();
-    for (int e = tid; e < TJ * 4 * (TG / 16); e += 256) {    // 128 sample rows x 128 bytes, 16 B per store
-        const int row = e / (TG / 16), c16 = e % (TG / 16);
-        const int64_t smp = 4 * j0 + row, col = g0 + 16 * c16;
-        if (smp < N && col < ld) *reinterpret_cast<uint4*>(out + smp * ld + col) = *reinterpret_cast<const uint4*>(&s_t[row][16 * c16]);
+    for (int e4 = tid; e4 < 16 * BT_JD * (BT_SNPS / 64); e4 += 256) {        // 512 sample rows x 128 bytes, 16 B per store
+        const int srow = e4 / (BT_SNPS / 64), c16 = e4 % (BT_SNPS / 64);
+        const int64_t smp = 16 * jd0 + srow, col = m0 / 4 + 16 * c16;
+        if (smp < N && col < ld) {
+            const uint32_t* src = &s_t[((srow % 16) * BT_JD + srow / 16) * BT_PITCH + 4 * c16];
+            *reinterpret_cast<uint4*>(out + smp * ld + col) = make_uint4(src[0], src[1], src[2], src[3]);
+        }
     }
     atomicAdd(&s_cnt[1], c1); atomicAdd(&s_cnt[2], c2); atomicAdd(&s_cnt[3], c3); atomicAdd(&s_cnt[0], cv - c1 - c2 - c3);
     __syncthreads();
@@ -1313,7 +1358,7 @@ extern "C" int nadm_bed_to_packed_dev(const uint8_t* bed_dev, int64_t N, int64_t
     if (hipMemsetAsync(counts_dev, 0, 4 * sizeof(uint64_t), st) != hipSuccess || hipMemsetAsync(flipped_dev, 0, sizeof(int32_t), st) != hipSuccess)
         return fail("nadm_bed_to_packed_dev: memset failed");
     // the tile grid covers ld bytes per row, so the row padding is written (as zeros) too
-    dim3 grid((unsigned)((ld + 127) / 128), (unsigned)((nb + 31) / 32));
+    dim3 grid((unsigned)((nb + 4 * BT_JD - 1) / (4 * BT_JD)), (unsigned)((ld + BT_SNPS / 4 - 1) / (BT_SNPS / 4)));
     hipLaunchKernelGGL(bed_to_packed_kernel, grid, dim3(256), 0, st, bed_dev, N, M, nb, out_dev, ld, (unsigned long long*)counts_dev);
     if (flip_if_mean_ge1) {
         const int64_t mp16 = ((M + 3) / 4 + 15) / 16;

@@ -82,7 +82,7 @@ xp = torch.empty((N, ld), dtype=torch.uint8, device=dev)
 cnt = torch.zeros(4, dtype=torch.int64, device=dev)
 flp = torch.zeros(1, dtype=torch.int32, device=dev)
 t = gpu_time(lambda: check(lib.nadm_bed_to_packed_dev(ptr(bed_d), N, M, ptr(xp), ld, ptr(cnt), 1, ptr(flp), None), "bed_dev"))
-print(f"f-1 .bed -> packed on the device (all rows):        {N * M / t / 1e9:8.1f} G genotypes/s   {(M * nb + N * ld) / t / 1e12:6.2f} TB/s moved (2 x 1/4 B per genotype)   {t * 1e3:.1f} ms")
+print(f"f-1 .bed -> packed on the device (all rows):        {N * M / t / 1e9:8.1f} G genotypes/s   {(M * nb + N * ld) / t / 1e12:6.2f} TB/s moved (2 x 1/4 B per genotype)   {t * 1e3:.1f} ms (the transpose + the allele-flip pass this input asks for: {int(flp.item())})")
 mh = min(M, 40_000)
 bed_h = bed_d[:mh].cpu().numpy()
 ldh = ModelLayout.row_stride(mh)
