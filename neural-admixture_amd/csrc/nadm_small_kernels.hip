@@ -1137,14 +1137,32 @@ __global__ void pack2bit_kernel(const uint8_t* __restrict__ g, uint8_t* __restri
     *reinterpret_cast<uint32_t*>(out + r * ld + w * 4) = word;
 }
 
+// (interop only: no kernel of the step reads unpacked genotypes.)  A thread takes 4 packed bytes = 16 genotypes; a byte b spreads into a
+// dword of four codes as (b | b << 6 | b << 12 | b << 18) & 0x03030303 (the shifts put the four fields at bit 0 of bytes 0..3).  One
+// packed byte per thread and four single-byte stores moved 1.7 TB/s (profiles/r05_io_timing.txt).
 __global__ void unpack2bit_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int64_t rows, int64_t M,
                                   int64_t ld) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;    // packed byte within row
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;    // packed dword within the row
     const int64_t r = blockIdx.y;
-    if (r >= rows || c * 4 >= M) return;
-    const uint32_t v = in[r * ld + c];
-    for (int s = 0; s < 4; ++s)
-        if (c * 4 + s < M) out[r * M + c * 4 + s] = (v >> (2 * s)) & 3u;
+    if (r >= rows || c * 16 >= M) return;
+    const uint8_t* src = in + r * ld + 4 * c;
+    uint32_t v = 0;
+    if (4 * c + 4 <= ld) __builtin_memcpy(&v, src, 4);
+    else for (int k = 0; k < (int)(ld - 4 * c); ++k) v |= (uint32_t)src[k] << (8 * k);
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t bq = (v >> (8 * k)) & 0xFFu;
+        o[k] = (bq | (bq << 6) | (bq << 12) | (bq << 18)) & 0x03030303u;
+    }
+    uint8_t* dst = out + r * M + 16 * c;
+    const int64_t n = M - 16 * c;
+    if (n >= 16) {
+        if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+        else __builtin_memcpy(dst, o, 16);                                 // (M need not be a multiple of 16: rows start at any byte)
+    } else {
+        for (int k = 0; k < (int)n; ++k) dst[k] = (uint8_t)(o[k >> 2] >> (8 * (k & 3)));
+    }
 }
 
 // =================================================================================================
@@ -1390,7 +1408,7 @@ extern "C" int nadm_unpack2bit(const uint8_t* in_dev, uint8_t* out_dev, int64_t 
     if (rows == 0 || M == 0) return 0;
     for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
         const int64_t nr = rows - r0 < 65535 ? rows - r0 : 65535;
-        dim3 grid((unsigned)(((M + 3) / 4 + 255) / 256), (unsigned)nr), block(256);
+        dim3 grid((unsigned)(((M + 15) / 16 + 255) / 256), (unsigned)nr), block(256);
         hipLaunchKernelGGL(unpack2bit_kernel, grid, block, 0, (hipStream_t)stream, in_dev + r0 * ld, out_dev + r0 * M, nr, M, ld);
     }
     return check_launch("unpack2bit");
