@@ -503,6 +503,13 @@ int nadm_savetxt_f32(const char* path, const float* a, int64_t rows, int64_t col
 int nadm_synth_packed(uint8_t* xp, int64_t rows, int64_t row0, int64_t M, int64_t ld,
                       const float* Qt, const float* Fq, int32_t K, float missing, uint64_t seed, void* stream);
 
+/* Box fingerprint (bench.py "box"; csrc/nadm_calib.hip): a fixed stream of packed-f32 VALU chains + bf16 matrix instructions, three
+ * waves per SIMD on every CU, `iters` rounds.  Block i writes out[2i] = shader cycles (s_memtime) and out[2i+1] = constant-rate ticks
+ * (s_memrealtime, nadm_wall_clock_khz) it took: cycles / ticks x rate = the shader clock the box sustains under an issue-bound load.
+ * Returns the number of reporting blocks (<= max_blocks), or a negative status.  `sink`: one float, never written. */
+int nadm_calib_clock(int32_t iters, uint64_t* out /* device [2 * max_blocks] */, int32_t max_blocks, float* sink, void* stream);
+int64_t nadm_wall_clock_khz(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,6 +152,8 @@ def _load():
         "nadm_plan_bucket_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(i32)]),
         "nadm_plan_poisoned": (i32, [vp]),
         "nadm_test_force_generic_mlp": (None, [i32]),
+        "nadm_calib_clock": (C.c_int, [i32, vp, i32, vp, vp]),
+        "nadm_wall_clock_khz": (i64, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing

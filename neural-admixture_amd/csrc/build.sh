@@ -8,5 +8,6 @@ hipcc $FLAGS -c nadm_small_kernels.hip -o nadm_small_kernels.o "$@"
 hipcc $FLAGS -c nadm_step.hip -o nadm_step.o "$@"
 hipcc $FLAGS -x hip -c nadm_gmm.cpp -o nadm_gmm.o "$@"          # host code only (decoder-init mixture fit)
 hipcc $FLAGS -c nadm_gmm_dev.hip -o nadm_gmm_dev.o "$@"         # the same fit with the sums over the samples on the device
-hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libnadm.so -o libnadm.so nadm_genotype_passes.o nadm_small_kernels.o nadm_step.o nadm_gmm.o nadm_gmm_dev.o -lpthread -ldl
+hipcc $FLAGS -c nadm_calib.hip -o nadm_calib.o "$@"             # measurement helper: the box fingerprint of bench.py (not on the training path)
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libnadm.so -o libnadm.so nadm_genotype_passes.o nadm_small_kernels.o nadm_step.o nadm_gmm.o nadm_gmm_dev.o nadm_calib.o -lpthread -ldl
 echo "built $(pwd)/libnadm.so"

@@ -220,8 +220,9 @@ class NeuralAdmixture:
         if parallelism not in ("dp", "snp"):
             raise ValueError("parallelism must be 'dp' (samples sharded, gradients summed over ranks) or 'snp' (SNPs sharded)")
         self.parallelism = parallelism
-        self.loss_mode = loss_mode       # "logged": loss only on epochs that print it (:416); "always": every step
-        self.epoch_losses: dict = {}
+        self.loss_mode = loss_mode       # "logged": loss only on epochs that print it (:416); "always": every step; "steps": every step
+        self.epoch_losses: dict = {}     # AND read back after each one like the reference's loss.item() (:414) -> step_losses (parity tests)
+        self.step_losses: list = []
         self.logliks: Optional[list] = None   # filled by the SNP-sharded run (computed where the SNP slices live)
 
     # ---- batch order (src/loaders.py:8-35; sampler objects are torch's own) ----
@@ -280,7 +281,7 @@ class NeuralAdmixture:
         try:
             for epoch in range(self.epochs):
                 logged = (epoch % log_every == 0)
-                with_loss = logged or self.loss_mode == "always"
+                with_loss = logged or self.loss_mode in ("always", "steps")
                 if world > 1:
                     order = seq                                # rows are stored in shard order
                 else:
@@ -288,6 +289,8 @@ class NeuralAdmixture:
                 for s in range(0, n_local, b):
                     bb = min(b, n_local - s)
                     eng.train_step(order[s:s + bb], bb, self.lr, with_loss)     # ONE C call, collectives included
+                    if self.loss_mode == "steps":
+                        self.step_losses.append(eng.read_loss(reset=False)[1])
                 if orders is not None:
                     orders.epoch_queued()                      # next epoch's order: drawn and copied underneath this epoch's steps
                 if with_loss:

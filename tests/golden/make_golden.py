@@ -27,6 +27,7 @@ import torch
 
 REF = os.environ.get("NADM_REF", "/tmp/refbuild")
 sys.path.insert(0, REF)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 from neural_admixture.model.neural_admixture import Q_P, NeuralAdmixture  # noqa: E402
@@ -375,8 +376,115 @@ def case_long_horizon():
     np.savez_compressed(os.path.join(OUT, "multibatch_k8_e60.npz"), **out)
 
 
+# ------------------------------------------------------------------------------------------
+# r06: BASELINE configs[1] at FULL WIDTH (2504 x 600k, K = 7, batch 800: steps of 800/800/800/104) against the reference
+# itself.  Inputs are regenerated from a seed on both sides (tests/golden/seeded_inputs.py): the fixtures hold the
+# reference's outputs and a sha256 of every regenerated input, nothing else.
+C2 = dict(N=2504, M=600_000, K=7, seed=2026, Hd=1024, C=8, b=800, lr=2e-3, epochs=5, run_seed=42, nrows=4096)
+
+
+def _c2_matrix():
+    import seeded_inputs as SI
+    G = SI.genotypes(C2["N"], C2["M"], C2["K"], C2["seed"])
+    return SI, G
+
+
+def _sampled(SI, out, tag, P_Mk, V_MC):
+    """Rows of P / V at seeded SNP indices + float64 column sums over all SNPs."""
+    rows = SI.sample_rows(C2["M"], C2["nrows"], C2["seed"])
+    out[f"{tag}_P_rows"] = P_Mk[rows]
+    out[f"{tag}_P_colsum"] = P_Mk.astype(np.float64).sum(0)
+    if V_MC is not None:
+        out[f"{tag}_V_rows"] = V_MC[rows]
+        out[f"{tag}_V_colsum"] = V_MC.astype(np.float64).sum(0)
+        out[f"{tag}_V_abssum"] = np.abs(V_MC.astype(np.float64)).sum(0)
+
+
+def case_c2_trajectory():
+    """launch_training (model/neural_admixture.py:324-392) for 5 epochs = 20 steps from a seeded V0 / P0, 'hi' and 'med'."""
+    SI, G = _c2_matrix()
+    V0, P0 = SI.init_v_p(C2["M"], C2["C"], C2["K"], C2["seed"])
+    out = dict(sha_G=SI.sha(G), sha_V0=SI.sha(V0), sha_P0=SI.sha(P0), **{k: v for k, v in C2.items()})
+    for mode in ("hi", "med"):
+        Qs, Ps, sd, sl = run_reference_training(G, V0, P0, C2["K"], None, None, C2["Hd"], C2["epochs"], C2["b"], C2["lr"],
+                                                C2["run_seed"], mode)
+        out[f"{mode}_Q"], out[f"{mode}_losses"] = Qs[0], sl
+        _sampled(SI, out, mode, Ps[0], sd["V"])
+        out[f"{mode}_loglik"] = np.float64(ref_cy.loglikelihood(G, np.ascontiguousarray(Ps[0].astype(np.float64)),
+                                                                np.ascontiguousarray(Qs[0].astype(np.float64)), C2["K"]))
+        print("c2 trajectory", mode, sl[:4], sl[-1], out[f"{mode}_loglik"], flush=True)
+    np.savez_compressed(os.path.join(OUT, "c2_trajectory.npz"), **out)
+
+
+def case_c2_end_to_end():
+    """The whole default pipeline on the same matrix: the reference's RSVD (src/svd.py:39-83), then its train()
+    (model/train.py:19-149: PCA projection, GaussianMixture, launch_training, log-likelihood), 5 epochs.  Kept: a sample of Vt,
+    the mixture's means, final Q, sampled P rows, the log-likelihood it printed.  'hi' and 'med'."""
+    from neural_admixture.model import train as ref_train_mod
+    from sklearn.mixture import GaussianMixture
+    SI, G = _c2_matrix()
+    ref_utils.set_seed(C2["run_seed"])
+    Vt = RSVD(G, C2["N"], C2["M"], C2["C"], C2["run_seed"])                 # [C, M]
+    rows = SI.sample_rows(C2["M"], C2["nrows"], C2["seed"])
+    out = dict(sha_G=SI.sha(G), Vt_rows=Vt[:, rows].astype(np.float32), Vt_colsum=Vt.astype(np.float64).sum(1),
+               Vt_abssum=np.abs(Vt.astype(np.float64)).sum(1), **{k: v for k, v in C2.items()})
+    # the first 20 singular values of the sketch are not returned by RSVD; its Vt alone defines the init.  Gram matrix of the
+    # projected samples (what the mixture sees) as a summary of the spectrum:
+    captured = {}
+    real_fit = GaussianMixture.fit
+
+    def fit(self, X, y=None):
+        r = real_fit(self, X, y)
+        captured["means"], captured["lower_bound"], captured["n_iter"] = self.means_.copy(), self.lower_bound_, self.n_iter_
+        captured["X_pca_rows"] = np.asarray(X[:256]).copy()
+        return r
+
+    class _Utils:                                                            # train.py:139: utils.loglikelihood(...)
+        @staticmethod
+        def loglikelihood(data, P, Q, K):
+            captured["loglik"] = float(ref_cy.loglikelihood(data, P, Q, K))
+            return captured["loglik"]
+    real_utils = ref_train_mod.utils
+    for mode in ("hi", "med"):
+        GaussianMixture.fit = fit
+        ref_train_mod.utils = _Utils
+        try:
+            with precision(mode):
+                torch.manual_seed(C2["run_seed"])
+                Ps, Qs, model = ref_train_mod.train(C2["epochs"], C2["b"], C2["lr"], C2["K"], C2["run_seed"], torch.tensor(G),
+                                                    torch.device("cpu"), 0, C2["Hd"], True, Vt.copy(), None, None, None, C2["C"])
+        finally:
+            GaussianMixture.fit = real_fit
+            ref_train_mod.utils = real_utils
+        out[f"{mode}_Q"], out[f"{mode}_loglik"] = Qs[0], np.float64(captured["loglik"])
+        _sampled(SI, out, mode, Ps[0], state_np(model)["V"])
+        if mode == "hi":
+            out["gmm_means"], out["gmm_lower_bound"], out["gmm_n_iter"] = captured["means"], captured["lower_bound"], captured["n_iter"]
+            out["X_pca_rows"] = captured["X_pca_rows"]
+        print("c2 end-to-end", mode, captured["loglik"], captured["lower_bound"], captured["n_iter"], flush=True)
+    np.savez_compressed(os.path.join(OUT, "c2_end_to_end.npz"), **out)
+
+
+def case_c2_multihead():
+    """configs[2] at full width: one epoch (4 steps) of ks = 2..10 on the same matrix from a seeded V0 / P0 [54, M], 'hi'."""
+    SI, G = _c2_matrix()
+    ks = list(range(2, 11))
+    V0, P0 = SI.init_v_p(C2["M"], C2["C"], sum(ks), C2["seed"] + 1)
+    out = dict(sha_G=SI.sha(G), sha_V0=SI.sha(V0), sha_P0=SI.sha(P0), ks=np.asarray(ks), init_seed=C2["seed"] + 1,
+               **{k: v for k, v in C2.items() if k not in ("K", "epochs")})
+    Qs, Ps, sd, sl = run_reference_training(G, V0, P0, None, 2, 10, C2["Hd"], 1, C2["b"], C2["lr"], C2["run_seed"], "hi")
+    rows = SI.sample_rows(C2["M"], 1024, C2["seed"])
+    for h in range(len(ks)):
+        out[f"hi_Q{h}"], out[f"hi_P{h}_rows"], out[f"hi_P{h}_colsum"] = Qs[h], Ps[h][rows], Ps[h].astype(np.float64).sum(0)
+    out["hi_V_rows"], out["hi_V_colsum"], out["hi_losses"] = sd["V"][rows], sd["V"].astype(np.float64).sum(0), sl
+    print("c2 multihead", sl, flush=True)
+    np.savez_compressed(os.path.join(OUT, "c2_multihead.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    import resource                                         # the full-width cases hold tens of GB: fail with MemoryError, not the OOM killer
+    resource.setrlimit(resource.RLIMIT_AS, (58 << 30, 58 << 30))
     cases = {
         "pack": case_pack,
         "bce": case_bce_elementwise,
@@ -398,6 +506,10 @@ if __name__ == "__main__":
         # r05: configs[4]'s model shape (K = 16: the two-k-slot variant of pass 2, 7 MFMAs per tile) and the smallest K that uses it
         "one_step_k16_h1024": lambda: one_step_case("one_step_k16_h1024", 48, 1021, [16], 1024, 8, seed=11),
         "one_step_k9": lambda: one_step_case("one_step_k9", 64, 509, [9], 64, 8, seed=12),
+        # r06: configs[1] / configs[2] at full width against the reference itself (minutes each; inputs regenerated from a seed)
+        "c2_trajectory": case_c2_trajectory,
+        "c2_end_to_end": case_c2_end_to_end,
+        "c2_multihead": case_c2_multihead,
     }
     for name in (sys.argv[1:] or list(cases)):            # no arguments: every fixture; else only the named cases
         cases[name]()

@@ -13,6 +13,7 @@ hipcc $FLAGS -c $src/nadm_small_kernels.hip -o /tmp/abl_$name/b.o "$@" &
 hipcc $FLAGS -c $src/nadm_step.hip -o /tmp/abl_$name/c.o "$@" &
 hipcc $FLAGS -x hip -c $src/nadm_gmm.cpp -o /tmp/abl_$name/d.o "$@" &
 hipcc $FLAGS -c $src/nadm_gmm_dev.hip -o /tmp/abl_$name/e.o "$@" &
+hipcc $FLAGS -c $src/nadm_calib.hip -o /tmp/abl_$name/f.o "$@" &
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libnadm.so -o $out/$name.so /tmp/abl_$name/a.o /tmp/abl_$name/b.o /tmp/abl_$name/c.o /tmp/abl_$name/d.o /tmp/abl_$name/e.o -lpthread -ldl
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libnadm.so -o $out/$name.so /tmp/abl_$name/a.o /tmp/abl_$name/b.o /tmp/abl_$name/c.o /tmp/abl_$name/d.o /tmp/abl_$name/e.o /tmp/abl_$name/f.o -lpthread -ldl
 echo "built $out/$name.so"
