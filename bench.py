@@ -17,6 +17,11 @@ all-gather of the result (csrc/nadm_step.hip, NADM_MODE_DP) -- every step is ONE
     python bench.py --gpus 8                       # spawns 8 ranks itself (re-exec under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
     python bench.py --min-k 2 --max-k 10 --rows 2504 --snps 600000      # configs[2]: nine heads over one pass of X
+
+With N > 1 ranks the same processes go on, behind the headline, to time every open multi-GPU alternative (`"alt"` in the JSON line:
+the reference's global batch 800, SNP sharding at both batch semantics, message B in two buckets, a second communicator for message
+A) and the step's own collectives at their real sizes (`"collectives"`), so that ONE run on an 8-GPU node decides DESIGN.md section 5's
+open questions.  `--alt` runs those legs on one GPU too; `--share-gpu` proves the whole flow on a one-GPU box.
 """
 import argparse
 import hashlib
@@ -35,8 +40,25 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak (same guide); the three GEMM-shaped products run as bf16 pieces
 N_SIMD = 256 * 4          # 256 CUs x 4 SIMDs
-VALU_CYCLES_PER_INST = 4  # one wave64 VALU instruction occupies its SIMD for 4 cycles (tools/ubench_valu.hip; packed f32 alike)
-PROFILE_ROUND = "r05"     # profiles/<round>_pmc_*.json hold the counter passes of the kernels of THIS build (tools/pmc_profile.py)
+PROFILE_ROUND = "r06"     # profiles/<round>_pmc_*.json hold the counter passes of the kernels of THIS build (tools/pmc_profile.py)
+
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints a version banner through C stdio on stdout whenever a communicator is created; stdout carries the ONE JSON line:
+    send fd 1 to stderr for the duration and flush the C buffers before switching back."""
+    import ctypes
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
 
 
 def parse():
@@ -74,6 +96,9 @@ def parse():
     ap.add_argument("--share-gpu", action="store_true",
                     help="functional check of the N>1 flow on a ONE-GPU box: all ranks use cuda:0 and gloo carries the tensors "
                          "(RCCL refuses two ranks per device); not a measurement")
+    ap.add_argument("--alt", action="store_true", help="run the alternative multi-GPU legs + the collective micro-benchmark behind the headline (default at N > 1)")
+    ap.add_argument("--no-alt", action="store_true", help="N > 1: only the headline")
+    ap.add_argument("--alt-steps", type=int, default=50, help="timed steps of every alternative leg (after 10 warm-up steps)")
     ap.add_argument("--no-epoch-loop", action="store_true", help="skip the production epoch loop behind the timed region (profiling passes: only the K-step kernels)")
     ap.add_argument("--cpu-rows", type=int, default=2400, help="rows of the same workload used for the bounded CPU baseline")
     ap.add_argument("--cpu-steps", type=int, default=12, help="timed steps of the CPU baseline (min / median / max reported)")
@@ -219,6 +244,181 @@ def cpu_baseline_reference_shaped(eng, args, dev):
             "reference_itself_in_the_survey_container": {"value": 9.2e7, "cores": 8, "source": "BASELINE.md section 2: the unmodified reference, "
                                                          "8 Xeon cores (AMX bf16 matmuls), 8000 x 50000, K=8 -- another machine, quoted for scale"}}
 
+def box_fingerprint(dev):
+    """What THIS box sustains (r06): (1) csrc/nadm_calib.hip -- a fixed stream of packed-f32 VALU chains + bf16 matrix instructions at pass 2's
+    occupancy on every CU, with s_memtime (shader cycles) and s_memrealtime (constant rate) read around it in every block: the
+    effective shader clock under an issue-bound load, and the duration of the fixed work; (2) a 1 GiB device copy.  A slower
+    headline on a box whose calibration launch is slower by the same factor is the box, not the code."""
+    from neural_admixture_amd._lib import lib, ptr
+    cap, iters = 1024, 8192
+    out = torch.zeros(2 * cap, dtype=torch.int64, device=dev)
+    sink = torch.zeros(1, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = lib.nadm_calib_clock(iters, ptr(out), cap, ptr(sink), st)
+    if nb <= 0:
+        return None
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    for a, b_ in evs:
+        a.record()
+        lib.nadm_calib_clock(iters, ptr(out), cap, ptr(sink), st)
+        b_.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b_) for a, b_ in evs)
+    o = out[:2 * nb].view(nb, 2).cpu().numpy().astype(np.float64)
+    khz = float(lib.nadm_wall_clock_khz())
+    ok = o[:, 1] > 0
+    ghz = float(np.median(o[ok, 0] / o[ok, 1])) * khz * 1e3 / 1e9 if khz > 0 and ok.any() else None
+    n = 1 << 30
+    src, dst = torch.empty(n, dtype=torch.uint8, device=dev), torch.empty(n, dtype=torch.uint8, device=dev)
+    dst.copy_(src)
+    cev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+    for a, b_ in cev:
+        a.record()
+        dst.copy_(src)
+        b_.record()
+    torch.cuda.synchronize()
+    cms = sorted(a.elapsed_time(b_) for a, b_ in cev)
+    del src, dst
+    return {"effective_sclk_ghz": ghz, "calib_ms": ms[len(ms) // 2], "calib_ms_min": ms[0], "calib_blocks": int(nb), "calib_iters": iters,
+            "shader_cycles_per_iter": float(np.median(o[:, 0])) / iters, "wall_clock_khz": khz,
+            "copy_gbs": 2.0 * n / (cms[len(cms) // 2] * 1e-3) / 1e9,
+            "note": "calib: 8 v_pk_fma_f32 chains + 1 v_mfma_f32_16x16x32_bf16 per round, 3 waves/SIMD on every CU (csrc/nadm_calib.hip); "
+                    "effective_sclk_ghz = s_memtime cycles / s_memrealtime ticks x rate, median over blocks; copy: 1 GiB read + 1 GiB written"}
+
+
+ALT_LEGS = ("dp_weak", "dp_global_batch", "snp_weak", "snp_global_batch", "dp_2buckets", "dp_comm_a")
+ALT_COLLECTIVES = ("reduce_scatter_msg_a", "all_gather_msg_a", "reduce_scatter_msg_b", "all_gather_msg_b", "all_reduce_small")
+
+
+def timed_leg(step, finish, warmup, steps, world, dev):
+    """`warmup` untimed + `steps` timed calls of step(i) between barrier + synchronize on both sides; the max over ranks, seconds."""
+    import torch.distributed as dist
+    for i in range(warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i)
+    finish()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def collectives_bench(comm, lay, dev, world, reps=20):
+    """The step's own communicator on the step's own message sizes: reduce-scatter / all-gather of message A = [all P] and message
+    B = [small | V] (slice x world floats each, in place, nadm_comm_t's contract) and the 200 KB all-reduce of the SNP-sharded step
+    (b x sum K floats).  us per call (max over ranks of the mean over `reps` back-to-back calls) and bus GB/s = bytes x (W-1)/W / time
+    (all-reduce: 2 x)."""
+    import torch.distributed as dist
+    c = comm.handle.contents
+    st = torch.cuda.current_stream().cuda_stream
+    n_a, n_b = int(lay.slice_a) * world, int(lay.slice_b) * world
+    n_small = 50_000                                              # 200 KB: Z / dQ partials of a 6400-row global batch
+    buf = torch.zeros(max(n_a, n_b, n_small), dtype=torch.float32, device=dev)
+    tr = getattr(comm, "transport", None)
+    if tr is not None:
+        tr.buffers.append(buf)
+    out = {}
+    try:
+        for name, fn, n, per in (("reduce_scatter_msg_a", c.reduce_scatter, n_a, n_a // world), ("all_gather_msg_a", c.all_gather, n_a, n_a // world),
+                                 ("reduce_scatter_msg_b", c.reduce_scatter, n_b, n_b // world), ("all_gather_msg_b", c.all_gather, n_b, n_b // world),
+                                 ("all_reduce_small", c.all_reduce, n_small, n_small)):
+            def call(_i, fn=fn, per=per):
+                if fn(c.ctx, buf.data_ptr(), per, st):
+                    raise RuntimeError(f"collective {name} failed")
+            dt = timed_leg(call, lambda: None, 3, reps, world, dev) / reps
+            frac = (world - 1) / world if world > 1 else 1.0
+            bus = 4.0 * n * frac * (2.0 if name == "all_reduce_small" else 1.0) / dt / 1e9
+            out[name] = {"bytes": 4 * n, "us": dt * 1e6, "bus_gbs": bus}
+            buf.zero_()
+    finally:
+        if tr is not None:
+            tr.buffers[:] = [t_ for t_ in tr.buffers if t_ is not buf]
+    return out
+
+
+def bench_params(M, S):
+    rng = np.random.default_rng(42)                                     # identical parameters on every rank
+    V0 = (0.01 * rng.standard_normal((M, 8))).astype(np.float32)
+    P0 = rng.uniform(5e-6, 1 - 5e-6, size=(S, M)).astype(np.float32)
+    return V0, P0
+
+
+def alt_legs(args, eng, comm, dev, world, rank, ks, headline):
+    """Behind the headline, in the same processes: every alternative DESIGN.md section 5 lists for "the first 8-GPU node", `--alt-steps`
+    timed steps each (barrier + synchronize on both sides, max over ranks), no CPU legs.  value = the genotypes ALL ranks processed
+    per second of that leg.  Returns (legs, collectives)."""
+    import neural_admixture_amd as na
+    from neural_admixture_amd import comm as nacomm
+    from neural_admixture_amd.model import init_encoder_weights
+    from neural_admixture_amd.snp_parallel import SnpShardedEngine
+    M, S, K, lr, with_loss = args.snps, sum(ks), max(ks), 2e-3, not args.no_loss
+    steps, warm = max(1, args.alt_steps), 10
+    if comm is None:                                                    # one GPU, plain step in the headline: a 1-rank communicator for the legs
+        comm = nacomm.torch_comm(rank, world) if args.share_gpu else nacomm.make_comm(dev, rank, world)
+    mk_comm = (lambda: nacomm.torch_comm(rank, world)) if args.share_gpu else (lambda: nacomm.make_comm(dev, rank, world))
+    legs = {"dp_weak": dict(headline, note="the headline above: samples sharded, --batch rows per GPU and step")}
+    small = init_encoder_weights(42, 8, args.hidden, ks)
+    xp = eng.xp
+    rows_local = xp.shape[0]
+    seq = torch.arange(rows_local, dtype=torch.int32, device=dev)       # stored shard order, contiguous batches (model.py launch_training)
+
+    def run(name, e, rows_step, units_step, order, note):
+        nb = max(1, int(order.numel()) // rows_step)
+
+        def step(i):
+            o = (i % nb) * rows_step
+            e.train_step(order[o:o + rows_step], rows_step, lr, with_loss)
+        dt = timed_leg(step, e.sync, warm, steps, world, dev)
+        legs[name] = {"ms_per_step": dt / steps * 1e3, "value": units_step * steps / dt, "unit": "genotypes/s", "steps": steps,
+                      "rows_per_rank_per_step": rows_step, "global_batch": units_step // M, "note": note}
+
+    def dp_engine(**kw):
+        e = na.Engine(M, 8, args.hidden, ks, dev, args.batch, mode="dp", comm=comm, **kw)
+        e.set_packed(xp)
+        e.load_params(*bench_params(M, S), small)
+        return e
+
+    dp = eng if eng.mode == "dp" else dp_engine()
+    if eng.mode != "dp":
+        run("dp_weak_1rank_comm", dp, args.batch, args.batch * world * M, seq, "the sample-sharded step on this rank count's communicator (the headline ran the plain step)")
+    b_ref = max(1, args.batch // world)                                 # neural_admixture.py:287
+    run("dp_global_batch", dp, b_ref, b_ref * world * M, seq,
+        f"the reference's own semantics: --batch_size {args.batch} over all GPUs = {b_ref} rows per GPU and step (strong scaling)")
+    if dp is not eng:
+        del dp
+    e2 = dp_engine(n_buckets=2)
+    run("dp_2buckets", e2, args.batch, args.batch * world * M, seq, f"message B = [small | V] in {e2.lay.n_buckets} SNP-range buckets, pipelined against pass 3 / the next pass 1")
+    del e2
+    ca = mk_comm()
+    e3 = dp_engine(comm_a=ca)
+    run("dp_comm_a", e3, args.batch, args.batch * world * M, seq, "a second communicator for message A = [all P]: A and B share the links instead of queueing")
+    coll = collectives_bench(comm, eng.lay if eng.mode == "dp" else e3.lay, dev, world)
+    del e3
+    ca.close()
+    torch.cuda.empty_cache()
+    # SNP sharding: every rank holds ALL rows of its M / world SNPs (the same bytes per rank) and processes the global batch
+    gb_w, gb_r = args.batch * world, args.batch
+    es = SnpShardedEngine(M, 8, args.hidden, ks, dev, gb_w, comm=comm)
+    es.set_packed(make_dataset(es, args.rows, 0, K, dev, seed=1234 + 7 * rank))
+    es.load_params(*bench_params(M, S), small)
+    gperm = torch.Generator(device="cpu").manual_seed(1000)             # the same global batches on every rank
+    order = torch.randperm(args.rows, generator=gperm).to(torch.int32).to(dev)
+    run("snp_weak", es, gb_w, gb_w * M, order, f"SNPs sharded, global batch {gb_w} (= --batch x GPUs): two ~{4 * gb_w * (8 + S) // 2 // 1000} KB all-reduces per step, no big message")
+    run("snp_global_batch", es, gb_r, gb_r * M, order, f"SNPs sharded at the reference's global batch {gb_r}")
+    del es
+    torch.cuda.empty_cache()
+    return legs, coll
+
 
 def main():
     args = parse()
@@ -268,10 +468,10 @@ def main():
         import threading
 
         def _give_up():
-            sys.stderr.write(f"[bench] rank {rank}: no result after 900 s -- a collective or a peer is stuck; aborting\n")
+            sys.stderr.write(f"[bench] rank {rank}: no result within the deadline -- a collective or a peer is stuck; aborting\n")
             sys.stderr.flush()
             os._exit(3)
-        hang_guard = threading.Timer(900.0, _give_up)
+        hang_guard = threading.Timer(1800.0 if args.share_gpu else 900.0, _give_up)
         hang_guard.daemon = True
         hang_guard.start()
     import neural_admixture_amd as na
@@ -288,9 +488,6 @@ def main():
         b = args.batch
     snp = args.parallelism == "snp"
     ddp = not snp and (world > 1 or args.force_ddp)
-    if os.environ.get("NADM_FORCE_SLICES"):               # A/B of pass 2's sample slices (tools): 1 = never, n = n slices, unset / 0 = the library's choice
-        from neural_admixture_amd._lib import lib as _nlib
-        _nlib.nadm_test_force_slices(int(os.environ["NADM_FORCE_SLICES"]))
     from neural_admixture_amd import comm as nacomm
     comm = None
     if args.emulate_world is not None:
@@ -312,9 +509,7 @@ def main():
             ctypes.CDLL(None).fflush(None)
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
-    rng = np.random.default_rng(42)                                     # identical parameters on every rank
-    V0 = (0.01 * rng.standard_normal((M, 8))).astype(np.float32)
-    P0 = rng.uniform(5e-6, 1 - 5e-6, size=(S, M)).astype(np.float32)
+    V0, P0 = bench_params(M, S)
     if snp:
         # every rank: ALL rows of its SNP slice (same bytes in HBM per rank as the sample-sharded layout), global batch b*world
         from neural_admixture_amd.snp_parallel import SnpShardedEngine
@@ -334,7 +529,12 @@ def main():
         gperm = torch.Generator(device="cpu").manual_seed(1000 + rank)
     eng.load_params(V0, P0, init_encoder_weights(42, 8, args.hidden, ks))
     del V0, P0
-    perm = torch.randperm(rows_local, generator=gperm).to(torch.int32).to(dev)
+    if world > 1 and not snp:
+        # the production trainer stores a rank's rows in shard order and steps through them contiguously (model.py launch_training:
+        # `order = seq`; DistributedSampler.set_epoch is never called, src/loaders.py:27): the bench's pass 1 gathers what the trainer's does
+        perm = torch.arange(rows_local, dtype=torch.int32, device=dev)
+    else:
+        perm = torch.randperm(rows_local, generator=gperm).to(torch.int32).to(dev)
     nb = max(1, rows_local // gb)
     with_loss = not args.no_loss
     lr = 2e-3
@@ -400,6 +600,11 @@ def main():
         step(s)
     host_queue_ms = (time.perf_counter() - t_h) / 20 * 1e3
     torch.cuda.synchronize()
+    box = box_fingerprint(dev)                              # the chip is warm from the timed region: what this box sustains (r06)
+    if box is not None and world > 1:
+        clocks = [None] * world
+        dist.all_gather_object(clocks, (box["effective_sclk_ghz"], box["calib_ms"]))
+        box["by_rank"] = [{"effective_sclk_ghz": c_[0], "calib_ms": c_[1]} for c_ in clocks]
     # ---- the literal "epoch-seconds" of the metric: the production trainer's epoch loop (model.NeuralAdmixture.launch_training: the
     # sampler's order per epoch drawn and copied underneath the steps, every batch of the epoch incl. a ragged last one, the loss value
     # only on the epochs that log it -- every 5th, neural_admixture.py:416) over whole epochs of the resident matrix.  Reported beside
@@ -460,19 +665,22 @@ def main():
     if sq is not None:
         # SQ_INSTS_VALU / SQ_INSTS_MFMA are summed over the shader engines by rocprofv3's per-dispatch record
         valu, mfma = sq["valu_insts_per_launch"], sq["mfma_insts_per_launch"]
-        clk = sq.get("sclk_ghz", 2.4)
-        issue_peak = N_SIMD * clk * 1e9 / VALU_CYCLES_PER_INST           # wave-instructions per second, whole chip
+        # the shader clock is MEASURED in this run (box_fingerprint: s_memtime against the constant-rate clock under an issue-bound
+        # load), not assumed; no "peak" instruction rate is claimed (an instruction costs 2.9-8.3 cycles by its class): the figure is the
+        # VALU wave-instructions each SIMD issued per shader cycle of THIS run's launch -- times the mix's mean cost it is valu_busy_frac
+        clk = box["effective_sclk_ghz"] if box is not None and box.get("effective_sclk_ghz") else None
         simd_cycles = sq.get("busy_cycles_sum_over_se", 0.0) * 32.0        # SQ_BUSY_CYCLES is per shader engine (32 SIMDs each)
         issue = {"valu_insts_per_genotype": valu * 64.0 / genotypes_launch, "mfma_insts_per_64_genotypes": mfma * 64.0 / genotypes_launch,
-                 "valu_wave_insts_per_launch": valu, "issue_peak_wave_insts_per_s": issue_peak, "sclk_ghz": clk,
-                 "achieved_frac_of_valu_issue_peak": valu / t_dom / issue_peak,
+                 "valu_wave_insts_per_launch": valu, "sclk_ghz": clk, "sclk_source": "measured in this run (box.effective_sclk_ghz)",
+                 "valu_insts_per_simd_cycle": valu / t_dom / (N_SIMD * clk * 1e9) if clk else None,
+                 "shader_cycles_per_launch_this_run": t_dom * clk * 1e9 if clk else None,
+                 "shader_cycles_per_launch_profiled": simd_cycles / N_SIMD if simd_cycles else None,
                  # counters of the same launch: cycles a SIMD spent issuing VALU work / matrix work over all SIMD-cycles of the launch.
                  # The two do not overlap on a SIMD (tools/ubench_issue.hip), so their sum is the issue utilisation; the rest is the
                  # partly filled last round of blocks, barriers and dependency stalls
                  "simd_valu_busy_frac": sq["active_inst_valu_quad_cycles"] * 4.0 / simd_cycles if simd_cycles else None,
                  "simd_mfma_busy_frac": sq["valu_mfma_busy_cycles"] / simd_cycles if simd_cycles else None,
-                 "note": "VALU wave-instructions of one launch / its duration vs 1024 SIMDs x clk / 4 cycles (instructions cost 2.9-8.3 cycles, "
-                         "tools/ubench_valu_asm.hip); MFMA issue comes on top (not hidden, DESIGN.md section 4)"}
+                 "note": "instruction counts and busy fractions: replayed counter passes (issue_source); clock and launch duration: this run"}
     achieved = alg_8d / t_dom / 1e9
     step_bytes = 0.75 * b * M + 36.0 * (8 + S) * M                        # SURVEY.md 8d whole-step figure: 0.75 + 36 (C+S)/b per genotype
     per_step_units = (gb if snp else b * world) * M
@@ -501,10 +709,9 @@ def main():
         "roofline": {"bound": "valu_issue", "roof_8d": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_8d": achieved / HBM_PEAK_GBS, "frac_min": alg_min / t_dom / 1e9 / HBM_PEAK_GBS,
                      # what the counters say the launch is bound by: the fraction of all SIMD-cycles of the launch spent issuing VALU and
-                     # matrix instructions (they do not overlap on a SIMD), and the VALU instruction rate against 1024 SIMDs x clk / 4
+                     # matrix instructions (they do not overlap on a SIMD)
                      "issue_frac": (issue["simd_valu_busy_frac"] + issue["simd_mfma_busy_frac"]) if issue and issue["simd_valu_busy_frac"] is not None else None,
                      "valu_busy_frac": issue["simd_valu_busy_frac"] if issue else None, "mfma_busy_frac": issue["simd_mfma_busy_frac"] if issue else None,
-                     "valu_issue_rate_frac": issue["achieved_frac_of_valu_issue_peak"] if issue else None,
                      "x_walks": x_walks, "bytes_incl_x_rewalks": alg_8d + (x_walks - 1) * rows_b * m_loc / 4,
                      "traffic": hbm["traffic_bytes_per_launch"] if hbm else None,
                      "traffic_source": (f"profiles/{PROFILE_ROUND}_pmc_hbm.json (replayed, not measured in this run: separate --pmc passes of FETCH_SIZE and WRITE_SIZE; {hbm['correction']}; src_hash {hbm['src_hash']})"
@@ -527,11 +734,17 @@ def main():
                               "frac": b * M * args.steps / dt * (4 * 8 + 6 * S) / 1e12 / MFMA_BF16_PEAK_TFLOPS}},
         "loss_last_step": loss_last,
         "epoch_loop": full_run,
+        "box": box,
     }
     if world > 1:
         out["ms_per_step_this_rank"] = dt_rank / args.steps * 1e3          # rank 0's own clock; ms_per_step is the max over ranks
     if args.share_gpu:
         out["config"]["share_gpu"] = "all ranks on cuda:0 over gloo: functional check, not a measurement"
+    if ((world > 1 and not args.no_alt) or args.alt) and not snp and args.emulate_world is None:
+        headline = {"ms_per_step": out["ms_per_step"], "value": out["value"], "unit": "genotypes/s", "steps": args.steps,
+                    "rows_per_rank_per_step": b, "global_batch": b * world}
+        with stdout_to_stderr():                                        # (the legs create communicators)
+            out["alt"], out["collectives"] = alt_legs(args, eng, comm if ddp else None, dev, world, rank, ks, headline)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and len(ks) == 1 and args.emulate_world is None:
             out["cpu_baseline"] = cpu_baseline(eng, args, dev)

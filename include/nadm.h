@@ -42,7 +42,7 @@ extern "C" {
 #define NADM_MAX_K 64
 #define NADM_MAX_BUCKETS 8
 #define NADM_MAX_P2_SLICES 8   /* sample slices of pass 2 (nadm_decode_bce_sliced) */
-#define NADM_ABI_VERSION 11  /* 11: nadm_gmm_fit_means_dev, nadm_loglik_blocks counts 8 row slices per 1024-SNP block, nadm_decode_bce_sliced / nadm_decode_slices / nadm_decode_slab_floats / nadm_test_force_slices + nadm_plan_desc_t.p2_slab / p2_cnt (pass 2 in sample slices when the SNP chunks alone do not fill the chip); 10: message B of the sample-sharded step in SNP-range buckets (nadm_flat_layout takes n_buckets, nadm_flat_layout_t.bkt_*, nadm_plan_desc_t.n_buckets / p3_whole / comm_a / debug, nadm_encode_fwd_part, nadm_plan_bucket_ms), nadm_comm_t.async_error, nadm_comm_rccl_probe, nadm_comm_rccl with a watchdog (timeout_ms), a failed step poisons its plan; 9: nadm_step / nadm_plan_* / nadm_comm_* / nadm_flat_layout (the step as one call, sharded optimizer), nadm_test_force_generic_mlp; 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
+#define NADM_ABI_VERSION 12  /* 12: nadm_test_force_slices / nadm_test_force_generic_mlp exist in the test build only (-DNADM_TEST_HOOKS), nadm_calib_clock / nadm_wall_clock_khz; 11: nadm_gmm_fit_means_dev, nadm_loglik_blocks counts 8 row slices per 1024-SNP block, nadm_decode_bce_sliced / nadm_decode_slices / nadm_decode_slab_floats / nadm_test_force_slices + nadm_plan_desc_t.p2_slab / p2_cnt (pass 2 in sample slices when the SNP chunks alone do not fill the chip); 10: message B of the sample-sharded step in SNP-range buckets (nadm_flat_layout takes n_buckets, nadm_flat_layout_t.bkt_*, nadm_plan_desc_t.n_buckets / p3_whole / comm_a / debug, nadm_encode_fwd_part, nadm_plan_bucket_ms), nadm_comm_t.async_error, nadm_comm_rccl_probe, nadm_comm_rccl with a watchdog (timeout_ms), a failed step poisons its plan; 9: nadm_step / nadm_plan_* / nadm_comm_* / nadm_flat_layout (the step as one call, sharded optimizer), nadm_test_force_generic_mlp; 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
@@ -209,9 +209,11 @@ int nadm_decode_bce_sliced(const uint8_t* xp, int64_t ld, const int32_t* idx, in
                            float* dP, float* dqpart, float* losspart, int32_t with_loss,
                            uint8_t* xg, const nadm_adam_t* adam, const void* qimg,
                            int32_t n_slices, float* slab, int32_t* counters, void* stream);
-/* tests and experiments: n > 0 makes nadm_decode_slices return n (capped by the number of tiles) for every kp <= 16 shape, 0 = the
- * library's choice.  Process-wide; set it before the buffers of a plan are sized. */
+#ifdef NADM_TEST_HOOKS   /* the TEST build only (csrc/build.sh -> libnadm_testhooks.so); the shipping library does not export it */
+/* n > 0 makes nadm_decode_slices return n (capped by the number of tiles) for every kp <= 16 shape, 0 = the library's choice.
+ * Process-wide; set it before the buffers of a plan are sized (a plan refuses a step that would need more slices than its slab holds). */
 void nadm_test_force_slices(int32_t n);
+#endif
 /* `weights` (may be NULL): the MLP weight-gradient partials -- the first half of nadm_mlp_bwd_weights, which like pass 3
  * depends only on the outputs of nadm_mlp_bwd(grad_small = NULL) -- are computed by extra blocks of the same launch (they
  * fill the under-occupied last round of pass 3) into small_part [nadm_sample_splits(b), n_small]; nadm_small_grads then
@@ -456,9 +458,10 @@ int  nadm_plan_kernel_ms(nadm_plan_t* plan, float* ms /* [NADM_T_COUNT] */, int3
 int  nadm_plan_bucket_ms(nadm_plan_t* plan, float* ms /* [NADM_MAX_BUCKETS] */, int32_t* n);
 int32_t nadm_plan_poisoned(const nadm_plan_t* plan);
 
-/* ---- test hook: route nadm_mlp_fwd / nadm_mlp_bwd to the generic (any hidden width) kernels even where the register-resident
- * ones apply, so that tests can compare the two.  Process-wide; not for production use. */
+#ifdef NADM_TEST_HOOKS   /* the TEST build only: route nadm_mlp_fwd / nadm_mlp_bwd to the generic (any hidden width) kernels even where the
+                          * register-resident ones apply, so that tests can compare the two.  Process-wide. */
 void nadm_test_force_generic_mlp(int32_t on);
+#endif
 
 /* ---- 8(f)-3: log-likelihood report from the packed matrix (src/utils_c/utils.pyx:15-40, called train.py:134-146) -----
  * partial[b] (b < nadm_loglik_blocks(M) = 8 row slices x ceil(M / 1024), double, device) = sum over the block's 1024 SNPs and

@@ -111,7 +111,6 @@ def _load():
         "nadm_decode_slices": (i32, [i32, i64, i32]),
         "nadm_decode_slices_max": (i32, [i32, i64, i32]),
         "nadm_decode_slab_floats": (i64, [i64, i32, i32]),
-        "nadm_test_force_slices": (None, [i32]),
         "nadm_mlp_fwd_images": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, i64, vp]),
         "nadm_q_image_bytes": (C.c_int64, [i32]),
         "nadm_encode_fwd_small": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp]),
@@ -151,7 +150,6 @@ def _load():
         "nadm_plan_kernel_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(i32)]),
         "nadm_plan_bucket_ms": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(i32)]),
         "nadm_plan_poisoned": (i32, [vp]),
-        "nadm_test_force_generic_mlp": (None, [i32]),
         "nadm_calib_clock": (C.c_int, [i32, vp, i32, vp, vp]),
         "nadm_wall_clock_khz": (i64, []),
     }
@@ -159,7 +157,10 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
-    if lib.nadm_abi_version() != 11:
+    for name in ("nadm_test_force_slices", "nadm_test_force_generic_mlp"):      # the TEST build only (csrc/libnadm_testhooks.so, -DNADM_TEST_HOOKS)
+        if hasattr(lib, name):
+            getattr(lib, name).restype, getattr(lib, name).argtypes = None, [i32]
+    if lib.nadm_abi_version() != 12:
         raise RuntimeError("neural_admixture_amd: libnadm.so ABI version mismatch")
     return lib, tuple(sig)
 

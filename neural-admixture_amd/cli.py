@@ -43,6 +43,10 @@ def parse_train_args(argv):
                         "The GPU step does not use them; the decoder-init mixture fit and the host side of the readers do: 4 is a good value")
     p.add_argument("--parallelism", choices=("dp", "snp"), default="dp",
                    help="multi-GPU sharding: dp = samples (the reference's DDP), snp = SNPs (two tiny all-reduces per step)")
+    p.add_argument("--gmm", choices=("auto", "sklearn", "native", "device", "em"), default="auto",
+                   help="decoder-init mixture fit (model/train.py:60-68): sklearn = the reference's own scikit-learn GaussianMixture call; "
+                        "auto (default) = its float64 restatement on host threads / HIP kernels (same means to 1e-10, no library import: "
+                        "0.1 s instead of 1.5 s on a 1000-Genomes-sized run); see INTEGRATION.md section 3")
     p.add_argument("--share_gpu", action="store_true",
                    help="functional check of a --num_gpus N run on a ONE-GPU box: every rank uses cuda:0 and gloo carries the "
                         "tensors (RCCL refuses two ranks per device)")
@@ -95,7 +99,7 @@ def _train_worker(rank, args, num_gpus, data, V, pops, t0):
     K = args.k
     Ps, Qs, model = train(args.epochs, args.batch_size, args.learning_rate, K, args.seed, data, device, num_gpus, args.hidden_size,
                           master, V, pops, args.min_k, args.max_k, args.n_components, parallelism=args.parallelism,
-                          host_threads=args.threads)
+                          host_threads=args.threads, gmm=args.gmm)
     if master:
         save_model(model, args.name, args.save_dir)
         write_outputs(Qs, args.name, K, args.min_k, args.max_k, args.save_dir, Ps)

@@ -11,3 +11,9 @@ hipcc $FLAGS -c nadm_gmm_dev.hip -o nadm_gmm_dev.o "$@"         # the same fit w
 hipcc $FLAGS -c nadm_calib.hip -o nadm_calib.o "$@"             # measurement helper: the box fingerprint of bench.py (not on the training path)
 hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libnadm.so -o libnadm.so nadm_genotype_passes.o nadm_small_kernels.o nadm_step.o nadm_gmm.o nadm_gmm_dev.o nadm_calib.o -lpthread -ldl
 echo "built $(pwd)/libnadm.so"
+# the TEST build: the same sources with -DNADM_TEST_HOOKS (nadm_test_force_slices / nadm_test_force_generic_mlp exist only here).  The tests that
+# need a hook re-run themselves in a child process against it (tests/conftest.py: in_hook_build); the shipping library has none.
+hipcc $FLAGS -DNADM_TEST_HOOKS -c nadm_genotype_passes.hip -o nadm_genotype_passes_th.o "$@"
+hipcc $FLAGS -DNADM_TEST_HOOKS -c nadm_small_kernels.hip -o nadm_small_kernels_th.o "$@"
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-soname,libnadm.so -o libnadm_testhooks.so nadm_genotype_passes_th.o nadm_small_kernels_th.o nadm_step.o nadm_gmm.o nadm_gmm_dev.o nadm_calib.o -lpthread -ldl
+echo "built $(pwd)/libnadm_testhooks.so"

@@ -597,9 +597,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef NADM_BF_TS
 #define NADM_BF_TS 64        // samples per LDS tile
 #endif
-#ifndef NADM_TW_SWZ
-#define NADM_TW_SWZ 1        // rotate the chunks of the dR transposition buffer's rows (conflict-free, see the kernel)
-#endif
 #ifndef NADM_BF_WPE
 #define NADM_BF_WPE 3        // waves per SIMD the register allocator must leave room for (K <= 8)
 #endif
@@ -693,26 +690,16 @@ __device__ __forceinline__ f32x2_t two_max0(const f32x2_t v) {                 /
 }
 // gradient w.r.t. the pre-clamp reconstruction for two genotypes, TIMES 1e-12 (eps; the caller multiplies the sums by rcp(1e-12));
 // den = (1 - d) d is handed back for the loss
-// NADM_P2_SCALAR_F32 (A/B builds only: tools/build_variant.sh p2scalar -DNADM_P2_SCALAR_F32 -fno-slp-vectorize): the per-genotype algebra of
-// the tile loop with scalar v_*_f32 instead of v_pk_*_f32 -- the same IEEE operations, the same bits.  MI355X_MICROARCH.md prices packed
-// f32 beside MFMAs at +22..26 cycles per instruction against two scalar ones; measured here (r05, profiles/r05_ablations.txt) the scalar
-// form is SLOWER: twice the issue slots cost more than the penalty saves at three waves per SIMD.
-#ifdef NADM_P2_SCALAR_F32
-#define P2_FMA(a, b, c) ((f32x2_t){__builtin_fmaf((a).x, (b).x, (c).x), __builtin_fmaf((a).y, (b).y, (c).y)})
-#define P2_SUB(a, b) ((f32x2_t){(a).x - (b).x, (a).y - (b).y})
-#define P2_MUL(a, b) ((f32x2_t){(a).x * (b).x, (a).y * (b).y})
-#else
-#define P2_FMA(a, b, c) __builtin_elementwise_fma(a, b, c)
-#define P2_SUB(a, b) ((a) - (b))
-#define P2_MUL(a, b) ((a) * (b))
-#endif
+// (r05, profiles/r05_abl_p2scalar.txt: the same algebra with scalar v_*_f32 instead of v_pk_*_f32 -- MI355X_MICROARCH.md prices packed f32
+// beside MFMAs at +22..26 cycles per instruction against two scalar ones -- is SLOWER here, 260 vs 239 us: twice the issue slots cost more
+// than the penalty saves at three waves per SIMD.  The arm is gone from the source.)
 __device__ __forceinline__ f32x2_t bce_grad2(const f32x2_t d, const f32x2_t x, const float eps, f32x2_t& den) {
-    den = P2_FMA(-d, d, d);                                                    // d - d^2 in one rounding; < 0 exactly when d is outside [0, 1]
+    den = __builtin_elementwise_fma(-d, d, d);                                                    // d - d^2 in one rounding; < 0 exactly when d is outside [0, 1]
     // sat(1e-12 / den): 1 at den <= 1e-12 (and +0), 0 for den < 0.  Written per element so that the clamp folds into the multiply
     // (v_mul_f32_e64 ... clamp); as inline asm (v_pk_mul_f32 ... clamp) it would sit right behind the v_rcp without the wait state
     // the hardware needs between a transcendental and its consumer -- the hazard recognizer does not look into asm statements
     const f32x2_t inv = {__builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(den.x) * eps, 0.f, 1.f), __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(den.y) * eps, 0.f, 1.f)};
-    return P2_MUL(P2_SUB(d, x), inv);
+    return (d - x) * inv;
 }
 // exact form: adds x*log2(r') + (1-x)*log2((1-r)') + 20 per genotype to lossacc (packed halves)
 template <bool UNIT_P>
@@ -735,9 +722,9 @@ __device__ __forceinline__ void bce_loss_exact2(const f32x2_t d, const f32x2_t o
 // h = [c == 1] per genotype
 __device__ __forceinline__ void bce_loss_prod2(const f32x2_t d, const f32x2_t den, const f32x2_t x, const f32x2_t h, float& acc) {
     const f32x2_t o = {__builtin_amdgcn_fmed3f(1.f - d.x, 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - d.y, 0.f, 1.f)};   // 1 - r: v_sub_f32 ... clamp
-    const f32x2_t q = P2_SUB(o, x);                                                      // 1-r | . | -d  for c = 0 | 1 | 2
-    const f32x2_t qq = P2_MUL(q, q);                                                     // (1-r)^2 | . | d^2
-    const f32x2_t f = P2_FMA(h, P2_SUB(den, qq), qq);                                    // c == 1: qq + (den - qq)
+    const f32x2_t q = o - x;                                                             // 1-r | . | -d  for c = 0 | 1 | 2
+    const f32x2_t qq = q * q;                                                            // (1-r)^2 | . | d^2
+    const f32x2_t f = __builtin_elementwise_fma(h, den - qq, qq);                        // c == 1: qq + (den - qq)
     acc += __builtin_amdgcn_logf(f.x * f.y);
     asm volatile("" : "+v"(acc));             // pin the accumulation here (see bce_loss_exact2)
 }
@@ -822,15 +809,11 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
     uint4 (*const s_qr)[2][64] = reinterpret_cast<uint4 (*)[2][64]>(&s_qimg[0]);
     uint4 (*const s_qd)[W ? 2 : 1][64] = reinterpret_cast<uint4 (*)[W ? 2 : 1][64]>(&s_qimg[(MF_TS / 16) * 2 * 64]);
     __shared__ __attribute__((aligned(16))) float s_dq[MF_WAVES][W ? 1 : 2][MF_TS * KP];   // K <= 8: [hi part | mid part] of the P operand, added up below
-    // row stride / plane size of the transposition buffer in bf16 units: 16 SNPs + 4 pad.  With dense 32-byte rows the 8-byte
-    // writes of a half-wave fall on 4 banks groups (4-way conflicts, 56 % of the LDS-busy cycles in r01's counters); 40-byte
-    // rows spread them.  -4 % on the kernel without the loss value (230 -> 221 us), nothing with it (VALU-bound); K > 8 keeps
-    // the dense rows, its 50 KB of LDS would not fit three blocks per CU with the pad
-    // NADM_TW_SWZ: dense 32-byte rows with the four 8-byte chunks of row r rotated by (r >> 2) & 3 -- the writes of a half-wave
-    // (16 rows x 2 chunks) then fall on every bank exactly twice (their minimum) AND the transposing reads (4 consecutive rows x
-    // 4 chunks per 16 lanes) on every bank once, which no padded row stride gives (reads want stride = 8 mod 32 dwords, writes 2 x odd)
-    constexpr bool SWZ = NADM_TW_SWZ != 0;
-    constexpr int TWS = SWZ ? 16 : (W ? 16 : 20), TWP = 32 * TWS;
+    // the transposition buffer: dense 32-byte rows (16 SNPs as bf16) with the four 8-byte chunks of row r rotated by (r >> 2) & 3 -- the
+    // writes of a half-wave (16 rows x 2 chunks) then fall on every bank exactly twice (their minimum) AND the transposing reads (4
+    // consecutive rows x 4 chunks per 16 lanes) on every bank once, which no padded row stride gives (reads want stride = 8 mod 32 dwords,
+    // writes 2 x odd; r01's unswizzled dense rows: 4-way conflicts, 56 % of the LDS-busy cycles; padded 40-byte rows: the r02-r04 form)
+    constexpr int TWS = 16, TWP = 32 * TWS;
     __shared__ __attribute__((aligned(16))) uint16_t s_t[MF_WAVES][2][2][TWP];  // per wave: [SNP tile of the pair][hi / lo][32 samples][16 SNPs (+ pad)]
     __shared__ float s_loss[MF_WAVES];
 
@@ -1036,10 +1019,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
     float eps_v = 1e-12f;
     asm volatile("" : "+s"(eps_v));                        // (opaque: the compiler would otherwise pair the two multiplies and clamp separately)
     const float eps = eps_v;
-#ifndef NADM_FAST_LOSS_MAXKP
-#define NADM_FAST_LOSS_MAXKP 16
-#endif
-    constexpr bool FAST_LOSS = LOSS && UNIT_P && KP <= NADM_FAST_LOSS_MAXKP;   // one logarithm per pair of genotypes, exact form as the cold fallback
+    constexpr bool FAST_LOSS = LOSS && UNIT_P;              // one logarithm per pair of genotypes, exact form as the cold fallback
     // the lane's codes of one 16-sample tile: nibble = one 2-bit code, codes 0,2 / 1,3 of each byte (byte t = 4 SNPs of tile t)
     auto load_codes = [&](int st, uint32_t& ev, uint32_t& od) {
         uint32_t w;
@@ -1061,7 +1041,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
         return D;
     };
     uint16_t* const tw = &s_t[wave][0][0][0];
-    const int wchunk = SWZ ? ((a + (n >> 2)) & 3) : a;      // where this lane's 8-byte chunk of row 16*s2 + n goes
+    const int wchunk = (a + (n >> 2)) & 3;                 // where this lane's 8-byte chunk of row 16*s2 + n goes (rotated, see s_t)
     for (int tl = tl0; tl < tl1; ++tl) {
         const int i0 = tl * MF_TS;
         const int nt = min(MF_TS, b - i0);
@@ -1107,7 +1087,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                                     bce_loss_exact2<UNIT_P>(d, (f32x2_t){1.f, 1.f} - d, x, lossacc);
                                 const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector(dR, bf16x2_t));
                                 hi[t2][h2] = hp;
-                                const f32x2_t rem = P2_SUB(dR, ((f32x2_t){__uint_as_float(hp << 16), __uint_as_float(hp & 0xFFFF0000u)}));
+                                const f32x2_t rem = dR - (f32x2_t){__uint_as_float(hp << 16), __uint_as_float(hp & 0xFFFF0000u)};
                                 lo[t2][h2] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rem, bf16x2_t));
                             }
                             // transposition buffer of this SNP tile: T[t2][hl][sample 16*s2 + n][SNP 4a .. 4a+3]  (row = 16 bf16 = 32 B)
@@ -1121,9 +1101,6 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                         dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q1[tp]), bl, dq[s2], 0, 0, 0);
                         if constexpr (W) {
                             dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q2[tp]), bh, dq[s2], 0, 0, 0);
-#ifdef NADM_W_KEEP_MIDLO       // A/B builds only (profiles/r05_ablations.txt item 7): the P_mid x dR_lo term, 2^-16 of the product
-                            dq[s2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_q2[tp]), bl, dq[s2], 0, 0, 0);
-#endif
                         }
                     }
                     // dP: per SNP tile, read dR (hi, lo) of the 32 samples back transposed, then 2 (W: 4) MFMAs
@@ -1132,8 +1109,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                         // A operand: lane (row = SNP n, slot a = samples 8a..8a+7): two transposing reads of 4 samples each
                         typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_p;
                         const int trow = 8 * a + (n >> 2);
-                        const int tcol = SWZ ? 4 * (((n & 3) + 2 * a) & 3) : (n & 3) * 4;           // rows trow: (trow >> 2) & 3 = 2a
-                        const int tcol4 = SWZ ? 4 * (((n & 3) + 2 * a + 1) & 3) : (n & 3) * 4;      // rows trow + 4: 2a + 1
+                        const int tcol = 4 * (((n & 3) + 2 * a) & 3);                               // rows trow: (trow >> 2) & 3 = 2a
+                        const int tcol4 = 4 * (((n & 3) + 2 * a + 1) & 3);                          // rows trow + 4: 2a + 1
                         const uint16_t* th = tw + (2 * t2 + 0) * TWP, *tlw = tw + (2 * t2 + 1) * TWP;
                         const s16x4_t h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(th + trow * TWS + tcol));
                         const s16x4_t h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(th + (trow + 4) * TWS + tcol4));
@@ -1146,9 +1123,6 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                         dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(qd1), dpacc[t], 0, 0, 0);
                         if constexpr (W) {
                             dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(qd2), dpacc[t], 0, 0, 0);
-#ifdef NADM_W_KEEP_MIDLO
-                            dpacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(qd2), dpacc[t], 0, 0, 0);
-#endif
                         }
                     }
                 }
@@ -1865,14 +1839,19 @@ extern "C" int nadm_decode_bce_images(const uint8_t* xp, int64_t ld, const int32
 }
 
 // ---- pass 2 with the batch's sample tiles dealt to n_slices blocks per SNP chunk (see decode_bce_bf16_kernel)
+#ifdef NADM_TEST_HOOKS          // the test build only (csrc/build.sh -> libnadm_testhooks.so): the shipping library has no way to override the rule below
 static std::atomic<int> g_force_slices{0};
 extern "C" void nadm_test_force_slices(int32_t n) { g_force_slices.store(n < 0 ? 0 : (n > NADM_MAX_P2_SLICES ? NADM_MAX_P2_SLICES : n)); }
+#endif
 
 extern "C" int32_t nadm_decode_slices(int32_t b, int64_t M, int32_t kp) {
     if (kp > 16 || b <= 0 || M <= 0) return 1;
     const int64_t chunks = (M + mf_chunk_snps(8) - 1) / mf_chunk_snps(8);
     const int tiles = (b + NADM_BF_TS - 1) / NADM_BF_TS;
-    int s = g_force_slices.load();
+    int s = 0;
+#ifdef NADM_TEST_HOOKS
+    s = g_force_slices.load();
+#endif
     if (s == 0) {
         // Measured (profiles/r05_ablations.txt item 11): below ~130k SNPs pass 2 is bound by the serial chain of ONE block -- its prologue
         // (P rows into operands, ~1.5 tile-times) + 13 tiles at b = 800 = 49 us whether 98 or 196 blocks run -- not by the chip; slices of

@@ -918,11 +918,12 @@ __device__ __forceinline__ void transpose4x4_bytes(const uint32_t (&in)[4], uint
 // with 512 (68 KB of LDS: two blocks per CU), 13.0 with 128 (32-byte reads).  The flip pass, when the data ask for it, 4.5 ms.
 constexpr int BT_SNPS = 512, BT_JD = 16, BT_PITCH = 33;       // SNPs per tile, dword columns of sample bytes per tile, LDS row pitch (dwords)
 __global__ __launch_bounds__(256) void bed_to_packed_kernel(const uint8_t* __restrict__ bed, int64_t N, int64_t M, int64_t nb,
-                                                            uint8_t* __restrict__ out, int64_t ld, unsigned long long* __restrict__ counts) {
+                                                            uint8_t* __restrict__ out, int64_t ld, unsigned long long* __restrict__ counts,
+                                                            int64_t tile_y0) {
     __shared__ uint32_t s_t[16 * BT_JD * BT_PITCH];            // row (s % 16) * 32 + s / 16 holds sample s of the tile: 32 dwords = 512 SNPs
     __shared__ unsigned int s_cnt[4];
     const int tid = threadIdx.x;
-    const int64_t m0 = (int64_t)blockIdx.y * BT_SNPS, jd0 = (int64_t)blockIdx.x * BT_JD;      // (sample tiles run fastest over the grid)
+    const int64_t m0 = (tile_y0 + blockIdx.y) * BT_SNPS, jd0 = (int64_t)blockIdx.x * BT_JD;      // (sample tiles run fastest over the grid)
     if (tid < 4) s_cnt[tid] = 0;
     unsigned int c1 = 0, c2 = 0, c3 = 0, cv = 0;
     for (int t = tid; t < (BT_SNPS / 16) * BT_JD; t += 256) {
@@ -1376,8 +1377,12 @@ extern "C" int nadm_bed_to_packed_dev(const uint8_t* bed_dev, int64_t N, int64_t
     if (hipMemsetAsync(counts_dev, 0, 4 * sizeof(uint64_t), st) != hipSuccess || hipMemsetAsync(flipped_dev, 0, sizeof(int32_t), st) != hipSuccess)
         return fail("nadm_bed_to_packed_dev: memset failed");
     // the tile grid covers ld bytes per row, so the row padding is written (as zeros) too
-    dim3 grid((unsigned)((nb + 4 * BT_JD - 1) / (4 * BT_JD)), (unsigned)((ld + BT_SNPS / 4 - 1) / (BT_SNPS / 4)));
-    hipLaunchKernelGGL(bed_to_packed_kernel, grid, dim3(256), 0, st, bed_dev, N, M, nb, out_dev, ld, (unsigned long long*)counts_dev);
+    const int64_t tiles_y = (ld + BT_SNPS / 4 - 1) / (BT_SNPS / 4);
+    for (int64_t y0 = 0; y0 < tiles_y; y0 += 65535) {         // grid.y limit: SNP tiles in chunks (33.5 M SNPs each; whole-genome call sets have more)
+        const int64_t ny = tiles_y - y0 < 65535 ? tiles_y - y0 : 65535;
+        dim3 grid((unsigned)((nb + 4 * BT_JD - 1) / (4 * BT_JD)), (unsigned)ny);
+        hipLaunchKernelGGL(bed_to_packed_kernel, grid, dim3(256), 0, st, bed_dev, N, M, nb, out_dev, ld, (unsigned long long*)counts_dev, y0);
+    }
     if (flip_if_mean_ge1) {
         const int64_t mp16 = ((M + 3) / 4 + 15) / 16;
         for (int64_t r0 = 0; r0 < N; r0 += 65535) {           // grid.y limit: rows in chunks
@@ -1415,8 +1420,12 @@ extern "C" int nadm_unpack2bit(const uint8_t* in_dev, uint8_t* out_dev, int64_t 
 }
 
 // test hook (nadm_test_force_generic_mlp): the generic kernels also where the register-resident ones apply
+#ifdef NADM_TEST_HOOKS          // the test build only (csrc/build.sh -> libnadm_testhooks.so)
 static int g_force_generic_mlp = 0;
 extern "C" void nadm_test_force_generic_mlp(int32_t on) { g_force_generic_mlp = on != 0; }
+#else
+constexpr int g_force_generic_mlp = 0;
+#endif
 
 static int mlp_fwd_impl(const nadm_heads_t* hd, const float* small, const float* zpart, int64_t n_chunks, int32_t b,
                         float* Z, float* rinv, float* Zn, float* H, float* Q, uint4* qimg, int64_t qimg_head_u4, void* stream) {

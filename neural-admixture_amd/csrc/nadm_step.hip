@@ -304,6 +304,7 @@ struct nadm_plan {
     int n_classes = 0;
     float sup_weight = 0.f;
     int64_t enc_chunks = 0, dec_chunks[NADM_MAX_HEADS] = {0}, loss_off[NADM_MAX_HEADS] = {0}, slab_off[NADM_MAX_HEADS] = {0}, n_loss = 0;
+    int32_t slices_cap[NADM_MAX_HEADS] = {0};       // sample slices the head's region of p2_slab was sized for (nadm_decode_slices_max at creation)
     uint32_t tmask = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trec[NADM_T_COUNT], trec_bkt[NADM_MAX_BUCKETS];
     std::vector<hipEvent_t> pool;
@@ -435,6 +436,8 @@ int decode_heads(nadm_plan* p, const int32_t* idx, int b, int with_loss, const f
         int rc;
         const void* qi = (d.qimg && kp <= 16) ? (const char*)d.qimg + (int64_t)h * d.qimg_head_bytes : nullptr;
         const int slices = d.p2_slab ? nadm_decode_slices(b, d.M, kp) : 1;     // sample slices where the SNP chunks alone leave CUs idle
+        if (slices > 1 && slices > p->slices_cap[h])                           // (the rule is a function of (b, M, kp); only the test build can move it)
+            return fail("nadm_step: pass 2 would be cut into more sample slices than the plan's slab was sized for at creation");
         if (slices > 1)
             rc = nadm_decode_bce_sliced(d.xp, d.ld, idx, b, d.M, Ph, kp, Qh, hd.SP, dPh, slab, lossp, flags, xg, adp, qi, slices,
                                         d.p2_slab + p->slab_off[h], d.p2_cnt + p->loss_off[h], st);
@@ -517,7 +520,8 @@ extern "C" int nadm_plan_create(const nadm_plan_desc_t* desc, nadm_plan_t** out)
         p->loss_off[h] = p->n_loss;                              // (= the head's offset into the slice counters as well)
         p->n_loss += p->dec_chunks[h];
         p->slab_off[h] = slab_floats;
-        slab_floats += nadm_decode_slab_floats(d.M, hd.kp[h], nadm_decode_slices_max(d.bmax, d.M, hd.kp[h]));
+        p->slices_cap[h] = nadm_decode_slices_max(d.bmax, d.M, hd.kp[h]);
+        slab_floats += nadm_decode_slab_floats(d.M, hd.kp[h], p->slices_cap[h]);
     }
     bool ok = true;
     auto stream_ok = [&](hipStream_t* s) { ok = ok && hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess; };

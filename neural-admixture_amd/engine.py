@@ -92,9 +92,10 @@ class Engine:
         self._iota = torch.arange(b, dtype=torch.int32, device=device) if tiled else None
         # pass 2 in sample slices (include/nadm.h, nadm_decode_bce_sliced): where the SNP chunks alone leave CUs idle (M below ~330k)
         # every slice parks its partial of dP in a slab; one region per head, one counter per chunk
-        self._p2_slab_off = [0]
+        self._p2_slab_off, self._p2_slices_cap = [0], []
         for kp in L.kp:
-            self._p2_slab_off.append(self._p2_slab_off[-1] + int(lib.nadm_decode_slab_floats(self.M, kp, int(lib.nadm_decode_slices_max(b, self.M, kp)))))
+            self._p2_slices_cap.append(int(lib.nadm_decode_slices_max(b, self.M, kp)))
+            self._p2_slab_off.append(self._p2_slab_off[-1] + int(lib.nadm_decode_slab_floats(self.M, kp, self._p2_slices_cap[-1])))
         self._p2_slab = z(self._p2_slab_off[-1]) if gpu and self._p2_slab_off[-1] else None
         self._p2_cnt = torch.zeros(L.n_loss, dtype=torch.int32, device=device) if self._p2_slab is not None else None
         # validity of the three by-products for the plain phases below (the plan's own step always produces what it consumes)
@@ -395,6 +396,8 @@ class Engine:
             xg = ptr(self._xg) if (h == 0 and self._xg is not None) else None     # head 0's launch leaves the batch copy for pass 3
             qi = C.c_void_p(self.qimg.data_ptr() + h * self._qimg_head) if (self.qimg is not None and self._qimg_b == b and kp <= 16) else None
             slices = int(lib.nadm_decode_slices(b, L.M, kp)) if self._p2_slab is not None else 1
+            if slices > self._p2_slices_cap[h]:
+                raise RuntimeError("pass 2 would be cut into more sample slices than this engine's slab was sized for")
             if slices > 1:                                                        # the library's cut of the batch, as in the step
                 check(lib.nadm_decode_bce_sliced(*args, xg, None, qi, slices, C.c_void_p(self._p2_slab.data_ptr() + self._p2_slab_off[h] * fsz),
                                                  C.c_void_p(self._p2_cnt.data_ptr() + loss_offs[h] * 4), st), "decode_bce_sliced")

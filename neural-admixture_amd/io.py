@@ -97,6 +97,7 @@ def _file_to_device(path, offset: int, n_bytes: int, device: torch.device, chunk
     ring = [torch.empty(min(chunk, max(n_bytes, 1)), dtype=torch.uint8).pin_memory() for _ in range(2)]
     done = [None, None]
     stream = torch.cuda.Stream(device)
+    stream.wait_stream(torch.cuda.current_stream(device))  # `out` may be a recycled block whose last use is still queued on the caller's stream
     with open(path, "rb", buffering=0) as f:
         f.seek(offset)
         pos, i = 0, 0

@@ -114,7 +114,7 @@ def gram64(A: torch.Tensor, chunk: int = 32768) -> torch.Tensor:
     return G
 
 
-def _omega_to_device(rng, M: int, kp: int, device: torch.device, chunk: int = 32768) -> torch.Tensor:
+def _omega_to_device(rng, M: int, kp: int, device: torch.device, chunk: int = 32768, after=None) -> torch.Tensor:
     """Omega [M, k'] ~ N(0, 1) float32 from the reference's own stream (``rng.standard_normal(size=(M, kp), dtype=float32)``,
     src/svd.py:47-48) straight into HBM: generated ``chunk`` rows at a time into two small pinned buffers that are copied while the
     next chunk is drawn.  Chunked draws continue the generator's stream exactly (checked by tests/test_abi_and_host.py); what
@@ -124,6 +124,8 @@ def _omega_to_device(rng, M: int, kp: int, device: torch.device, chunk: int = 32
     ring = [torch.empty((min(chunk, M), kp), dtype=torch.float32).pin_memory() for _ in range(2)]
     done = [None, None]
     with torch.cuda.device(device):
+        if after is not None:                                # called on a helper thread (its own current stream): `out` may be a recycled block
+            torch.cuda.current_stream().wait_stream(after)   # whose last use is still queued on the caller's stream
         for i, s in enumerate(range(0, M, chunk)):
             e = min(M, s + chunk)
             if done[i & 1] is not None:
@@ -184,10 +186,11 @@ def RSVD(A_uint8, N: int, M: int, k: int = 8, seed: int = 42, oversampling: int 
             # the draw is the longest single item of the GPU path
             import threading
             box = {}
+            caller_stream = torch.cuda.current_stream(device)
 
             def _draw():
                 try:
-                    box["omega"] = _omega_to_device(rng, M, kp, device)
+                    box["omega"] = _omega_to_device(rng, M, kp, device, after=caller_stream)
                 except BaseException as e:                   # re-raised on the caller's thread
                     box["error"] = e
             th = threading.Thread(target=_draw, name="nadm-rsvd-omega")

@@ -82,7 +82,9 @@ def gmm_p_init(data_np, V_CM: np.ndarray, K: Optional[int], min_k, max_k, n_comp
         from .gmm import fit_means as fit_means_host
         if len(ks) > 1:
             from concurrent.futures import ThreadPoolExecutor     # (the C call releases the GIL; each fit runs its restarts on threads of its own)
-            with ThreadPoolExecutor(max_workers=len(ks)) as pool:
+            # (each fit sizes its restart x worker threads for the whole host, csrc/nadm_gmm.cpp: two at a time keep K = 2..10 from
+            # putting several hundred spinning threads on it -- ADVICE r05)
+            with ThreadPoolExecutor(max_workers=min(2, len(ks))) as pool:
                 means = list(pool.map(lambda k_: fit_means_host(X_pca, k_, seed), ks))
         else:
             means = [fit_means_host(X_pca, ks[0], seed)]
@@ -181,18 +183,19 @@ def capped_host_threads(limit: int = 4):
 
 def train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int, data: torch.Tensor, device: torch.device,
           num_gpus: int, hidden_size: int, master: bool, V: np.ndarray, pops, min_k: int = None, max_k: int = None,
-          n_components: int = None, *, parallelism: str = "dp", host_threads: int = 4):
+          n_components: int = None, *, parallelism: str = "dp", host_threads: int = 4, gmm: str = "auto"):
     """The reference's boundary function (see the module docstring and _train).  The host thread pools (torch intra-op, BLAS,
     OpenMP) are capped at ``host_threads`` while it runs -- the reference's CLI does that with --threads (entry.py:138-146), and
-    this package's CLI passes its --threads here; the epoch loop itself always runs with torch's pool at 1 (model.py)."""
+    this package's CLI passes its --threads here; the epoch loop itself always runs with torch's pool at 1 (model.py).
+    ``gmm`` (keyword, CLI --gmm): who fits the decoder-init mixture (gmm_p_init's ``fit``): "sklearn" is the reference's own call."""
     with capped_host_threads(max(1, int(host_threads))):
         return _train(epochs, batch_size, learning_rate, K, seed, data, device, num_gpus, hidden_size, master, V, pops, min_k, max_k,
-                      n_components, parallelism=parallelism)
+                      n_components, parallelism=parallelism, gmm=gmm)
 
 
 def _train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int, data: torch.Tensor, device: torch.device,
            num_gpus: int, hidden_size: int, master: bool, V: np.ndarray, pops, min_k: int = None, max_k: int = None,
-           n_components: int = None, *, parallelism: str = "dp"):
+           n_components: int = None, *, parallelism: str = "dp", gmm: str = "auto"):
     """See module docstring.  ``data`` uint8 [N,M] CPU tensor (or an ``io.PackedGenotypes``, e.g. from
     ``io.read_bed_packed``); ``V`` numpy [C,M] (RSVD output,
     svd.py:83); returns Ps (list of [M,k] float32), Qs (list of [N,k] float32), model.
@@ -211,7 +214,7 @@ def _train(epochs: int, batch_size: int, learning_rate: float, K: int, seed: int
         log.info("")
         log.info("    Running Gaussian Mixture in PCA subspace...")
         log.info("")
-        P = gmm_p_init(data if hasattr(data, "unpack_rows") else data.numpy(), V, K, min_k, max_k, n_components, seed, device)
+        P = gmm_p_init(data if hasattr(data, "unpack_rows") else data.numpy(), V, K, min_k, max_k, n_components, seed, device, fit=gmm)
     elif master:
         log.info("")
         log.info("    Running Supervised Mode...")

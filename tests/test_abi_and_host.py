@@ -21,13 +21,20 @@ def test_library_exports_every_declared_symbol():
     from neural_admixture_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "nadm.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    hooks = set(re.findall(r"\b(nadm_[a-z0-9_]+)\s*\(", "".join(re.findall(r"#ifdef NADM_TEST_HOOKS.*?#endif", hdr, flags=re.S))))
+    hdr = re.sub(r"#ifdef NADM_TEST_HOOKS.*?#endif", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(nadm_[a-z0-9_]+)\s*\(", hdr))
-    assert len(declared) >= 17
-    raw = C.CDLL(_lib.LIB_PATH)
+    assert len(declared) >= 17 and hooks == {"nadm_test_force_slices", "nadm_test_force_generic_mlp"}
+    from conftest import HOOK_LIB
+    product = os.path.join(ROOT, "neural-admixture_amd", "csrc", "libnadm.so")
+    raw, test_build = C.CDLL(product), C.CDLL(HOOK_LIB)
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in nadm.h but not exported"
+        assert hasattr(test_build, name)
+    for name in hooks:                                   # the laboratory is not in the product
+        assert not hasattr(raw, name) and hasattr(test_build, name)
     assert declared == set(_lib.EXPORTS)               # the Python binding covers the whole header
-    assert _lib.lib.nadm_abi_version() == 11
+    assert _lib.lib.nadm_abi_version() == 12
 
 
 def test_argument_validation_without_gpu():
@@ -115,6 +122,13 @@ def test_pass2_sample_slice_rule_and_slab_sizes():
                 assert 1 <= s_ <= mx and (s_ == 1 or (s_ - 1) * ((tiles + s_ - 1) // s_) < tiles)      # no empty slice
     chunks = lib.nadm_decode_chunks(50_000, 8)
     assert lib.nadm_decode_slab_floats(50_000, 8, 3) == 3 * chunks * (256 * 8 + 4) and lib.nadm_decode_slab_floats(50_000, 8, 1) == 0
+
+
+def test_force_hook_of_the_test_build_overrides_the_slice_rule(request):
+    from conftest import in_hook_build
+    if not in_hook_build(request):
+        return
+    from neural_admixture_amd._lib import lib
     try:
         lib.nadm_test_force_slices(4)
         assert lib.nadm_decode_slices(800, 500_000, 8) == 4 and lib.nadm_decode_slices(100, 500_000, 8) == 2 and lib.nadm_decode_slices(800, 500_000, 32) == 1

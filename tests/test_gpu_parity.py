@@ -317,9 +317,12 @@ def test_step_with_mostly_missing_genotypes_and_an_all_missing_sample():
     assert mx(e.Z.cpu().numpy()[: N * 8].reshape(N, 8)[5], 0 * aux["Z"][5]) == 0          # the all-missing sample projects to exactly 0
 
 
-def test_fast_and_generic_mlp_kernels_agree():
+def test_fast_and_generic_mlp_kernels_agree(request):
     """nadm_mlp_fwd / nadm_mlp_bwd pick register-resident kernels for Hd <= 2048, C <= 8 and the generic ones otherwise
-    (the test hook nadm_test_force_generic_mlp forces the latter): same outputs up to the summation order over the hidden dimension."""
+    (the test hook nadm_test_force_generic_mlp -- test build only -- forces the latter): same outputs up to the summation order over the hidden dimension."""
+    from conftest import in_hook_build
+    if not in_hook_build(request):
+        return
     from neural_admixture_amd._lib import lib
     rng = np.random.default_rng(21)
     for Hd, ks in ((1024, [8]), (1536, [2, 3, 4, 5]), (96, [11])):
@@ -1423,11 +1426,15 @@ def test_mixture_fit_with_the_sums_on_the_device_equals_the_host_form_and_the_li
 
 
 @pytest.mark.parametrize("ks,b,M", [([8], 800, 6200), ([5], 333, 3000), ([12], 400, 2301), ([3, 9], 800, 5000)])
-def test_pass2_in_sample_slices_gives_the_unsliced_gradients_and_is_reproducible(ks, b, M):
+def test_pass2_in_sample_slices_gives_the_unsliced_gradients_and_is_reproducible(request, ks, b, M):
     """nadm_decode_bce_sliced (the batch's sample tiles dealt to S blocks per SNP chunk, the partial dP sums added by the block counted
     last): against the S = 1 kernel on the same inputs -- dQ-driven gradients and dP equal to rounding (the sum over the slices has an
     order of its own), the loss value to 1e-6 -- for S = 2, 3, 4 and the library's own choice; the same bits call after call; counters
-    back at zero; the fused step (Adam in the last block's epilogue) against the unsliced step after three steps; ragged batches."""
+    back at zero; the fused step (Adam in the last block's epilogue) against the unsliced step after three steps; ragged batches.
+    (Forcing S needs the test build of the library: conftest.in_hook_build.)"""
+    from conftest import in_hook_build
+    if not in_hook_build(request):
+        return
     from neural_admixture_amd._lib import lib
     N = max(b + 40, 200)
     Gm = O.synth_genotypes(N, M, max(ks), seed=31)
