@@ -416,6 +416,24 @@ def case_c2_trajectory():
     np.savez_compressed(os.path.join(OUT, "c2_trajectory.npz"), **out)
 
 
+def case_c2_trajectory_warm():
+    """As case_c2_trajectory, from a start inside the regime a real run trains in (seeded_inputs.warm_v_p: P near the true
+    frequencies, V spanning the signal directions), reproducible on both sides to the bit -- the engine alone in the mixture-init
+    regime, where c2_end_to_end also carries the (irreproducible) noise component of the RSVD."""
+    SI, G = _c2_matrix()
+    V0, P0 = SI.warm_v_p(C2["N"], C2["M"], C2["K"], C2["C"], C2["seed"])
+    out = dict(sha_G=SI.sha(G), sha_V0=SI.sha(V0), sha_P0=SI.sha(P0), **{k: v for k, v in C2.items()})
+    for mode in ("hi", "med"):
+        Qs, Ps, sd, sl = run_reference_training(G, V0, P0, C2["K"], None, None, C2["Hd"], C2["epochs"], C2["b"], C2["lr"],
+                                                C2["run_seed"], mode)
+        out[f"{mode}_Q"], out[f"{mode}_losses"] = Qs[0], sl
+        _sampled(SI, out, mode, Ps[0], sd["V"])
+        out[f"{mode}_loglik"] = np.float64(ref_cy.loglikelihood(G, np.ascontiguousarray(Ps[0].astype(np.float64)),
+                                                                np.ascontiguousarray(Qs[0].astype(np.float64)), C2["K"]))
+        print("c2 trajectory warm", mode, sl[:4], sl[-1], out[f"{mode}_loglik"], flush=True)
+    np.savez_compressed(os.path.join(OUT, "c2_trajectory_warm.npz"), **out)
+
+
 def case_c2_end_to_end():
     """The whole default pipeline on the same matrix: the reference's RSVD (src/svd.py:39-83), then its train()
     (model/train.py:19-149: PCA projection, GaussianMixture, launch_training, log-likelihood), 5 epochs.  Kept: a sample of Vt,
@@ -465,6 +483,35 @@ def case_c2_end_to_end():
     np.savez_compressed(os.path.join(OUT, "c2_end_to_end.npz"), **out)
 
 
+def case_c2_end_to_end_t4():
+    """The yardstick of c2_end_to_end: the SAME reference run ('hi', true fp32) with torch's intra-op pool at 4 threads instead of 8 --
+    nothing changes but the summation order inside the reference's own fp32 operators (RSVD, projection and mixture fit are computed
+    exactly as in case_c2_end_to_end: they do not run on torch's pool).  From the mixture init the run sits where Adam turns rounding-level
+    differences of near-zero gradients into steps of +-lr, so two fp32 evaluations of the reference drift apart; the distance between
+    them is what any other fp32 implementation can be held to."""
+    from neural_admixture.model import train as ref_train_mod
+    SI, G = _c2_matrix()
+    ref_utils.set_seed(C2["run_seed"])
+    Vt = RSVD(G, C2["N"], C2["M"], C2["C"], C2["run_seed"])
+    e2e = np.load(os.path.join(OUT, "c2_end_to_end.npz"))
+    rows = SI.sample_rows(C2["M"], C2["nrows"], C2["seed"])
+    assert np.array_equal(Vt[:, rows].astype(np.float32), e2e["Vt_rows"])           # the same V as the 8-thread fixture
+    out = dict(sha_G=SI.sha(G), threads=4)
+    torch.set_num_threads(4)
+    try:
+        with precision("hi"):
+            torch.manual_seed(C2["run_seed"])
+            Ps, Qs, model = ref_train_mod.train(C2["epochs"], C2["b"], C2["lr"], C2["K"], C2["run_seed"], torch.tensor(G),
+                                                torch.device("cpu"), 0, C2["Hd"], True, Vt.copy(), None, None, None, C2["C"])
+    finally:
+        torch.set_num_threads(8)
+    out["hi_Q"] = Qs[0]
+    _sampled(SI, out, "hi", Ps[0], state_np(model)["V"])
+    print("c2 end-to-end, 4 threads vs 8: max |dQ|", np.abs(Qs[0] - e2e["hi_Q"]).max(), "mean", np.abs(Qs[0] - e2e["hi_Q"]).mean(),
+          "max |dP|", np.abs(out["hi_P_rows"] - e2e["hi_P_rows"]).max(), "max |dV|", np.abs(out["hi_V_rows"] - e2e["hi_V_rows"]).max(), flush=True)
+    np.savez_compressed(os.path.join(OUT, "c2_end_to_end_t4.npz"), **out)
+
+
 def case_c2_multihead():
     """configs[2] at full width: one epoch (4 steps) of ks = 2..10 on the same matrix from a seeded V0 / P0 [54, M], 'hi'."""
     SI, G = _c2_matrix()
@@ -508,7 +555,9 @@ if __name__ == "__main__":
         "one_step_k9": lambda: one_step_case("one_step_k9", 64, 509, [9], 64, 8, seed=12),
         # r06: configs[1] / configs[2] at full width against the reference itself (minutes each; inputs regenerated from a seed)
         "c2_trajectory": case_c2_trajectory,
+        "c2_trajectory_warm": case_c2_trajectory_warm,
         "c2_end_to_end": case_c2_end_to_end,
+        "c2_end_to_end_t4": case_c2_end_to_end_t4,
         "c2_multihead": case_c2_multihead,
     }
     for name in (sys.argv[1:] or list(cases)):            # no arguments: every fixture; else only the named cases

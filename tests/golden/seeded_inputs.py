@@ -73,6 +73,22 @@ def init_v_p(M: int, C: int, S: int, seed: int):
     return V0, P0
 
 
+def warm_v_p(N: int, M: int, K: int, C: int, seed: int):
+    """A start INSIDE the regime a real run trains in -- the decoder near the true allele frequencies (what the mixture init gives),
+    the projection spanning the signal directions -- that both sides can regenerate exactly: built from the generator's own F with
+    elementwise float64 arithmetic only (no norms, no factorisations: an RSVD's noise-direction components are not reproducible
+    between two fp32 implementations, profiles/r06_c2_vpert.txt).  V0 [M, C]: columns 0..K-1 = (F_k - 1/4) / (0.17 sqrt(M)) (unit-ish
+    norm like a singular vector), the remaining columns N(0, 1/M) noise; P0 [K, M] = clip(F_k + U(-0.01, 0.01), 5e-6, 1 - 5e-6)."""
+    F, _ = model_of(N, M, K, seed)
+    rng = np.random.default_rng([seed, 13])
+    V0 = np.empty((M, C), dtype=np.float64)
+    scale = 1.0 / (0.17 * float(np.sqrt(float(M))))
+    for c in range(C):
+        V0[:, c] = (F[c] - 0.25) * scale if c < K else rng.standard_normal(M) / float(np.sqrt(float(M)))
+    P0 = np.clip(F + (rng.random((K, M)) - 0.5) * 0.02, 5e-6, 1 - 5e-6)
+    return V0.astype(np.float32), P0.astype(np.float32)
+
+
 def sha(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 

@@ -50,13 +50,18 @@ def _trainer(ks, epochs, b, lr, run_seed, **kw):
                               None if single else ks[0], None if single else ks[-1], **kw)
 
 
-def test_c2_trajectory_20_steps_against_the_reference(c2_matrix):
+@pytest.mark.parametrize("start", ["cold", "warm"])
+def test_c2_trajectory_20_steps_against_the_reference(c2_matrix, start):
     """The production trainer (launch_training on the HIP engine) from the fixture's seeded V0 / P0 for 5 epochs of 800/800/800/104
-    rows -- the reference's launch_training (model/neural_admixture.py:324-392) on the same matrix, same start, same sampler."""
+    rows -- the reference's launch_training (model/neural_admixture.py:324-392) on the same matrix, same start, same sampler.
+    "cold": V0 ~ N(0, 1/M), P0 ~ U(0.05, 0.95) (c2_trajectory.npz); "warm": a start inside the regime a real run trains in -- P near the
+    true allele frequencies, V spanning the signal directions (seeded_inputs.warm_v_p, c2_trajectory_warm.npz): the engine alone where
+    c2_end_to_end also carries the RSVD's irreproducible noise component."""
     from neural_admixture_amd.report import loglikelihood_packed
-    d = np.load(f"{GOLD}/c2_trajectory.npz")
+    d = np.load(f"{GOLD}/c2_trajectory.npz" if start == "cold" else f"{GOLD}/c2_trajectory_warm.npz")
     N, M, K, C = int(d["N"]), int(d["M"]), int(d["K"]), int(d["C"])
-    V0, P0 = SI.init_v_p(M, C, K, int(d["seed"]))
+    assert str(d["sha_G"]) == SI.sha(c2_matrix.numpy())
+    V0, P0 = SI.init_v_p(M, C, K, int(d["seed"])) if start == "cold" else SI.warm_v_p(N, M, K, C, int(d["seed"]))
     assert SI.sha(V0) == str(d["sha_V0"]) and SI.sha(P0) == str(d["sha_P0"])
     tr = _trainer([K], int(d["epochs"]), int(d["b"]), float(d["lr"]), int(d["run_seed"]), loss_mode="steps")
     Qs, Ps, model = tr.launch_training(torch.from_numpy(P0), c2_matrix, int(d["Hd"]), C, torch.from_numpy(V0), M, N, None)
@@ -67,12 +72,13 @@ def test_c2_trajectory_20_steps_against_the_reference(c2_matrix):
     rel_loss = np.abs(got - d["hi_losses"]) / d["hi_losses"]
     dq, dp = mx(Qs[0], d["hi_Q"]), mx(Ps[0][rows], d["hi_P_rows"])
     dv = mx(V[rows], d["hi_V_rows"])
-    print(f"c2 trajectory: loss rel max {rel_loss.max():.2e}, dQ {dq:.2e} (ref hi-med {mx(d['med_Q'], d['hi_Q']):.2e}), "
+    print(f"c2 trajectory [{start}]: loss rel max {rel_loss.max():.2e}, dQ {dq:.2e} (ref hi-med {mx(d['med_Q'], d['hi_Q']):.2e}), "
           f"dP {dp:.2e} (ref {mx(d['med_P_rows'], d['hi_P_rows']):.2e}), dV {dv:.2e} (ref {mx(d['med_V_rows'], d['hi_V_rows']):.2e})")
     assert rel_loss.max() < 5e-5
     assert dq < 2e-3 and dp < 1e-2
-    # measured (r06): loss 1.0e-7, dQ 2.5e-7, dP 1.8e-7, dV 7.9e-6 -- the HIP path IS the reference's fp32 run at this width; hold it near there
-    assert rel_loss.max() < 2e-6 and dq < 2e-5 and dp < 2e-5 and dv < 2e-4
+    # measured (r06, cold): loss 1.0e-7, dQ 2.5e-7, dP 1.8e-7, dV 7.9e-6 -- the HIP path IS the reference's fp32 run at this width; hold it near there
+    if start == "cold":
+        assert rel_loss.max() < 2e-6 and dq < 2e-5 and dp < 2e-5 and dv < 2e-4
     assert dq < mx(d["med_Q"], d["hi_Q"]) and dp < mx(d["med_P_rows"], d["hi_P_rows"])      # closer to fp32 than the reference's bf16 run
     assert dv <= mx(d["med_V_rows"], d["hi_V_rows"])
     assert np.allclose(Ps[0].astype(np.float64).sum(0), d["hi_P_colsum"], rtol=2e-5)          # all 600k rows, not only the sampled ones
@@ -83,7 +89,7 @@ def test_c2_trajectory_20_steps_against_the_reference(c2_matrix):
 
 
 @pytest.mark.parametrize("fit", ["auto", "sklearn"])
-def test_c2_end_to_end_from_raw_genotypes_against_the_reference(c2_matrix, fit):
+def test_c2_end_to_end_from_raw_genotypes_against_the_reference(c2_matrix, fit, caplog):
     """RSVD + mixture fit + train() + log-likelihood from the raw matrix: neural_admixture_amd.svd.RSVD and
     neural_admixture_amd.train against the reference's RSVD (src/svd.py:39-83) and train() (model/train.py:19-149) -- with the SAME
     ancestry-column order: no permutation matching.  ``fit``: the default decoder init (the mixture fit restated, csrc/nadm_gmm*)
@@ -101,25 +107,30 @@ def test_c2_end_to_end_from_raw_genotypes_against_the_reference(c2_matrix, fit):
     # (sigma_8 ~ sigma_9): compare the subspace-independent part tightly and the last row loosely
     dvt = np.abs(Vt[:, rows] - d["Vt_rows"]).max(1)
     print("c2 end-to-end: |dVt| per component", np.array2string(dvt, precision=2))
-    records = []
-
-    class H(logging.Handler):
-        def emit(self, r):
-            records.append(r.getMessage())
-    h = H()
-    logging.getLogger("neural_admixture_amd.train").addHandler(h)
-    try:
+    with caplog.at_level(logging.INFO):
         Ps, Qs, model = na.train(int(d["epochs"]), int(d["b"]), float(d["lr"]), K, int(d["run_seed"]), c2_matrix, dev, 1, int(d["Hd"]),
                                  True, Vt, None, None, None, C, gmm=fit)
-    finally:
-        logging.getLogger("neural_admixture_amd.train").removeHandler(h)
+    records = [r.getMessage() for r in caplog.records]
     dq, dp = mx(Qs[0], d["hi_Q"]), mx(Ps[0][rows], d["hi_P_rows"])
     ll = [float(m.split(":")[1].strip().rstrip(".")) for m in records if "Log-likelihood" in m]
     print(f"c2 end-to-end [{fit}]: dQ {dq:.2e} (ref hi-med {mx(d['med_Q'], d['hi_Q']):.2e}), dP {dp:.2e} "
           f"(ref {mx(d['med_P_rows'], d['hi_P_rows']):.2e}), loglik {ll} vs {float(d['hi_loglik'])}")
-    assert dvt[:K].max() < 5e-5
-    assert dq < 2e-3 and dp < 1e-2                       # the same column order as the reference: nothing is permuted here
+    # RSVD: the seven data-determined right-singular vectors to 1e-8; the eighth lies in the sketch's noise bulk (sigma_8 ~ sigma_9) and is
+    # as far from the reference's as any two fp32 evaluations of it are (measured 2.7e-6 max-abs, 2e-3 of its entries' size)
+    assert dvt[:K].max() < 5e-8 and dvt[K:].max() < 2e-5
+    # ... and that one component is what the end-to-end distance is made of (profiles/r06_c2_vpert.txt: the HIP run's own Q moves by
+    # 3.5e-2 under a random perturbation of that size there, by 3e-7 under 1e-8 on a signal component; the reference's fp32 run is
+    # stable to 4e-7 under a change of its summation order, c2_end_to_end_t4.npz; from reproducible starts the engine tracks the
+    # reference to 1e-6, test_c2_trajectory...).  Held to SURVEY 8c's end-of-run bounds and to being closer to the reference's fp32 run
+    # than its own bf16 run is -- in the reference's column order: nothing is permuted here.
+    mean_dq, ref_mean = float(np.abs(Qs[0] - d["hi_Q"]).mean()), float(np.abs(d["med_Q"] - d["hi_Q"]).mean())
+    assert dq < mx(d["med_Q"], d["hi_Q"]) and mean_dq < ref_mean and mean_dq < 1e-2
+    assert dp < 1e-2 and dp < mx(d["med_P_rows"], d["hi_P_rows"])
+    assert np.allclose(Ps[0].astype(np.float64).sum(0), d["hi_P_colsum"], rtol=1e-4)
     assert len(ll) == 1 and abs(ll[0] - float(d["hi_loglik"])) / abs(float(d["hi_loglik"])) < 1e-4
+    assert abs(ll[0] - float(d["hi_loglik"])) < abs(float(d["med_loglik"]) - float(d["hi_loglik"]))
+    t4 = np.load(f"{GOLD}/c2_end_to_end_t4.npz")            # the yardstick's own pin: the reference's fp32 run does not move with its thread count
+    assert mx(t4["hi_Q"], d["hi_Q"]) < 2e-6 and mx(t4["hi_P_rows"], d["hi_P_rows"]) < 2e-6
 
 
 def test_c2_multihead_epoch_against_the_reference(c2_matrix):
@@ -139,5 +150,6 @@ def test_c2_multihead_epoch_against_the_reference(c2_matrix):
     worst_p = max(mx(Ps[h][rows], d[f"hi_P{h}_rows"]) for h in range(len(ks)))
     print(f"c2 multihead: loss rel max {rel_loss.max():.2e}, dQ {worst_q:.2e}, dP {worst_p:.2e}")
     assert rel_loss.max() < 5e-5 and worst_q < 2e-3 and worst_p < 1e-2
+    assert rel_loss.max() < 2e-6 and worst_q < 2e-4 and worst_p < 2e-5          # measured (r06): 1.5e-7, 9.2e-6, 7.5e-7
     for h in range(len(ks)):
         assert np.allclose(Ps[h].astype(np.float64).sum(0), d[f"hi_P{h}_colsum"], rtol=2e-5)
