@@ -98,7 +98,9 @@ def parse():
                          "(RCCL refuses two ranks per device); not a measurement")
     ap.add_argument("--alt", action="store_true", help="run the alternative multi-GPU legs + the collective micro-benchmark behind the headline (default at N > 1)")
     ap.add_argument("--no-alt", action="store_true", help="N > 1: only the headline")
-    ap.add_argument("--alt-steps", type=int, default=50, help="timed steps of every alternative leg (after 10 warm-up steps)")
+    ap.add_argument("--alt-steps", type=int, default=50, help="timed steps of every alternative leg")
+    ap.add_argument("--alt-warmup", type=int, default=10, help="untimed steps in front of every alternative leg")
+    ap.add_argument("--coll-reps", type=int, default=20, help="timed repetitions of every collective of the micro-benchmark")
     ap.add_argument("--no-epoch-loop", action="store_true", help="skip the production epoch loop behind the timed region (profiling passes: only the K-step kernels)")
     ap.add_argument("--cpu-rows", type=int, default=2400, help="rows of the same workload used for the bounded CPU baseline")
     ap.add_argument("--cpu-steps", type=int, default=12, help="timed steps of the CPU baseline (min / median / max reported)")
@@ -346,6 +348,34 @@ def collectives_bench(comm, lay, dev, world, reps=20):
     return out
 
 
+def validate_line(d, world):
+    """Problems (strings) with a bench JSON line as the driver / a reader needs it; empty = fine.  With several ranks (or --alt) every
+    alternative leg and every collective of the micro-benchmark must be there with a positive time."""
+    bad = []
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "box"):
+        if k not in d:
+            bad.append(f"missing {k}")
+    if d.get("n_gpus") != world:
+        bad.append(f"n_gpus {d.get('n_gpus')} != {world}")
+    if not (isinstance(d.get("value"), (int, float)) and d["value"] > 0 and d.get("ms_per_step", 0) > 0):
+        bad.append("value / ms_per_step not positive")
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        if k not in (d.get("roofline") or {}):
+            bad.append(f"roofline.{k} missing")
+    if world > 1 or "alt" in d:
+        alt, coll = d.get("alt") or {}, d.get("collectives") or {}
+        for leg in ALT_LEGS:
+            v = alt.get(leg)
+            if not v or not (v.get("ms_per_step", 0) > 0 and v.get("value", 0) > 0 and v.get("global_batch", 0) > 0):
+                bad.append(f"alt.{leg} missing or empty")
+        for c in ALT_COLLECTIVES:
+            v = coll.get(c)
+            if not v or not (v.get("us", 0) > 0 and v.get("bytes", 0) > 0 and "bus_gbs" in v):
+                bad.append(f"collectives.{c} missing or empty")
+    return bad
+
+
 def bench_params(M, S):
     rng = np.random.default_rng(42)                                     # identical parameters on every rank
     V0 = (0.01 * rng.standard_normal((M, 8))).astype(np.float32)
@@ -362,7 +392,7 @@ def alt_legs(args, eng, comm, dev, world, rank, ks, headline):
     from neural_admixture_amd.model import init_encoder_weights
     from neural_admixture_amd.snp_parallel import SnpShardedEngine
     M, S, K, lr, with_loss = args.snps, sum(ks), max(ks), 2e-3, not args.no_loss
-    steps, warm = max(1, args.alt_steps), 10
+    steps, warm = max(1, args.alt_steps), max(0, args.alt_warmup)
     if comm is None:                                                    # one GPU, plain step in the headline: a 1-rank communicator for the legs
         comm = nacomm.torch_comm(rank, world) if args.share_gpu else nacomm.make_comm(dev, rank, world)
     mk_comm = (lambda: nacomm.torch_comm(rank, world)) if args.share_gpu else (lambda: nacomm.make_comm(dev, rank, world))
@@ -402,7 +432,7 @@ def alt_legs(args, eng, comm, dev, world, rank, ks, headline):
     ca = mk_comm()
     e3 = dp_engine(comm_a=ca)
     run("dp_comm_a", e3, args.batch, args.batch * world * M, seq, "a second communicator for message A = [all P]: A and B share the links instead of queueing")
-    coll = collectives_bench(comm, eng.lay if eng.mode == "dp" else e3.lay, dev, world)
+    coll = collectives_bench(comm, eng.lay if eng.mode == "dp" else e3.lay, dev, world, reps=max(1, args.coll_reps))
     del e3
     ca.close()
     torch.cuda.empty_cache()
@@ -749,6 +779,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline and len(ks) == 1 and args.emulate_world is None:
             out["cpu_baseline"] = cpu_baseline(eng, args, dev)
             out["cpu_baseline_reference_shaped"] = cpu_baseline_reference_shaped(eng, args, dev)
+        problems = validate_line(out, world)
+        if problems:
+            print(f"[bench] incomplete line: {problems}", file=sys.stderr)
         print(json.dumps(out))
         sys.stdout.flush()
     if hang_guard is not None:
