@@ -42,7 +42,7 @@ extern "C" {
 #define NADM_MAX_K 64
 #define NADM_MAX_BUCKETS 8
 #define NADM_MAX_P2_SLICES 8   /* sample slices of pass 2 (nadm_decode_bce_sliced) */
-#define NADM_ABI_VERSION 12  /* 12: nadm_test_force_slices / nadm_test_force_generic_mlp exist in the test build only (-DNADM_TEST_HOOKS), nadm_calib_clock / nadm_wall_clock_khz; 11: nadm_gmm_fit_means_dev, nadm_loglik_blocks counts 8 row slices per 1024-SNP block, nadm_decode_bce_sliced / nadm_decode_slices / nadm_decode_slab_floats / nadm_test_force_slices + nadm_plan_desc_t.p2_slab / p2_cnt (pass 2 in sample slices when the SNP chunks alone do not fill the chip); 10: message B of the sample-sharded step in SNP-range buckets (nadm_flat_layout takes n_buckets, nadm_flat_layout_t.bkt_*, nadm_plan_desc_t.n_buckets / p3_whole / comm_a / debug, nadm_encode_fwd_part, nadm_plan_bucket_ms), nadm_comm_t.async_error, nadm_comm_rccl_probe, nadm_comm_rccl with a watchdog (timeout_ms), a failed step poisons its plan; 9: nadm_step / nadm_plan_* / nadm_comm_* / nadm_flat_layout (the step as one call, sharded optimizer), nadm_test_force_generic_mlp; 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
+#define NADM_ABI_VERSION 13  /* 13: pass 3 in sample slices (nadm_encode_bwd_sliced, nadm_encode_slices(_max), nadm_encode_slab_floats, nadm_encode_bwd_chunks, nadm_plan_desc_t.p3_slab / p3_cnt); 12: nadm_test_force_slices / nadm_test_force_generic_mlp exist in the test build only (-DNADM_TEST_HOOKS), nadm_calib_clock / nadm_wall_clock_khz; 11: nadm_gmm_fit_means_dev, nadm_loglik_blocks counts 8 row slices per 1024-SNP block, nadm_decode_bce_sliced / nadm_decode_slices / nadm_decode_slab_floats / nadm_test_force_slices + nadm_plan_desc_t.p2_slab / p2_cnt (pass 2 in sample slices when the SNP chunks alone do not fill the chip); 10: message B of the sample-sharded step in SNP-range buckets (nadm_flat_layout takes n_buckets, nadm_flat_layout_t.bkt_*, nadm_plan_desc_t.n_buckets / p3_whole / comm_a / debug, nadm_encode_fwd_part, nadm_plan_bucket_ms), nadm_comm_t.async_error, nadm_comm_rccl_probe, nadm_comm_rccl with a watchdog (timeout_ms), a failed step poisons its plan; 9: nadm_step / nadm_plan_* / nadm_comm_* / nadm_flat_layout (the step as one call, sharded optimizer), nadm_test_force_generic_mlp; 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
@@ -226,6 +226,22 @@ typedef struct {
 int nadm_encode_bwd_step(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                          const float* dZ, const void* dzimg, int32_t CP, float* V, float* dV, const nadm_adam_t* adam,
                          const nadm_mlp_weights_t* weights, int32_t flags /* NADM_X_CLEAN, see nadm_encode_bwd */, void* stream);
+/* Pass 3 with the batch's 128-sample tiles dealt to n_slices blocks per 512-SNP chunk (r06; C <= 8): for launches whose chunks alone leave
+ * most CUs idle -- an SNP-sharded rank's 6400 rows x 62.5k SNPs is 122 blocks.  Every slice parks its partial [512 x CP] sum in `slab`
+ * (nadm_encode_slab_floats(M, CP, n_slices) floats, 16-byte aligned), the block counted last (`counters`: nadm_encode_bwd_chunks(M) int32,
+ * zero-filled once, left zero) adds them in slice order and applies the update / stores the gradient: pass 2's hand-off, reproducible
+ * bit for bit.  n_slices comes from nadm_encode_slices(b, M, CP) -- a function of the shape alone, 1 for every single-GPU BASELINE shape --
+ * so that every path to the pass cuts the batch the same way; adam / weights as for nadm_encode_bwd_step (both may be NULL). */
+int32_t nadm_encode_slices(int32_t b, int64_t M, int32_t CP);
+int32_t nadm_encode_slices_max(int32_t bmax, int64_t M, int32_t CP);
+int64_t nadm_encode_slab_floats(int64_t M, int32_t CP, int32_t n_slices);
+int64_t nadm_encode_bwd_chunks(int64_t M);
+int nadm_encode_bwd_sliced(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                           const float* dZ, const void* dzimg, int32_t CP, float* V, float* dV, const nadm_adam_t* adam,
+                           const nadm_mlp_weights_t* weights, int32_t flags, int32_t n_slices, float* slab, int32_t* counters, void* stream);
+#ifdef NADM_TEST_HOOKS   /* the TEST build only: n > 0 makes nadm_encode_slices return n (capped by the tiles), 0 = the library's choice */
+void nadm_test_force_p3_slices(int32_t n);
+#endif
 int nadm_small_grads(const float* small_part, int32_t splits, int32_t n_small, float* grad_small, float* small,
                      const nadm_adam_t* adam, void* stream);
 /* nadm_encode_fwd of the NEXT step with nadm_small_grads of this one riding in the same launch as side blocks (pass 1 reads
@@ -411,6 +427,9 @@ typedef struct nadm_plan_desc {
                                            * heads before it of nadm_decode_slab_floats(M, kp, nadm_decode_slices_max(bmax, M, kp)); NULL (with
                                            * p2_cnt): pass 2 is never sliced                                                        */
     int32_t* p2_cnt;                      /* the heads' counters back to back, nadm_decode_chunks(M, kp) each, zero-filled once    */
+    float* p3_slab;                       /* pass 3 in sample slices (nadm_encode_bwd_sliced): nadm_encode_slab_floats(M, CP,
+                                           * nadm_encode_slices_max(bmax, M, CP)) floats; NULL (with p3_cnt): pass 3 is never sliced   */
+    int32_t* p3_cnt;                      /* nadm_encode_bwd_chunks(M) counters, zero-filled once                                    */
 } nadm_plan_desc_t;
 typedef struct nadm_plan nadm_plan_t;
 int  nadm_plan_create(const nadm_plan_desc_t* desc, nadm_plan_t** out);

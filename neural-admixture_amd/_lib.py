@@ -58,7 +58,8 @@ class PlanDesc(C.Structure):
                                              "dqpart", "losspart", "small_part", "zsum", "dqsum", "qimg")]
                 + [("qimg_head_bytes", C.c_int64), ("dzimg", C.c_void_p), ("dzcnt", C.c_void_p), ("xg", C.c_void_p), ("loss_acc", C.c_void_p),
                    ("comm", C.POINTER(CommStruct)), ("comm_a", C.POINTER(CommStruct)), ("n_buckets", C.c_int32), ("p3_whole", C.c_int32),
-                   ("debug", C.c_int32), ("reserved", C.c_int32), ("p2_slab", C.c_void_p), ("p2_cnt", C.c_void_p)])
+                   ("debug", C.c_int32), ("reserved", C.c_int32), ("p2_slab", C.c_void_p), ("p2_cnt", C.c_void_p),
+                   ("p3_slab", C.c_void_p), ("p3_cnt", C.c_void_p)])
 
 
 MODE_SINGLE, MODE_DP, MODE_SNP = 0, 1, 2
@@ -115,6 +116,11 @@ def _load():
         "nadm_q_image_bytes": (C.c_int64, [i32]),
         "nadm_encode_fwd_small": (C.c_int, [vp, i64, vp, i32, i64, vp, i32, vp, vp, i32, i32, vp, vp, vp, vp]),
         "nadm_encode_bwd_step": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, i32, vp, vp, vp, vp, i32, vp]),
+        "nadm_encode_slices": (i32, [i32, i64, i32]),
+        "nadm_encode_slices_max": (i32, [i32, i64, i32]),
+        "nadm_encode_slab_floats": (i64, [i64, i32, i32]),
+        "nadm_encode_bwd_chunks": (i64, [i64]),
+        "nadm_encode_bwd_sliced": (C.c_int, [vp, i64, vp, i32, i64, vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]),
         "nadm_small_grads": (C.c_int, [vp, i32, i32, vp, vp, vp, vp]),
         "nadm_mlp_bwd": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp]),
         "nadm_mlp_bwd_image": (C.c_int, [HP, vp, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]),
@@ -157,10 +163,10 @@ def _load():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
         fn.restype = res
         fn.argtypes = args
-    for name in ("nadm_test_force_slices", "nadm_test_force_generic_mlp"):      # the TEST build only (csrc/libnadm_testhooks.so, -DNADM_TEST_HOOKS)
+    for name in ("nadm_test_force_slices", "nadm_test_force_generic_mlp", "nadm_test_force_p3_slices"):      # the TEST build only (csrc/libnadm_testhooks.so, -DNADM_TEST_HOOKS)
         if hasattr(lib, name):
             getattr(lib, name).restype, getattr(lib, name).argtypes = None, [i32]
-    if lib.nadm_abi_version() != 12:
+    if lib.nadm_abi_version() != 13:
         raise RuntimeError("neural_admixture_amd: libnadm.so ABI version mismatch")
     return lib, tuple(sig)
 

@@ -1325,16 +1325,29 @@ __global__ __launch_bounds__(256) void dz_image_kernel(const float* __restrict__
 constexpr int EB4_XS = 132;               // bytes per byte column of the LDS tile: 128 samples + 4 (dword stride 33: the loader's 4-byte
                                           // stores of 32 consecutive column quads and the 4-byte column reads spread over the banks)
 // CLEAN_SRC: xp is pass 2's copy of the batch (xg_piece: tiled by this kernel's chunks, rows in batch order, missing calls already 0)
-template <int CP, bool CLEAN_SRC>
+// floats one (sample slice, SNP chunk) block of pass 3 parks for the block that adds the slices up: the chunk's [512 SNPs x CP] partial of dV
+constexpr int p3_slab_floats(int cp) { return EB_CHUNK_SNPS * cp; }
+
+// SLICED (r06): S sample slices.  The grid is one block per 512-SNP chunk with the batch's 128-sample tiles as a loop inside:
+// a rank of the SNP-sharded mode (6400 rows x 62.5k SNPs at configs[3] on 8 GPUs) launches 122 blocks on 256 CUs and runs 75 us where the
+// single-GPU shape (800 x 500k, the same genotypes) runs 41.  The tiles are dealt to S blocks per chunk; every slice parks its partial
+// [512 x CP] sum in `slab`, is counted, and the block counted LAST adds the S partials in slice order and runs the epilogue (Adam on the
+// chunk's V rows, or the gradient store) -- pass 2's idiom (decode_bce_bf16_kernel), the dZ image's hand-off contract: nobody
+// waits, the sum's order is fixed, S is a function of (b, M) alone (nadm_encode_slices).  false compiles the kernel as it stood.
+template <int CP, bool CLEAN_SRC, bool SLICED = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void encode_bwd_fp4_kernel(const uint8_t* __restrict__ xp, int64_t ld,
                                                               const int32_t* __restrict__ idx, int b, int64_t M,
                                                               const uint4* __restrict__ dzimg, float* __restrict__ dV,
-                                                              uint32_t missing_bf16, float* __restrict__ Vrw, AdamFused ad, MlpSide side) {
+                                                              uint32_t missing_bf16, float* __restrict__ Vrw, AdamFused ad, MlpSide side,
+                                                              float* slab, int* slice_cnt, int n_slices_arg) {
     static_assert(CP <= 8, "rows of the instruction: piece parity x 8 columns");
+    const int64_t nchunks = (M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS;
+    const int n_slices = SLICED ? n_slices_arg : 1;
+    // grid.x = chunks x slices (slice-major: all chunks of slice 0, then slice 1, ...) + the side blocks LAST: as a second grid dimension
+    // the slices were dispatched behind slice 0's ~1600 side blocks (b = 6400) and every further slice made the launch slower
     {   // blocks past the SNP chunks: the MLP weight-gradient partials (independent of pass 3; see mlp_bwd_b_block)
-        const int64_t nchunks = (M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS;
-        if ((int64_t)blockIdx.x >= nchunks) {
-            const int e = (int)(blockIdx.x - nchunks);
+        if ((int64_t)blockIdx.x >= nchunks * n_slices) {
+            const int e = (int)(blockIdx.x - nchunks * n_slices);
             mlp_bwd_b_block(side.hd, side.b, side.Zn, side.H, side.dL, side.dHpre, side.dgp, side.small_part, e % side.gx, e / side.gx);
             return;
         }
@@ -1343,7 +1356,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     static_assert(sizeof(s_xt) >= (size_t)EB_CHUNK_SNPS * CP * sizeof(float), "the dV image fits the tile buffers");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mcol = lane & 15, q = lane >> 4;
-    const int64_t chunk = blockIdx.x;
+    const int64_t chunk = SLICED ? (int64_t)(blockIdx.x % nchunks) : (int64_t)blockIdx.x;
     const int64_t byte0 = chunk * EB_COLS;
     // a missing call (code 3) is 0 in the model and 1.5 in the init-time products: 1.5 is the FP4 value of the nibble 0011, for the
     // model the loader clears both bits of every code 3 before the tile goes to LDS
@@ -1421,10 +1434,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     // prologue: tile 0 committed, tile 1 in flight, the row indices of tile 2 fetched.  A tile's loads are issued one tile phase
     // (~1.5 k cycles of work per wave) before they are committed, its row indices one phase before that.
-    const int ntiles = (b + DZI_TS - 1) / DZI_TS;
-    fetch_rows(0);
+    const int ntiles_all = (b + DZI_TS - 1) / DZI_TS;
+    const int slice = SLICED ? (int)(blockIdx.x / nchunks) : 0;
+    const int tps = (ntiles_all + n_slices - 1) / n_slices;       // (the host picks S so that no slice is empty)
+    const int tl0 = SLICED ? slice * tps : 0, ntiles = SLICED ? min(ntiles_all, tl0 + tps) : ntiles_all;      // this block's tiles: [tl0, ntiles)
+    fetch_rows(tl0 * DZI_TS);
     issue();
-    fetch_rows(DZI_TS);
+    fetch_rows((tl0 + 1) * DZI_TS);
     auto commit_tile = [&](int buf, int i0) {
         if (col_edge || i0 + DZI_TS > b) {
 #pragma unroll
@@ -1434,13 +1450,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int t = 0; t < 4; ++t) commit(buf, i0, t, std::false_type{});
         }
     };
-    commit_tile(0, 0);
+    commit_tile(0, tl0 * DZI_TS);
     issue();
-    fetch_rows(2 * DZI_TS);
+    fetch_rows((tl0 + 2) * DZI_TS);
     __syncthreads();
 
-    for (int T = 0; T < ntiles; ++T) {
-        const int cur = T & 1;
+    for (int T = tl0; T < ntiles; ++T) {
+        const int cur = (T - tl0) & 1;
         // the tile's A operands: 7 x 16 B per lane of the image every block of the launch reads (L2)
         const uint4* zi = dzimg + (int64_t)T * DZI_TILE_U4 + lane;
         uint4 z[7];
@@ -1512,18 +1528,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     }
     __syncthreads();
-    {
-        constexpr int ROW4 = CP / 4;
-        const int64_t m0 = chunk * EB_CHUNK_SNPS;
-        for (int e = tid; e < EB_CHUNK_SNPS * ROW4; e += 256) {
-            const int64_t m = m0 + e / ROW4;
-            if (m < M) {
-                const float4 g4 = *reinterpret_cast<const float4*>(s_dv + 4 * e);
-                const int64_t o = m * CP + 4 * (e % ROW4);
-                if (ad.m != nullptr) adam_float4(Vrw + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.inv_bc2, ad.grad_scale, false);
-                else *reinterpret_cast<float4*>(dV + o) = g4;
-            }
+    constexpr int ROW4 = CP / 4;
+    constexpr int CH_F4 = EB_CHUNK_SNPS * ROW4;
+    const int64_t m0 = chunk * EB_CHUNK_SNPS;
+    auto finish = [&](int e, const float4 g4) {                       // row piece e of the chunk, gradient complete
+        const int64_t m = m0 + e / ROW4;
+        if (m < M) {
+            const int64_t o = m * CP + 4 * (e % ROW4);
+            if (ad.m != nullptr) adam_float4(Vrw + o, g4, ad.m + o, ad.v + o, ad.step_size, ad.inv_bc2, ad.grad_scale, false);
+            else *reinterpret_cast<float4*>(dV + o) = g4;
         }
+    };
+    if constexpr (!SLICED) {
+        for (int e = tid; e < CH_F4; e += 256) finish(e, *reinterpret_cast<const float4*>(s_dv + 4 * e));
+        return;
+    }
+    // ---- S > 1: park the partial, be counted, the last one adds them up (pass 2's hand-off: write-through stores, vmcnt(0), a device-scope
+    // counter, device-scope loads)
+    constexpr int SLAB_F = p3_slab_floats(CP);
+    float* const mine = slab + ((int64_t)slice * nchunks + chunk) * SLAB_F;
+    for (int e = tid; e < CH_F4; e += 256) {
+        const float4 g4 = *reinterpret_cast<const float4*>(s_dv + 4 * e);
+        __hip_atomic_store(mine + 4 * e + 0, g4.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 4 * e + 1, g4.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 4 * e + 2, g4.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 4 * e + 3, g4.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __shared__ int s_last;
+    __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): this wave's stores have been acknowledged ...
+    __syncthreads();
+    if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(&slice_cnt[chunk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... before the block is counted
+        s_last = old == n_slices - 1;
+        if (s_last) __hip_atomic_store(&slice_cnt[chunk], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;                                              // block-uniform
+    for (int e = tid; e < CH_F4; e += 256) {
+        float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sl = 0; sl < n_slices; ++sl) {                       // slice order, whoever is last
+            const float* part = slab + ((int64_t)sl * nchunks + chunk) * SLAB_F + 4 * e;
+            g4.x += __hip_atomic_load(part + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g4.y += __hip_atomic_load(part + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g4.z += __hip_atomic_load(part + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            g4.w += __hip_atomic_load(part + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        finish(e, g4);
     }
 }
 
@@ -1908,7 +1958,7 @@ extern "C" int nadm_dz_image(const float* dZ, int32_t b, int32_t CP, void* dzimg
 static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
                            const float* dZ, const void* dzimg, int32_t CP, float* dV, void* stream, uint32_t missing_bf16, int32_t flags = 0,
                            float* Vrw = nullptr, AdamFused ad = AdamFused{nullptr, nullptr, 0.f, 0.f, 0.f},
-                           const nadm_mlp_weights_t* mw = nullptr) {
+                           const nadm_mlp_weights_t* mw = nullptr, int32_t n_slices = 1, float* slab = nullptr, int32_t* counters = nullptr) {
     if (!xp || !idx || !dZ || !dV) return fail("nadm_encode_bwd: null pointer");
     if (CP > 8 && (flags & NADM_X_CLEAN)) return fail("nadm_encode_bwd: the batch copy (NADM_X_CLEAN) is tiled for the matrix-core pass, C <= 8");
     if (CP <= 8 && (!dzimg || ((uintptr_t)dzimg & 15)))
@@ -1926,11 +1976,18 @@ static int encode_bwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
             side.Zn = mw->Zn; side.H = mw->H; side.dL = mw->dL; side.dHpre = mw->dHpre; side.dgp = mw->dgp; side.small_part = mw->small_part;
             extra = (int64_t)side.gx * nadm_sample_splits(b);
         }
-        dim3 g2((unsigned)((M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS + extra));
-#define NADM_P3_LAUNCH(CPV, CL) hipLaunchKernelGGL((encode_bwd_fp4_kernel<CPV, CL>), g2, block, 0, st, xp, ld, idx, b, M, (const uint4*)dzimg, dV, missing_bf16, Vrw, ad, side)
+        if (n_slices < 1 || n_slices > NADM_MAX_P2_SLICES) return fail("nadm_encode_bwd_sliced: n_slices must be in 1..8");
+        const int ntiles = (b + DZI_TS - 1) / DZI_TS;
+        if (n_slices > 1 && ((n_slices - 1) * ((ntiles + n_slices - 1) / n_slices) >= ntiles)) return fail("nadm_encode_bwd_sliced: an empty sample slice");
+        if (n_slices > 1 && (!slab || !counters || ((uintptr_t)slab & 15))) return fail("nadm_encode_bwd_sliced: the slab (16-byte aligned) and the counters are NULL");
+        dim3 g2((unsigned)(((M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS) * n_slices + extra));
+#define NADM_P3_LAUNCH(CPV, CL, SL) hipLaunchKernelGGL((encode_bwd_fp4_kernel<CPV, CL, SL>), g2, block, 0, st, xp, ld, idx, b, M, (const uint4*)dzimg, dV, missing_bf16, Vrw, ad, side, slab, counters, (int)n_slices)
         const bool clean = (flags & NADM_X_CLEAN) != 0 && missing_bf16 == 0u;
-        if (CP == 4) { if (clean) NADM_P3_LAUNCH(4, true); else NADM_P3_LAUNCH(4, false); }
-        else { if (clean) NADM_P3_LAUNCH(8, true); else NADM_P3_LAUNCH(8, false); }
+        if (n_slices > 1) {
+            if (CP == 4) { if (clean) NADM_P3_LAUNCH(4, true, true); else NADM_P3_LAUNCH(4, false, true); }
+            else { if (clean) NADM_P3_LAUNCH(8, true, true); else NADM_P3_LAUNCH(8, false, true); }
+        } else if (CP == 4) { if (clean) NADM_P3_LAUNCH(4, true, false); else NADM_P3_LAUNCH(4, false, false); }
+        else { if (clean) NADM_P3_LAUNCH(8, true, false); else NADM_P3_LAUNCH(8, false, false); }
 #undef NADM_P3_LAUNCH
         return check_launch("encode_bwd_fp4");
     }
@@ -1955,6 +2012,60 @@ extern "C" int nadm_encode_bwd_step(const uint8_t* xp, int64_t ld, const int32_t
     if (weights && (!weights->hd || !weights->Zn || !weights->H || !weights->dL || !weights->dHpre || !weights->dgp || !weights->small_part))
         return fail("nadm_encode_bwd_step: null pointer in the MLP weight-gradient arguments");
     return encode_bwd_impl(xp, ld, idx, b, M, dZ, dzimg, CP, dV, stream, 0u, flags, V, ad, weights);
+}
+
+// ---- pass 3 with the batch's 128-sample tiles dealt to n_slices blocks per SNP chunk (see encode_bwd_fp4_kernel)
+#ifdef NADM_TEST_HOOKS
+static std::atomic<int> g_force_p3_slices{0};
+extern "C" void nadm_test_force_p3_slices(int32_t n) { g_force_p3_slices.store(n < 0 ? 0 : (n > NADM_MAX_P2_SLICES ? NADM_MAX_P2_SLICES : n)); }
+#endif
+
+extern "C" int32_t nadm_encode_slices(int32_t b, int64_t M, int32_t cp) {
+    if (cp > 8 || b <= 0 || M <= 0) return 1;
+    const int64_t chunks = (M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS;
+    const int tiles = (b + DZI_TS - 1) / DZI_TS;
+    int s = 0;
+#ifdef NADM_TEST_HOOKS
+    s = g_force_p3_slices.load();
+#endif
+    if (s == 0) {
+        // Measured (profiles/r06_p3_slices.txt): a launch of ~120 chunk blocks that each walk 50 tiles (6400 rows x 62.5k SNPs, the SNP-sharded
+        // rank of configs[3] on 8 GPUs) lasts as long as one block's chain, 77 us where the same genotypes as 977 blocks take 41; two slices
+        // 57 us, three 62, four 64, eight 76 -- every slice pays a prologue and the hand-off (park 16 KB through to memory, be counted, the
+        // last one reads them all back and runs Adam: ~8 us of tail).  At 3200 x 125k (245 chunks x 25 tiles, 46 us) any cut loses: 53 / 65.
+        // So: two slices, only for few chunks AND long chains; every single-GPU BASELINE shape stays whole.
+        if (chunks >= 192 || tiles < 32) return 1;
+        s = 2;
+    }
+    if (s > tiles) s = tiles;
+    if (s < 2) return 1;
+    const int tps = (tiles + s - 1) / s;
+    return (tiles + tps - 1) / tps;                                   // no empty slice
+}
+
+extern "C" int32_t nadm_encode_slices_max(int32_t bmax, int64_t M, int32_t cp) {
+    int32_t mx = 1;
+    for (int32_t b = bmax; b > 0; b -= DZI_TS) { const int32_t s = nadm_encode_slices(b, M, cp); if (s > mx) mx = s; }
+    return mx;
+}
+
+extern "C" int64_t nadm_encode_slab_floats(int64_t M, int32_t cp, int32_t n_slices) {
+    if (cp > 8 || n_slices < 2 || M <= 0) return 0;
+    return (int64_t)n_slices * ((M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS) * p3_slab_floats(cp);
+}
+
+extern "C" int64_t nadm_encode_bwd_chunks(int64_t M) { return (M + EB_CHUNK_SNPS - 1) / EB_CHUNK_SNPS; }
+
+extern "C" int nadm_encode_bwd_sliced(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,
+                                      const float* dZ, const void* dzimg, int32_t CP, float* V, float* dV, const nadm_adam_t* adam,
+                                      const nadm_mlp_weights_t* weights, int32_t flags, int32_t n_slices, float* slab, int32_t* counters, void* stream) {
+    AdamFused ad;
+    if (adam_fused_args(adam, "nadm_encode_bwd_sliced: Adam state is NULL", &ad)) return 1;
+    if (ad.m && (!V || ((uintptr_t)V & 15))) return fail("nadm_encode_bwd_sliced: V must be non-NULL and 16-byte aligned");
+    if (CP > 8) return fail("nadm_encode_bwd_sliced: the matrix-core pass only (C <= 8)");
+    if (weights && (!weights->hd || !weights->Zn || !weights->H || !weights->dL || !weights->dHpre || !weights->dgp || !weights->small_part))
+        return fail("nadm_encode_bwd_sliced: null pointer in the MLP weight-gradient arguments");
+    return encode_bwd_impl(xp, ld, idx, b, M, dZ, dzimg, CP, dV, stream, 0u, flags, V, ad, weights, n_slices, slab, counters);
 }
 
 extern "C" int nadm_encode_bwd(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t M,

@@ -304,6 +304,7 @@ struct nadm_plan {
     int n_classes = 0;
     float sup_weight = 0.f;
     int64_t enc_chunks = 0, dec_chunks[NADM_MAX_HEADS] = {0}, loss_off[NADM_MAX_HEADS] = {0}, slab_off[NADM_MAX_HEADS] = {0}, n_loss = 0;
+    int32_t p3_slices_cap = 1;                      // sample slices p3_slab was sized for
     int32_t slices_cap[NADM_MAX_HEADS] = {0};       // sample slices the head's region of p2_slab was sized for (nadm_decode_slices_max at creation)
     uint32_t tmask = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> trec[NADM_T_COUNT], trec_bkt[NADM_MAX_BUCKETS];
@@ -505,6 +506,8 @@ extern "C" int nadm_plan_create(const nadm_plan_desc_t* desc, nadm_plan_t** out)
     if (d.reserved != 0) return fail("nadm_plan_create: nadm_plan_desc_t.reserved must be 0");
     if ((d.p2_slab == nullptr) != (d.p2_cnt == nullptr) || ((uintptr_t)d.p2_slab & 15))
         return fail("nadm_plan_create: p2_slab (16-byte aligned) and p2_cnt come together (both NULL: pass 2 is never sliced)");
+    if ((d.p3_slab == nullptr) != (d.p3_cnt == nullptr) || ((uintptr_t)d.p3_slab & 15))
+        return fail("nadm_plan_create: p3_slab (16-byte aligned) and p3_cnt come together (both NULL: pass 3 is never sliced)");
     nadm_plan* p = new nadm_plan;
     p->d = d;
     p->world = d.comm ? d.comm->world : 1;
@@ -523,6 +526,7 @@ extern "C" int nadm_plan_create(const nadm_plan_desc_t* desc, nadm_plan_t** out)
         p->slices_cap[h] = nadm_decode_slices_max(d.bmax, d.M, hd.kp[h]);
         slab_floats += nadm_decode_slab_floats(d.M, hd.kp[h], p->slices_cap[h]);
     }
+    p->p3_slices_cap = nadm_encode_slices_max(d.bmax, d.M, hd.CP);
     bool ok = true;
     auto stream_ok = [&](hipStream_t* s) { ok = ok && hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess; };
     auto event_ok = [&](hipEvent_t* e) { ok = ok && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; };
@@ -738,7 +742,11 @@ static int step_impl(nadm_plan_t* p, const int32_t* idx, int32_t b, float lr, in
     Timed t4{p, NADM_T_ENCODE_BWD, st};
     if (t4.begin()) return 1;
     const nadm_adam_t av = adam_at(p, p->lay.off_v, lr, p->step_count, scale);
-    if (nadm_encode_bwd_step(image ? d.xg : d.xp, d.ld, idx, b, d.M, d.dZ, image ? d.dzimg : nullptr, hd.CP, V, dV, &av, &mw, p3_flags, stream)) return 1;
+    const int p3_slices = (d.p3_slab && image) ? nadm_encode_slices(b, d.M, hd.CP) : 1;      // sample slices where the SNP chunks alone leave CUs idle
+    if (p3_slices > p->p3_slices_cap) return fail("nadm_step: pass 3 would be cut into more sample slices than the plan's slab was sized for at creation");
+    if (p3_slices > 1) {
+        if (nadm_encode_bwd_sliced(d.xg, d.ld, idx, b, d.M, d.dZ, d.dzimg, hd.CP, V, dV, &av, &mw, p3_flags, p3_slices, d.p3_slab, d.p3_cnt, stream)) return 1;
+    } else if (nadm_encode_bwd_step(image ? d.xg : d.xp, d.ld, idx, b, d.M, d.dZ, image ? d.dzimg : nullptr, hd.CP, V, dV, &av, &mw, p3_flags, stream)) return 1;
     if (t4.end()) return 1;
 
     // ---- the small parameters

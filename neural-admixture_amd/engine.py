@@ -98,6 +98,11 @@ class Engine:
             self._p2_slab_off.append(self._p2_slab_off[-1] + int(lib.nadm_decode_slab_floats(self.M, kp, self._p2_slices_cap[-1])))
         self._p2_slab = z(self._p2_slab_off[-1]) if gpu and self._p2_slab_off[-1] else None
         self._p2_cnt = torch.zeros(L.n_loss, dtype=torch.int32, device=device) if self._p2_slab is not None else None
+        # pass 3 likewise (nadm_encode_bwd_sliced, r06): an SNP-sharded rank's few chunks x many rows
+        self._p3_slices_cap = int(lib.nadm_encode_slices_max(b, self.M, L.CP)) if tiled else 1
+        n3 = int(lib.nadm_encode_slab_floats(self.M, L.CP, self._p3_slices_cap))
+        self._p3_slab = z(n3) if n3 else None
+        self._p3_cnt = torch.zeros(int(lib.nadm_encode_bwd_chunks(self.M)), dtype=torch.int32, device=device) if n3 else None
         # validity of the three by-products for the plain phases below (the plan's own step always produces what it consumes)
         self._qimg_b = self._dzimg_b = -1
         self._dz_last_b = 0
@@ -121,7 +126,7 @@ class Engine:
                         ("dHpre", self.dHpre), ("dgp", self.dgp), ("dZ", self._dZ), ("dqpart", self.dqpart), ("losspart", self.losspart),
                         ("small_part", self.small_part), ("zsum", self._zsum), ("dqsum", self._dqsum), ("qimg", self.qimg),
                         ("dzimg", self._dzimg), ("dzcnt", self._dzcnt), ("xg", self._xg), ("loss_acc", self.loss_acc),
-                        ("p2_slab", self._p2_slab), ("p2_cnt", self._p2_cnt)):
+                        ("p2_slab", self._p2_slab), ("p2_cnt", self._p2_cnt), ("p3_slab", self._p3_slab), ("p3_cnt", self._p3_cnt)):
             setattr(d, name, None if t is None else t.data_ptr())
         d.qimg_head_bytes = self._qimg_head
         d.n_buckets, d.p3_whole, d.debug = L.n_buckets, int(self.p3_whole), int(self.debug)
@@ -448,6 +453,13 @@ class Engine:
         else:
             src, rows, flags = self.xp, idx, 0
         self._xg_key = None
+        slices = int(lib.nadm_encode_slices(b, L.M, L.CP)) if (self._p3_slab is not None and flags) else 1
+        if slices > self._p3_slices_cap:
+            raise RuntimeError("pass 3 would be cut into more sample slices than this engine's slab was sized for")
+        if slices > 1:                                    # the library's cut of the batch, as in the step
+            check(lib.nadm_encode_bwd_sliced(ptr(src), self.ld, ptr(rows), b, L.M, ptr(self._dZ), dzimg, L.CP, None, ptr(self.gflat[L.off_v:]), None, None,
+                                             flags, slices, ptr(self._p3_slab), ptr(self._p3_cnt), st), "encode_bwd_sliced")
+            return
         check(lib.nadm_encode_bwd(ptr(src), self.ld, ptr(rows), b, L.M, ptr(self._dZ), dzimg, L.CP, ptr(self.gflat[L.off_v:]), flags, st), "encode_bwd")
 
     def backward(self, idx: torch.Tensor, b: int, with_loss: bool = True) -> None:

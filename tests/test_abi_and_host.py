@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     hooks = set(re.findall(r"\b(nadm_[a-z0-9_]+)\s*\(", "".join(re.findall(r"#ifdef NADM_TEST_HOOKS.*?#endif", hdr, flags=re.S))))
     hdr = re.sub(r"#ifdef NADM_TEST_HOOKS.*?#endif", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(nadm_[a-z0-9_]+)\s*\(", hdr))
-    assert len(declared) >= 17 and hooks == {"nadm_test_force_slices", "nadm_test_force_generic_mlp"}
+    assert len(declared) >= 17 and hooks == {"nadm_test_force_slices", "nadm_test_force_generic_mlp", "nadm_test_force_p3_slices"}
     from conftest import HOOK_LIB
     product = os.path.join(ROOT, "neural-admixture_amd", "csrc", "libnadm.so")
     raw, test_build = C.CDLL(product), C.CDLL(HOOK_LIB)
@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for name in hooks:                                   # the laboratory is not in the product
         assert not hasattr(raw, name) and hasattr(test_build, name)
     assert declared == set(_lib.EXPORTS)               # the Python binding covers the whole header
-    assert _lib.lib.nadm_abi_version() == 12
+    assert _lib.lib.nadm_abi_version() == 13
 
 
 def test_argument_validation_without_gpu():
@@ -122,6 +122,27 @@ def test_pass2_sample_slice_rule_and_slab_sizes():
                 assert 1 <= s_ <= mx and (s_ == 1 or (s_ - 1) * ((tiles + s_ - 1) // s_) < tiles)      # no empty slice
     chunks = lib.nadm_decode_chunks(50_000, 8)
     assert lib.nadm_decode_slab_floats(50_000, 8, 3) == 3 * chunks * (256 * 8 + 4) and lib.nadm_decode_slab_floats(50_000, 8, 1) == 0
+
+
+def test_pass3_sample_slice_rule_and_slab_sizes():
+    """nadm_encode_slices (r06) is a function of (b, M, CP) alone: 1 for every single-GPU BASELINE shape (the S = 1 kernel is their launch), for
+    short batches and for the fp32 kernels (CP > 8); the SNP-sharded rank of configs[3] on 8 GPUs (6400 rows x 62.5k SNPs) is cut; no empty
+    slice, at most 8; nadm_encode_slices_max bounds every shorter batch (it sizes the slab)."""
+    from neural_admixture_amd._lib import lib
+    for b, M in ((800, 500_000), (800, 600_000), (800, 1_000_000), (100, 500_000), (104, 600_000), (800, 62_500), (896, 4000), (6400, 500_000)):
+        assert lib.nadm_encode_slices(b, M, 8) == 1, (b, M)
+    assert lib.nadm_encode_slices(6400, 62_500, 8) == 2 and lib.nadm_encode_slices(6400, 62_500, 12) == 1       # measured: 77 -> 57 us; more slices lose
+    assert lib.nadm_encode_slices(3200, 125_000, 8) == 1 and lib.nadm_encode_slices(4096, 90_000, 4) == 2          # 245 chunks x 25 tiles: any cut loses
+    for M in (1100, 3000, 62_500, 125_000, 190_000):
+        for bmax in (1025, 1600, 6400):
+            mx = lib.nadm_encode_slices_max(bmax, M, 8)
+            assert 1 <= mx <= 8
+            for b in range(1, bmax + 1, 97):
+                s_ = lib.nadm_encode_slices(b, M, 8)
+                tiles = (b + 127) // 128
+                assert 1 <= s_ <= mx and (s_ == 1 or (s_ - 1) * ((tiles + s_ - 1) // s_) < tiles)
+    chunks = lib.nadm_encode_bwd_chunks(62_500)
+    assert chunks == 123 and lib.nadm_encode_slab_floats(62_500, 8, 2) == 2 * chunks * 512 * 8 and lib.nadm_encode_slab_floats(62_500, 8, 1) == 0
 
 
 def test_force_hook_of_the_test_build_overrides_the_slice_rule(request):

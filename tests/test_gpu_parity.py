@@ -1481,6 +1481,55 @@ def test_pass2_in_sample_slices_gives_the_unsliced_gradients_and_is_reproducible
         assert (pf - p1).abs().max().item() <= 2e-5               # three Adam steps on gradients equal to rounding (a flipped sign of a ~0 gradient moves lr)
 
 
+@pytest.mark.parametrize("ks,b,M,C", [([8], 1100, 3000, 8), ([3], 1283, 5003, 8), ([5], 4200, 1100, 4)])
+def test_pass3_in_sample_slices_gives_the_unsliced_gradient_and_is_reproducible(request, ks, b, M, C):
+    """nadm_encode_bwd_sliced (r06: the batch's 128-sample tiles dealt to S blocks per 512-SNP chunk, the partial dV sums added in slice
+    order by the block counted last): against the S = 1 kernel on the same dZ -- dV equal to rounding (the sum over the slices has an order
+    of its own) -- for S = 2, 3, 5 and the library's own choice; the same bits call after call; counters back at zero; the fused step
+    (Adam on V in the last block's epilogue, the MLP weight-gradient side blocks once) equal to the unsliced step after three steps to the
+    size of an Adam step on a rounding-level gradient; ragged batches.  (Forcing S needs the test build: conftest.in_hook_build.)"""
+    from conftest import in_hook_build
+    if not in_hook_build(request):
+        return
+    from neural_admixture_amd._lib import lib
+    N = b + 60
+    Gm = O.synth_genotypes(N, M, max(ks), seed=17, missing=0.03)
+    rng = np.random.default_rng(9)
+    p = O.make_params(5, (rng.standard_normal((M, C)) / np.sqrt(M)).astype(np.float32), rng.uniform(0.02, 0.98, (sum(ks), M)).astype(np.float32), 64, ks)
+    idx = torch.from_numpy(rng.permutation(N)[:b].astype(np.int32)).to(_dev())
+
+    def run(force):
+        lib.nadm_test_force_p3_slices(force)
+        try:
+            e = make_engine(Gm, p, b)
+            want = int(lib.nadm_encode_slices(b, M, e.lay.CP))
+            e.forward(idx, b)
+            e.backward(idx, b)
+            torch.cuda.synchronize()
+            gV = e.gV().cpu().numpy().copy()
+            e.forward(idx, b)
+            e.backward(idx, b)
+            assert np.array_equal(gV, e.gV().cpu().numpy()), "not reproducible"
+            assert e._p3_cnt is None or int(e._p3_cnt.abs().sum().item()) == 0
+            for bb in (b, b - 137, b):
+                e.train_step(idx[:bb], bb, 2e-3, True)
+            e.sync()
+            torch.cuda.synchronize()
+            assert e._p3_cnt is None or int(e._p3_cnt.abs().sum().item()) == 0
+            return gV, e.pflat.clone(), want
+        finally:
+            lib.nadm_test_force_p3_slices(0)
+
+    g1, p1, want1 = run(1)
+    assert want1 == 1
+    for force in (2, 3, 5, 0):
+        g, pf, want = run(force)
+        tiles = (b + 127) // 128
+        assert (want == min(force, tiles) or 1 < want <= force) if force else want == int(lib.nadm_encode_slices(b, M, 8 if C > 4 else 4))
+        assert np.abs(g - g1).max() <= 2e-6 * (np.abs(g1).max() + 1e-30), force
+        assert (pf - p1).abs().max().item() <= 2e-5
+
+
 @pytest.mark.parametrize("K", [5, 13, 20])
 def test_pass2_gather_byproduct_and_pass3_on_the_compact_copy(K):
     """nadm_decode_bce_gather = nadm_decode_bce + the batch's rows written back to back: same gradients / loss bit for bit,

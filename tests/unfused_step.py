@@ -56,8 +56,13 @@ def unfused_step(e, idx: torch.Tensor, b: int, lr: float, with_loss: bool = True
                     e.small_part.data_ptr())
     av = AdamArgs(mbig.data_ptr(), vbig.data_ptr(), lr, e.step_count, 1.0, 0)
     src, rows, flags = (xg, e._iota, NADM_X_CLEAN) if tiled else (e.xp, idx, 0)
-    check(lib.nadm_encode_bwd_step(ptr(src), e.ld, ptr(rows), b, L.M, ptr(e._dZ), dzimg, L.CP, ptr(big), ptr(gbig), C.byref(av), C.byref(mw),
-                                   flags, st), "encode_bwd_step")
+    slices = int(lib.nadm_encode_slices(b, L.M, L.CP)) if (e._p3_slab is not None and tiled) else 1
+    if slices > 1:
+        check(lib.nadm_encode_bwd_sliced(ptr(src), e.ld, ptr(rows), b, L.M, ptr(e._dZ), dzimg, L.CP, ptr(big), ptr(gbig), C.byref(av), C.byref(mw),
+                                         flags, slices, ptr(e._p3_slab), ptr(e._p3_cnt), st), "encode_bwd_sliced")
+    else:
+        check(lib.nadm_encode_bwd_step(ptr(src), e.ld, ptr(rows), b, L.M, ptr(e._dZ), dzimg, L.CP, ptr(big), ptr(gbig), C.byref(av), C.byref(mw),
+                                       flags, st), "encode_bwd_step")
     sa = AdamArgs(msmall.data_ptr(), vsmall.data_ptr(), lr, e.step_count, 1.0, 0)
     check(lib.nadm_small_grads(ptr(e.small_part), int(lib.nadm_sample_splits(b)), L.n_small, ptr(gsmall), ptr(small), C.byref(sa), st),
           "small_grads")
