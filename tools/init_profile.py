@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where does a default run spend its wall-clock OUTSIDE the epoch loop?  cProfile (cumulative host time; device work shows up where
 the host waits for it) of RSVD and of train() on the c2 / c3 shapes of tools/full_run.py.  Usage: init_profile.py [c2|c3] [epochs]
--> gpurun_out/r05_init_profile_<cfg>.txt"""
+-> gpurun_out/r06_init_profile_<cfg>.txt"""
 import cProfile
 import io
 import os
@@ -54,7 +54,7 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         prof("write", lambda: (save_model(model, "run", td), write_outputs(Qs, "run", K, mn, mx, td, Ps)))
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/r05_init_profile_{which}.txt", "w") as f:
+    with open(f"gpurun_out/r06_init_profile_{which}.txt", "w") as f:
         f.write("\n\n".join(lines) + "\n")
     print("\n\n".join(lines))
 

@@ -7,7 +7,7 @@ each (HBM ~5 TB/s achievable of 8 peak; PCIe; host memory):
   a15 / f-4a  the final-Q pass over all N rows (encoder only, batches of 1024 like the reference)  (neural_admixture.py:369-383)
   b-2  the .Q / .P text writers                                                                   (src/utils.py:54-66)
 
-    python tools/io_timing.py [N M]        default 100000 500000  -> stdout (profiles/r05_io_timing.txt)"""
+    python tools/io_timing.py [N M]        default 100000 500000  -> stdout (profiles/r06_io_timing.txt)"""
 import ctypes as C
 import os
 import sys

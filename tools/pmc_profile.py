@@ -281,7 +281,7 @@ def main():
                "busy_cycles_sum_over_se": tot("SQ_BUSY_CYCLES"), "wave_quad_cycles": tot("SQ_WAVE_CYCLES"), "active_inst_valu_quad_cycles": tot("SQ_ACTIVE_INST_VALU"),
                "valu_mfma_busy_cycles": tot("SQ_VALU_MFMA_BUSY_CYCLES"), "wait_inst_any_quad_cycles": tot("SQ_WAIT_INST_ANY"),
                "wait_any_quad_cycles": tot("SQ_WAIT_ANY"), "lds_bank_conflict_cycles": tot("SQ_LDS_BANK_CONFLICT"),
-               "active_inst_lds_quad_cycles": tot("SQ_ACTIVE_INST_LDS"), "sclk_ghz": 2.4,
+               "active_inst_lds_quad_cycles": tot("SQ_ACTIVE_INST_LDS"),
                "note": "per launch = all pass-2 launches of one step summed, counters summed over the 32 shader engines"}
         json.dump(out, open(os.path.join(OUT, f"{RND}_pmc_sq.json"), "w"), indent=1)
         open(os.path.join(OUT, f"{RND}_pmc_sq.txt"), "w").write(

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Per-rank cost of the sample-sharded step at world = W, emulated on ONE GPU (bench.py --force-ddp --emulate-world W: rank 0 of W,
-# no-op collectives, Adam on 1/W of the parameters) -> gpurun_out/r05_rank_emulation.txt.  NOT a scaling measurement: nothing
-# crosses xGMI; it shows what a rank's GPU and host have to do per step -- r05: for message B in 1 / 2 / 4 / 8 SNP-range buckets,
+# no-op collectives, Adam on 1/W of the parameters) -> gpurun_out/r06_rank_emulation.txt.  NOT a scaling measurement: nothing
+# crosses xGMI; it shows what a rank's GPU and host have to do per step -- r06: for message B in 1 / 2 / 4 / 8 SNP-range buckets,
 # pass 3 launched range by range or whole, one or two communicators.
-out=gpurun_out/r05_rank_emulation.txt
+out=gpurun_out/r06_rank_emulation.txt
 mkdir -p gpurun_out
 {
-echo "# r05 rank emulation on one MI355X (tools/rank_emulation.sh): ms/step, host ms to queue a step, kernel_ms (us); b = rows per rank"
+echo "# r06 rank emulation on one MI355X (tools/rank_emulation.sh): ms/step, host ms to queue a step, kernel_ms (us); b = rows per rank"
 echo "# weak = 800 rows per rank; strong = the reference's batch_size // num_gpus at --batch_size 800 (neural_admixture.py:287)"
 row() { python bench.py --no-cpu-baseline --steps 100 --warmup 30 "$@" 2>/dev/null | python -c "
 import json,sys

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """A long version of tests/test_soak_handoffs.py, run once per round on the GPU box: N production steps (nadm_step: Q images, dZ image
 built by the MLP backward's last blocks, small update riding in the next pass 1) against the same steps as the unfused launch
-sequence, bit for bit; batch sizes cycle 800 / 790 / 37 / 800 / 128 / 1.  -> gpurun_out/r05_soak.txt
+sequence, bit for bit; batch sizes cycle 800 / 790 / 37 / 800 / 128 / 1.  -> gpurun_out/r06_soak.txt
 
     python tools/soak.py [steps=100000] [dp [buckets=1]]          NADM_SOAK_KS=16 or 3,5,9: other heads than the default K = 8
 
 dp: the sample-sharded launch sequence (NADM_MODE_DP on a 1-rank RCCL communicator: side stream + events every step, Adam as launches of
-its own) against the single-GPU step instead -> gpurun_out/r05_soak_dp.txt"""
+its own) against the single-GPU step instead -> gpurun_out/r06_soak_dp.txt"""
 import os
 import sys
 import time
@@ -59,11 +59,11 @@ def main():
     torch.cuda.synchronize()
     ok = bad is None and _same_state(prod, ref) and prod.read_loss() == ref.read_loss()
     what = (f"sample-sharded steps (NADM_MODE_DP, 1-rank RCCL communicator, message B in {buckets} bucket(s)) vs the single-GPU step" if dp else "production steps vs the unfused launch sequence")
-    line = (f"r05 soak: {steps if bad is None else bad} consecutive {what} (M = {M}, K = {'/'.join(map(str, ks))}, Hd = 1024, batch sizes cycling {sizes}): parameters, moments "
+    line = (f"r06 soak: {steps if bad is None else bad} consecutive {what} (M = {M}, K = {'/'.join(map(str, ks))}, Hd = 1024, batch sizes cycling {sizes}): parameters, moments "
             f"and loss sums {'BIT-IDENTICAL' if ok else 'DIFFER'}; group counters zero; {time.time() - t0:.0f} s")
     print(line)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", (f"r05_soak_dp_b{buckets}" if dp else "r05_soak") + ("" if ks == [8] else "_k" + "_".join(map(str, ks))) + ".txt"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", (f"r06_soak_dp_b{buckets}" if dp else "r06_soak") + ("" if ks == [8] else "_k" + "_".join(map(str, ks))) + ".txt"), "w") as f:
         f.write(line + "\n")
     return 0 if ok else 1
 
