@@ -705,6 +705,9 @@ def main():
                  "valu_insts_per_simd_cycle": valu / t_dom / (N_SIMD * clk * 1e9) if clk else None,
                  "shader_cycles_per_launch_this_run": t_dom * clk * 1e9 if clk else None,
                  "shader_cycles_per_launch_profiled": simd_cycles / N_SIMD if simd_cycles else None,
+                 # the clock the DOMINANT kernel itself ran at in this run, if it spent the profiled launch's cycles: denser than the
+                 # calibration stream, it clocks a few per cent lower on the same box (MI355X_MICROARCH.md, DVFS give-back)
+                 "implied_sclk_ghz_dominant_kernel": simd_cycles / N_SIMD / t_dom / 1e9 if simd_cycles else None,
                  # counters of the same launch: cycles a SIMD spent issuing VALU work / matrix work over all SIMD-cycles of the launch.
                  # The two do not overlap on a SIMD (tools/ubench_issue.hip), so their sum is the issue utilisation; the rest is the
                  # partly filled last round of blocks, barriers and dependency stalls

@@ -66,23 +66,3 @@ extern "C" int nadm_calib_clock(int32_t iters, uint64_t* out, int32_t max_blocks
     const int rc = check_launch("calib_clock");
     return rc ? -rc : blocks;                                                           // > 0: the number of blocks that report
 }
-
-// (experiment, r06) read the batch rows idx[0..b) of the packed matrix and throw them away: what a prefetch of the NEXT step's rows into the
-// memory-side cache would cost / buy pass 1, the first reader of a fresh batch (tools/abl/prefetch_probe.py)
-namespace nadm {
-__global__ __launch_bounds__(256) void touch_rows_kernel(const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int64_t bytes,
-                                                         uint32_t* __restrict__ sink) {
-    const uint4* row = reinterpret_cast<const uint4*>(xp + (int64_t)idx[blockIdx.y] * ld);
-    uint32_t acc = 0;
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < bytes / 16; p += (int64_t)gridDim.x * 256) {
-        const uint4 w = row[p];
-        acc ^= w.x ^ w.y ^ w.z ^ w.w;
-    }
-    if (acc == 0x9E3779B9u) sink[0] = acc;
-}
-}  // namespace nadm
-extern "C" int nadm_touch_rows(const uint8_t* xp, int64_t ld, const int32_t* idx, int32_t b, int64_t bytes, uint32_t* sink, void* stream) {
-    using namespace nadm;
-    hipLaunchKernelGGL(touch_rows_kernel, dim3(8, (unsigned)b), dim3(256), 0, (hipStream_t)stream, xp, ld, idx, bytes, sink);
-    return check_launch("touch_rows");
-}
