@@ -19,7 +19,7 @@ from test_gpu_parity import decode_dz_image
 pytestmark = pytest.mark.gpu
 
 
-def _engines(M, ks, Hd, N, seed):
+def _engines(M, ks, Hd, N, seed, bmax=800):
     import neural_admixture_amd as na
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(seed)
@@ -31,7 +31,7 @@ def _engines(M, ks, Hd, N, seed):
     out = []
     Gt = torch.from_numpy(np.ascontiguousarray(Gm))
     for _ in range(2):
-        e = na.Engine(M, 8, Hd, ks, dev, 800)
+        e = na.Engine(M, 8, Hd, ks, dev, bmax)
         e.load_params(V0, P0, small)
         e.pack_from_host(Gt)
         out.append(e)
@@ -100,6 +100,30 @@ def test_2000_multihead_production_steps_equal_the_unfused_sequence():
     assert int(prod._dzcnt.abs().sum().item()) == 0
     assert prod.read_loss() == ref.read_loss()
     assert _same_state(prod, ref)
+
+
+def test_600_large_batch_steps_with_both_passes_in_sample_slices_equal_the_unfused_sequence():
+    """An SNP-sharded rank's shape in miniature (r06): 4200-row batches on 30k SNPs -- pass 2 AND pass 3 run in sample slices (park, count,
+    the last block adds the partials: the hand-off happens in two kernels of every step) -- against the unfused launch sequence, which takes
+    the library's same cut; ragged and tiny batches in between switch the sliced forms off and on."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from neural_admixture_amd._lib import lib
+    M, N, steps = 30_000, 4400, 600
+    sizes = (4200, 4100, 37, 4200, 800)
+    assert lib.nadm_encode_slices(4200, M, 8) == 2 and lib.nadm_decode_slices(4200, M, 8) > 1 and lib.nadm_encode_slices(800, M, 8) == 1
+    prod, ref = _engines(M, [8], 1024, N, seed=31, bmax=4200)
+    dev = prod.device
+    gen = torch.Generator().manual_seed(13)
+    for s in range(steps):
+        b = sizes[s % len(sizes)]
+        idx = torch.randint(0, N, (b,), generator=gen, dtype=torch.int32).to(dev)
+        prod.train_step(idx, b, 2e-3, s % 3 == 0)
+        unfused_step(ref, idx, b, 2e-3, s % 3 == 0)
+    torch.cuda.synchronize()
+    assert _same_state(prod, ref)
+    assert int(prod._p3_cnt.abs().sum().item()) == 0 and int(prod._p2_cnt.abs().sum().item()) == 0 and int(prod._dzcnt.abs().sum().item()) == 0
+    assert prod.read_loss() == ref.read_loss()
 
 
 def test_1000_data_parallel_steps_on_a_one_rank_rccl_communicator_equal_the_plain_step():

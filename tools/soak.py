@@ -27,20 +27,21 @@ def main():
     buckets = int(sys.argv[3]) if len(sys.argv) > 3 else 1        # message B: 1 = on the compute stream (the default), > 1 = SNP-range buckets
     M, N = 60_000, 4000
     ks = [int(v) for v in os.environ.get("NADM_SOAK_KS", "8").split(",")]
-    prod, ref = _engines(M, ks, 1024, N, seed=101)
+    sizes = tuple(int(v) for v in os.environ.get("NADM_SOAK_SIZES", "800,790,37,800,128,1").split(","))   # 4200,4100,37,4200: pass 3 in sample slices too
+    N = max(N, max(sizes) + 100)
+    prod, ref = _engines(M, ks, 1024, N, seed=101, bmax=max(sizes))
     dev = prod.device
     if dp:
         import neural_admixture_amd as na
         from neural_admixture_amd.comm import rccl_comm
         comm = rccl_comm(0, 1)
-        e = na.Engine(M, 8, 1024, ks, dev, 800, mode="dp", comm=comm, n_buckets=buckets)
+        e = na.Engine(M, 8, 1024, ks, dev, max(sizes), mode="dp", comm=comm, n_buckets=buckets)
         assert e.lay.n_buckets == buckets
         e.pflat.copy_(prod.pflat)
         e.set_packed(prod.xp)
         prod = e
     step_ref = (lambda idx, b, wl: ref.train_step(idx, b, 2e-3, wl)) if dp else (lambda idx, b, wl: unfused_step(ref, idx, b, 2e-3, wl))
     gen = torch.Generator().manual_seed(11)
-    sizes = (800, 790, 37, 800, 128, 1)
     t0 = time.time()
     bad = None
     for s in range(steps):
@@ -63,7 +64,7 @@ def main():
             f"and loss sums {'BIT-IDENTICAL' if ok else 'DIFFER'}; group counters zero; {time.time() - t0:.0f} s")
     print(line)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", (f"r06_soak_dp_b{buckets}" if dp else "r06_soak") + ("" if ks == [8] else "_k" + "_".join(map(str, ks))) + ".txt"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", (f"r06_soak_dp_b{buckets}" if dp else "r06_soak") + ("" if ks == [8] else "_k" + "_".join(map(str, ks))) + ("" if max(sizes) == 800 else f"_b{max(sizes)}") + ".txt"), "w") as f:
         f.write(line + "\n")
     return 0 if ok else 1
 
