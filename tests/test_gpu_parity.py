@@ -643,6 +643,8 @@ def _end_of_run_vs_reference(Gm, p, d, batch, lr, seed):
     ep = int(d["epochs"])
     Qs, Ps, model, tr = _run_trajectory(Gm, p, ep, batch, lr, seed)
     ll = loglikelihood_packed(tr.engine, torch.from_numpy(Gm), Ps[0], Qs[0])
+    dq, ref_dq = np.abs(Qs[0] - d["hi_Q"]), np.abs(d["med_Q"] - d["hi_Q"])
+    print(f"end of run ({ep} epochs): max |dQ| {dq.max():.3e} (reference's bf16 run {ref_dq.max():.3e}), mean {dq.mean():.3e} ({ref_dq.mean():.3e})")
     check_end_of_run(Qs[0], Ps[0], [tr.epoch_losses[e_] for e_ in range(ep)], ll, d, worst_sample_factor=2.0)
 
 
