@@ -637,7 +637,7 @@ def _end_of_run_vs_reference(Gm, p, d, batch, lr, seed):
     """A run of the PRODUCTION path (NeuralAdmixture.launch_training on the HIP engine: fused epilogues, deferred small update,
     prefetched epoch orders) of the fixture's length, held to SURVEY 8c's end-of-run bounds against the reference's fp32 run
     (tests/test_oracle_golden.check_end_of_run: mean |dQ| <= 1e-2, max |dP| <= 1e-2, per-epoch loss <= 1e-3 rel, log-likelihood
-    <= 1e-4 rel, and closer to it than the reference's own bf16 run is)."""
+    <= 1e-4 rel, and closer to it than the reference's own bf16 run is -- on average AND in the worst sample)."""
     from neural_admixture_amd.report import loglikelihood_packed
     from test_oracle_golden import check_end_of_run
     ep = int(d["epochs"])
@@ -645,7 +645,9 @@ def _end_of_run_vs_reference(Gm, p, d, batch, lr, seed):
     ll = loglikelihood_packed(tr.engine, torch.from_numpy(Gm), Ps[0], Qs[0])
     dq, ref_dq = np.abs(Qs[0] - d["hi_Q"]), np.abs(d["med_Q"] - d["hi_Q"])
     print(f"end of run ({ep} epochs): max |dQ| {dq.max():.3e} (reference's bf16 run {ref_dq.max():.3e}), mean {dq.mean():.3e} ({ref_dq.mean():.3e})")
-    check_end_of_run(Qs[0], Ps[0], [tr.epoch_losses[e_] for e_ in range(ep)], ll, d, worst_sample_factor=2.0)
+    # r06: the production path is held to the yardstick itself, worst sample included (r04-r05 allowed 2 x): measured 5.82e-2 against the
+    # reference's 6.03e-2 on the 250-epoch demo, 1.14e-2 against 4.80e-2 on the 60-epoch miniature -- and the kernels are bit-reproducible
+    check_end_of_run(Qs[0], Ps[0], [tr.epoch_losses[e_] for e_ in range(ep)], ll, d, worst_sample_factor=1.0)
 
 
 def test_default_horizon_demo_250_epochs_vs_reference():
