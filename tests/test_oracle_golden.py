@@ -231,3 +231,23 @@ def test_long_horizon_multibatch_60_epochs():
     p = O.make_params(int(m["seed"]), m["V0"], m["P0"], int(m["Hd"]), [int(m["K"])])
     p, Qs, losses = O.train_run(Gm, p, int(d["epochs"]), int(m["b"]), float(m["lr"]), int(m["seed"]))
     check_end_of_run(Qs[0], p.P[0], losses, O.loglikelihood(Gm, p.P[0], Qs[0]), d)
+
+
+def test_oracle_first_step_at_configs1_full_width():
+    """The oracle pinned against the reference itself at a BASELINE width (r06): the first step (800 rows) of configs[1]'s
+    trajectory fixture (2504 x 600k, K = 7; inputs regenerated from the seed, tests/golden/seeded_inputs.py) -- per-step loss against the
+    loss the reference's launch_training recorded.  (~1.5 minutes, ~12 GB: the whole 20-step trajectory is the GPU suite's,
+    tests/test_c2_full_width.py.)"""
+    import sys
+    sys.path.insert(0, G)
+    import seeded_inputs as SI
+    d = np.load(f"{G}/c2_trajectory.npz")
+    N, M, K, C = int(d["N"]), int(d["M"]), int(d["K"]), int(d["C"])
+    Gm = SI.genotypes(N, M, K, int(d["seed"]), threads=min(16, os.cpu_count() or 8))
+    assert SI.sha(Gm) == str(d["sha_G"])
+    V0, P0 = SI.init_v_p(M, C, K, int(d["seed"]))
+    assert SI.sha(V0) == str(d["sha_V0"]) and SI.sha(P0) == str(d["sha_P0"])
+    p = O.make_params(int(d["run_seed"]), V0, P0, int(d["Hd"]), [K])
+    perm = O.EpochOrder(N, int(d["run_seed"]), 1).next_epoch()
+    loss, grads, _ = O.step_grads(p, Gm[perm[:800]])
+    assert abs(loss - float(d["hi_losses"][0])) / float(d["hi_losses"][0]) < 2e-6, (loss, float(d["hi_losses"][0]))
