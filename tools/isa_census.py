@@ -146,7 +146,7 @@ def main():
     print("overhead     " + ", ".join(f"{k} {v}" for k, v in sorted(left.items(), key=lambda x: -x[1]) if v > 0))
     print("\nbucket                        per round   per genotype")
     for bk in ("decode", "gradient", "loss", "bf16 split", "address / mask / overhead"):
-        print(f"{bk:28s} {bucket[bk] + (missing if bk == 'gradient' and False else 0):8d}     {bucket[bk] / per_lane:6.3f}")
+        print(f"{bk:28s} {bucket[bk]:8d}     {bucket[bk] / per_lane:6.3f}")
     print(f"{'hot loop total':28s} {valu(H):8d}     {valu(H) / per_lane:6.3f}")
     print(f"\n# outside the hot loop, per genotype: tile staging {valu(T) * tiles / geno:.3f} (commit: clean_codes x 4, masks, LDS / batch-copy stores; dQ slab rows summed over "
           f"the waves), block prologue + epilogue {(valu(P) + valu(E) + extra) / geno:.3f} (P rows -> bf16 operand pieces; dP fold, Adam + clamp on the block's P rows)")
