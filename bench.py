@@ -619,10 +619,23 @@ def main():
         for s in range(min(args.steps, 20)):
             step(n_ramp + args.warmup + args.steps + s)
         eng.sync()
+        torch.cuda.synchronize()
         for name, v in eng.kernel_ms().items():
             if name != "decode_bce":
                 kms[name] = v
     eng.time_kernels(None)
+    # the dominant kernel clocks itself (r06), straight behind the timed region and NOT inside it: while a probe pointer is set pass 2 runs its
+    # measurement build (the block in the middle of the grid reads s_memtime / s_memrealtime around its work) -- the timed steps run the kernel
+    # without it
+    from neural_admixture_amd._lib import lib as _nlib, ptr as _ptr
+    clk_probe = torch.zeros(2, dtype=torch.int64, device=dev)
+    _nlib.nadm_clock_probe(_ptr(clk_probe))
+    for s in range(20):
+        step(n_ramp + args.warmup + args.steps + 20 + s)
+    eng.sync()
+    torch.cuda.synchronize()
+    _nlib.nadm_clock_probe(None)
+    probe_cycles, probe_ticks = (int(v) for v in clk_probe.cpu())
     # the host's cost of queueing a step, measured where the GPU cannot hide it: steps queued back to back onto an idle device
     torch.cuda.synchronize()
     t_h = time.perf_counter()
@@ -631,6 +644,11 @@ def main():
     host_queue_ms = (time.perf_counter() - t_h) / 20 * 1e3
     torch.cuda.synchronize()
     box = box_fingerprint(dev)                              # the chip is warm from the timed region: what this box sustains (r06)
+    if box is not None:
+        # ... and what it sustained under the dominant kernel itself, measured INSIDE that kernel during the timed region (pass 2's S = 1
+        # form; None for the other forms): denser than the calibration stream, pass 2 clocks lower, and by how much differs box to box
+        box["dominant_kernel_sclk_ghz"] = probe_cycles / probe_ticks * box["wall_clock_khz"] * 1e3 / 1e9 if probe_ticks > 0 else None
+        box["dominant_kernel_probe_block_us"] = probe_ticks / (box["wall_clock_khz"] * 1e3) * 1e6 if probe_ticks > 0 else None
     if box is not None and world > 1:
         clocks = [None] * world
         dist.all_gather_object(clocks, (box["effective_sclk_ghz"], box["calib_ms"]))
@@ -695,13 +713,12 @@ def main():
     if sq is not None:
         # SQ_INSTS_VALU / SQ_INSTS_MFMA are summed over the shader engines by rocprofv3's per-dispatch record
         valu, mfma = sq["valu_insts_per_launch"], sq["mfma_insts_per_launch"]
-        # the shader clock is MEASURED in this run (box_fingerprint: s_memtime against the constant-rate clock under an issue-bound
-        # load), not assumed; no "peak" instruction rate is claimed (an instruction costs 2.9-8.3 cycles by its class): the figure is the
+        # the shader clock is MEASURED in this run (s_memtime against the constant-rate clock inside pass 2 itself), not assumed; no "peak" instruction rate is claimed (an instruction costs 2.9-8.3 cycles by its class): the figure is the
         # VALU wave-instructions each SIMD issued per shader cycle of THIS run's launch -- times the mix's mean cost it is valu_busy_frac
-        clk = box["effective_sclk_ghz"] if box is not None and box.get("effective_sclk_ghz") else None
+        clk = (box.get("dominant_kernel_sclk_ghz") or box.get("effective_sclk_ghz")) if box is not None else None
         simd_cycles = sq.get("busy_cycles_sum_over_se", 0.0) * 32.0        # SQ_BUSY_CYCLES is per shader engine (32 SIMDs each)
         issue = {"valu_insts_per_genotype": valu * 64.0 / genotypes_launch, "mfma_insts_per_64_genotypes": mfma * 64.0 / genotypes_launch,
-                 "valu_wave_insts_per_launch": valu, "sclk_ghz": clk, "sclk_source": "measured in this run (box.effective_sclk_ghz)",
+                 "valu_wave_insts_per_launch": valu, "sclk_ghz": clk, "sclk_source": "measured in this run: inside the dominant kernel (box.dominant_kernel_sclk_ghz), else the calibration stream's",
                  "valu_insts_per_simd_cycle": valu / t_dom / (N_SIMD * clk * 1e9) if clk else None,
                  "shader_cycles_per_launch_this_run": t_dom * clk * 1e9 if clk else None,
                  "shader_cycles_per_launch_profiled": simd_cycles / N_SIMD if simd_cycles else None,

@@ -42,7 +42,7 @@ extern "C" {
 #define NADM_MAX_K 64
 #define NADM_MAX_BUCKETS 8
 #define NADM_MAX_P2_SLICES 8   /* sample slices of pass 2 (nadm_decode_bce_sliced) */
-#define NADM_ABI_VERSION 13  /* 13: pass 3 in sample slices (nadm_encode_bwd_sliced, nadm_encode_slices(_max), nadm_encode_slab_floats, nadm_encode_bwd_chunks, nadm_plan_desc_t.p3_slab / p3_cnt); 12: nadm_test_force_slices / nadm_test_force_generic_mlp exist in the test build only (-DNADM_TEST_HOOKS), nadm_calib_clock / nadm_wall_clock_khz; 11: nadm_gmm_fit_means_dev, nadm_loglik_blocks counts 8 row slices per 1024-SNP block, nadm_decode_bce_sliced / nadm_decode_slices / nadm_decode_slab_floats / nadm_test_force_slices + nadm_plan_desc_t.p2_slab / p2_cnt (pass 2 in sample slices when the SNP chunks alone do not fill the chip); 10: message B of the sample-sharded step in SNP-range buckets (nadm_flat_layout takes n_buckets, nadm_flat_layout_t.bkt_*, nadm_plan_desc_t.n_buckets / p3_whole / comm_a / debug, nadm_encode_fwd_part, nadm_plan_bucket_ms), nadm_comm_t.async_error, nadm_comm_rccl_probe, nadm_comm_rccl with a watchdog (timeout_ms), a failed step poisons its plan; 9: nadm_step / nadm_plan_* / nadm_comm_* / nadm_flat_layout (the step as one call, sharded optimizer), nadm_test_force_generic_mlp; 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
+#define NADM_ABI_VERSION 14  /* 14: nadm_clock_probe; 13: pass 3 in sample slices (nadm_encode_bwd_sliced, nadm_encode_slices(_max), nadm_encode_slab_floats, nadm_encode_bwd_chunks, nadm_plan_desc_t.p3_slab / p3_cnt); 12: nadm_test_force_slices / nadm_test_force_generic_mlp exist in the test build only (-DNADM_TEST_HOOKS), nadm_calib_clock / nadm_wall_clock_khz; 11: nadm_gmm_fit_means_dev, nadm_loglik_blocks counts 8 row slices per 1024-SNP block, nadm_decode_bce_sliced / nadm_decode_slices / nadm_decode_slab_floats / nadm_test_force_slices + nadm_plan_desc_t.p2_slab / p2_cnt (pass 2 in sample slices when the SNP chunks alone do not fill the chip); 10: message B of the sample-sharded step in SNP-range buckets (nadm_flat_layout takes n_buckets, nadm_flat_layout_t.bkt_*, nadm_plan_desc_t.n_buckets / p3_whole / comm_a / debug, nadm_encode_fwd_part, nadm_plan_bucket_ms), nadm_comm_t.async_error, nadm_comm_rccl_probe, nadm_comm_rccl with a watchdog (timeout_ms), a failed step poisons its plan; 9: nadm_step / nadm_plan_* / nadm_comm_* / nadm_flat_layout (the step as one call, sharded optimizer), nadm_test_force_generic_mlp; 8: nadm_dz_image(_bytes), nadm_mlp_bwd_image; nadm_encode_bwd, nadm_encode_bwd_step, nadm_pca_project_t take the operand image of dZ / Y; 7: nadm_encode_fwd_step, nadm_sum_rows, dqpart of nadm_mlp_bwd is float* (folded in place); 6: nadm_mlp_fwd_images, nadm_decode_bce_images, nadm_q_image_bytes, nadm_encode_fwd_small; 5: nadm_adam_t.when, nadm_adam2, with_loss bit 1; 4: nadm_decode_bce_step, nadm_encode_bwd_step (nadm_adam_t, nadm_mlp_weights_t), nadm_small_grads; 3: nadm_decode_bce_gather; 2: nadm_mlp_bwd_weights, nadm_supervised_ce, nadm_pca_project(_t), nadm_loglik, nadm_savetxt_f32, nadm_decode_chunk_snps; grad_small of nadm_mlp_bwd may be NULL */
 
 /* Head table shared by the MLP entry points (mirror of NeuralEncoder/NeuralDecoder's ks list,
  * neural_admixture.py:27-29,66-76). Offsets are element offsets into the `small` flat buffer. */
@@ -529,6 +529,10 @@ int nadm_synth_packed(uint8_t* xp, int64_t rows, int64_t row0, int64_t M, int64_
  * waves per SIMD on every CU, `iters` rounds.  Block i writes out[2i] = shader cycles (s_memtime) and out[2i+1] = constant-rate ticks
  * (s_memrealtime, nadm_wall_clock_khz) it took: cycles / ticks x rate = the shader clock the box sustains under an issue-bound load.
  * Returns the number of reporting blocks (<= max_blocks), or a negative status.  `sink`: one float, never written. */
+/* Measurement only: with a non-NULL device pointer every following S = 1 launch of the matrix-core pass 2 has the block in the middle of its
+ * grid write out2[0] = shader cycles (s_memtime) and out2[1] = constant-rate ticks (s_memrealtime) it took: the clock the DOMINANT kernel
+ * itself ran at in this run.  NULL switches it off.  Process-wide (one process per GPU); a few scalar instructions in one block. */
+void nadm_clock_probe(uint64_t* out2_dev);
 int nadm_calib_clock(int32_t iters, uint64_t* out /* device [2 * max_blocks] */, int32_t max_blocks, float* sink, void* stream);
 int64_t nadm_wall_clock_khz(void);
 

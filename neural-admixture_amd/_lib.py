@@ -158,6 +158,7 @@ def _load():
         "nadm_plan_poisoned": (i32, [vp]),
         "nadm_calib_clock": (C.c_int, [i32, vp, i32, vp, vp]),
         "nadm_wall_clock_khz": (i64, []),
+        "nadm_clock_probe": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
@@ -166,7 +167,7 @@ def _load():
     for name in ("nadm_test_force_slices", "nadm_test_force_generic_mlp", "nadm_test_force_p3_slices"):      # the TEST build only (csrc/libnadm_testhooks.so, -DNADM_TEST_HOOKS)
         if hasattr(lib, name):
             getattr(lib, name).restype, getattr(lib, name).argtypes = None, [i32]
-    if lib.nadm_abi_version() != 13:
+    if lib.nadm_abi_version() != 14:
         raise RuntimeError("neural_admixture_amd: libnadm.so ABI version mismatch")
     return lib, tuple(sig)
 

@@ -770,13 +770,23 @@ constexpr int BF_TS = NADM_BF_TS;       // samples per LDS tile
 // of being split from the fp32 Q by every block: same bf16 pieces, same results.
 // SLICED: the sample-slice form (gridDim.y slices, see the head of the body); false compiles the S = 1 kernel exactly as it stood before
 // the slices existed (the headline shape's launch: on an A/B box the merged form cost it 1.2 %, profiles/r05_ablations.txt item 11)
-template <int KP, bool LOSS, bool UNIT_P = true, bool QIMG = false, bool SLICED = false>
+// PROBE: the measurement build of the S = 1 form (nadm_clock_probe): launched only while a probe pointer is set, so that the kernel every
+// other launch runs is instruction for instruction the one without it (as an always-present run-time branch the probe cost 0.8 %: an extra
+// scalar load + wait in the prologue)
+template <int KP, bool LOSS, bool UNIT_P = true, bool QIMG = false, bool SLICED = false, bool PROBE = false>
 __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(bf_wpe(KP), bf_wpe(KP)))) void decode_bce_bf16_kernel(
     const uint8_t* __restrict__ xp, int64_t ld, const int32_t* __restrict__ idx, int b, int64_t M,
     float* P, const float* __restrict__ Q, int SP,
     float* __restrict__ dP, float* __restrict__ dqpart, float* __restrict__ losspart, uint8_t* __restrict__ xg, AdamFused ad,
-    const uint4* __restrict__ qimg, float* slab, int* slice_cnt) {
+    const uint4* __restrict__ qimg, float* slab, int* slice_cnt, unsigned long long* clk) {
     static_assert(KP <= 16, "one or two 8-wide k slots");
+    // measurement only (nadm_clock_probe, bench.py "box"): the block in the middle of the grid brackets itself with the shader-cycle counter
+    // (s_memtime) and the constant-rate one (s_memrealtime): cycles / ticks x rate = the clock THIS kernel ran at in THIS run -- a denser
+    // stream than any calibration kernel, it clocks lower on the same box, and by how much is the box's business (S = 1 form only)
+    static_assert(!(PROBE && SLICED), "the probe brackets the S = 1 form");
+    const bool probe = PROBE && clk != nullptr && blockIdx.x == (gridDim.x >> 1);
+    unsigned long long pc0 = 0, pr0 = 0;
+    if (probe) { pc0 = __builtin_readcyclecounter(); pr0 = __builtin_amdgcn_s_memrealtime(); }
     // gridDim.y = S sample SLICES (r05): with few SNP chunks (M below ~130k) a launch lasts as long as one block's serial chain over all the
     // sample tiles, not as long as the chip needs -- the batch's sample tiles are dealt to S blocks per chunk.  Everything a block writes is per sample (dQ slab rows, the batch copy) except dP and
     // the loss value: every slice parks its partial [chunk SNPs x KP] sum (+ its loss partial) in `slab`, is counted, and the block that
@@ -1224,6 +1234,10 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                 losspart[chunk] = tot;
             }
         }
+        if (probe && tid == 0) {
+            clk[0] = __builtin_readcyclecounter() - pc0;
+            clk[1] = __builtin_amdgcn_s_memrealtime() - pr0;
+        }
         return;
     }
     float my_loss = 0.f;
@@ -1615,6 +1629,10 @@ static int launch_gather_rows(const uint8_t* xp, int64_t ld, const int32_t* idx,
     return check_launch("gather_rows");
 }
 
+// measurement only: where pass 2's probe block leaves its two counter differences (NULL: no probe).  Process-wide, like the launches' device.
+static std::atomic<unsigned long long*> g_clock_probe{nullptr};
+extern "C" void nadm_clock_probe(uint64_t* out2_dev) { g_clock_probe.store(reinterpret_cast<unsigned long long*>(out2_dev)); }
+
 template <int KP>
 static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx, int b, int64_t M, float* P,
                               const float* Q, int SP, float* dP, float* dqpart, float* losspart, int with_loss,
@@ -1623,14 +1641,18 @@ static int launch_decode_mfma(const uint8_t* xp, int64_t ld, const int32_t* idx,
     const int64_t chunks = (M + mf_chunk_snps(KP) - 1) / mf_chunk_snps(KP);
     dim3 grid((unsigned)chunks, (unsigned)n_slices), block(64 * BF_WAVES);
     constexpr bool CAN_IMG = BF_TS == QI_TS;                 // (variant builds with another tile depth: decode_bce_impl refuses qimg)
+    unsigned long long* const clk_probe = g_clock_probe.load();
 #define NADM_P2_LAUNCH(...)                                                                                                                     \
     do {                                                                                                                                       \
         if (n_slices > 1)                                                                                                                      \
             hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, __VA_ARGS__, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart,   \
-                               losspart, xg, ad, qimg, slab, slice_cnt);                                                                      \
+                               losspart, xg, ad, qimg, slab, slice_cnt, (unsigned long long*)nullptr);                                        \
+        else if (clk_probe != nullptr)                                                                                                         \
+            hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, __VA_ARGS__, false, true>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP,    \
+                               dqpart, losspart, xg, ad, qimg, slab, slice_cnt, clk_probe);                                                    \
         else                                                                                                                                   \
             hipLaunchKernelGGL((decode_bce_bf16_kernel<KP, __VA_ARGS__, false>), grid, block, 0, st, xp, ld, idx, b, M, P, Q, SP, dP, dqpart,  \
-                               losspart, xg, ad, qimg, slab, slice_cnt);                                                                      \
+                               losspart, xg, ad, qimg, slab, slice_cnt, (unsigned long long*)nullptr);                                        \
     } while (0)
     if (with_loss & 2) {        // loss value with P possibly outside [0, 1] (before the first restrict_P)
         if (qimg) NADM_P2_LAUNCH(true, false, CAN_IMG); else NADM_P2_LAUNCH(true, false, false);

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for name in hooks:                                   # the laboratory is not in the product
         assert not hasattr(raw, name) and hasattr(test_build, name)
     assert declared == set(_lib.EXPORTS)               # the Python binding covers the whole header
-    assert _lib.lib.nadm_abi_version() == 13
+    assert _lib.lib.nadm_abi_version() == 14
 
 
 def test_argument_validation_without_gpu():

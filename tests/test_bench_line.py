@@ -46,7 +46,7 @@ def test_bench_share_gpu_runs_every_leg_and_prints_one_valid_line(world):
 @pytest.mark.gpu
 def test_bench_one_gpu_line_carries_a_measured_clock_and_a_box_fingerprint():
     import bench
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "8000", "--snps", "100000", "--steps", "5", "--warmup", "2",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "8000", "--snps", "200000", "--steps", "5", "--warmup", "2",
                         "--ramp-ms", "50", "--no-cpu-baseline", "--no-epoch-loop"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
@@ -54,3 +54,5 @@ def test_bench_one_gpu_line_carries_a_measured_clock_and_a_box_fingerprint():
     box = d["box"]
     assert 1.0 < box["effective_sclk_ghz"] < 2.6 and box["calib_ms"] > 0.1 and 2000 < box["copy_gbs"] < 8000
     assert box["wall_clock_khz"] == 100000.0
+    assert 1.0 < box["dominant_kernel_sclk_ghz"] <= box["effective_sclk_ghz"] * 1.03            # pass 2 clocks itself; denser than the calibration stream
+    assert d["roofline"]["issue"] is None or d["roofline"]["issue"]["sclk_ghz"] == box["dominant_kernel_sclk_ghz"]
