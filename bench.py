@@ -101,6 +101,8 @@ def parse():
     ap.add_argument("--alt-steps", type=int, default=50, help="timed steps of every alternative leg")
     ap.add_argument("--alt-warmup", type=int, default=10, help="untimed steps in front of every alternative leg")
     ap.add_argument("--coll-reps", type=int, default=20, help="timed repetitions of every collective of the micro-benchmark")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the 20 steps behind the timed region in which pass 2 clocks itself (profiling passes: "
+                                                                  "only the kernels of the timed steps)")
     ap.add_argument("--no-epoch-loop", action="store_true", help="skip the production epoch loop behind the timed region (profiling passes: only the K-step kernels)")
     ap.add_argument("--cpu-rows", type=int, default=2400, help="rows of the same workload used for the bounded CPU baseline")
     ap.add_argument("--cpu-steps", type=int, default=12, help="timed steps of the CPU baseline (min / median / max reported)")
@@ -629,12 +631,13 @@ def main():
     # without it
     from neural_admixture_amd._lib import lib as _nlib, ptr as _ptr
     clk_probe = torch.zeros(2, dtype=torch.int64, device=dev)
-    _nlib.nadm_clock_probe(_ptr(clk_probe))
-    for s in range(20):
-        step(n_ramp + args.warmup + args.steps + 20 + s)
-    eng.sync()
-    torch.cuda.synchronize()
-    _nlib.nadm_clock_probe(None)
+    if not args.no_clock_probe:
+        _nlib.nadm_clock_probe(_ptr(clk_probe))
+        for s in range(20):
+            step(n_ramp + args.warmup + args.steps + 20 + s)
+        eng.sync()
+        torch.cuda.synchronize()
+        _nlib.nadm_clock_probe(None)
     probe_cycles, probe_ticks = (int(v) for v in clk_probe.cpu())
     # the host's cost of queueing a step, measured where the GPU cannot hide it: steps queued back to back onto an idle device
     torch.cuda.synchronize()

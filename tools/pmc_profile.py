@@ -42,7 +42,7 @@ def run_pass(counters, tag, bench_flags):
     shutil.rmtree(d, ignore_errors=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc", *counters, "-d", d, "-o", "run", "--", sys.executable, os.path.join(ROOT, "bench.py"),
-           "--steps", "5", "--warmup", "2", "--ramp-ms", "0", "--no-cpu-baseline", "--no-epoch-loop", *bench_flags]
+           "--steps", "5", "--warmup", "2", "--ramp-ms", "0", "--no-cpu-baseline", "--no-epoch-loop", "--no-clock-probe", *bench_flags]
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     dbs = [os.path.join(p, f) for p, _, fs in os.walk(d) for f in fs if f.endswith(".db")]

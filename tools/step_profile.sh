@@ -5,7 +5,7 @@ tag=${1:-r02}; shift
 R=$PWD; export TMPDIR=/tmp
 mkdir -p gpurun_out
 out=gpurun_out/${tag}_kernel_stats.txt
-cmd="python $R/bench.py --steps 100 --warmup 60 --ramp-ms 0 --no-cpu-baseline --no-epoch-loop $*"
+cmd="python $R/bench.py --steps 100 --warmup 60 --ramp-ms 0 --no-cpu-baseline --no-epoch-loop --no-clock-probe $*"
 echo "# $cmd   (first 60 calls of every kernel = the untimed warm-up, left out of the table)" > $out
 $cmd 2>/dev/null | python3 -c "
 import json,sys
