@@ -100,6 +100,9 @@ def parse():
     ap.add_argument("--no-alt", action="store_true", help="N > 1: only the headline")
     ap.add_argument("--alt-steps", type=int, default=50, help="timed steps of every alternative leg")
     ap.add_argument("--alt-warmup", type=int, default=10, help="untimed steps in front of every alternative leg")
+    ap.add_argument("--alt-deadline", type=float, default=420.0,
+                    help="seconds the alternative legs may take in all; past it rank 0 prints the headline line without them (alt_error says so) "
+                         "and every rank leaves -- a stuck leg must not cost the run its headline")
     ap.add_argument("--coll-reps", type=int, default=20, help="timed repetitions of every collective of the micro-benchmark")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the 20 steps behind the timed region in which pass 2 clocks itself (profiling passes: "
                                                                   "only the kernels of the timed steps)")
@@ -796,8 +799,35 @@ def main():
     if ((world > 1 and not args.no_alt) or args.alt) and not snp and args.emulate_world is None:
         headline = {"ms_per_step": out["ms_per_step"], "value": out["value"], "unit": "genotypes/s", "steps": args.steps,
                     "rows_per_rank_per_step": b, "global_batch": b * world}
-        with stdout_to_stderr():                                        # (the legs create communicators)
-            out["alt"], out["collectives"] = alt_legs(args, eng, comm if ddp else None, dev, world, rank, ks, headline)
+        # The legs come behind a measured headline and must never cost it: a deadline of their own (a leg that hangs -- a collective that
+        # never completes, a second communicator that does not come up) and a catch-all (a leg that raises) both end in rank 0 printing the
+        # line it already has, with alt_error saying what happened, and every rank leaving.
+        import threading
+
+        def _headline_only(why):
+            if rank == 0:
+                line = dict(out, alt=None, collectives=None, alt_error=why)
+                os.write(saved_stdout_fd, (json.dumps(line) + "\n").encode())
+            sys.stderr.write(f"[bench] rank {rank}: {why}\n")
+            sys.stderr.flush()
+            os._exit(0)
+        saved_stdout_fd = os.dup(1)                                     # (stdout itself points at stderr while the legs run)
+        alt_guard = threading.Timer(max(1.0, args.alt_deadline), _headline_only,
+                                    args=(f"the alternative legs did not complete within {args.alt_deadline:.0f} s: headline only",))
+        alt_guard.daemon = True
+        alt_guard.start()
+        try:
+            with stdout_to_stderr():                                    # (the legs create communicators)
+                out["alt"], out["collectives"] = alt_legs(args, eng, comm if ddp else None, dev, world, rank, ks, headline)
+        except BaseException as e:                                      # noqa: BLE001 -- whatever it was, the headline goes out
+            if rank == 0 or world == 1:
+                _headline_only(f"the alternative legs failed on rank {rank} ({type(e).__name__}: {e}): headline only")
+            sys.stderr.write(f"[bench] rank {rank}: alternative legs failed ({type(e).__name__}: {e}); waiting for the deadline\n")
+            sys.stderr.flush()
+            time.sleep(max(1.0, args.alt_deadline) + 5.0)               # the other ranks are inside a leg: all leave at the deadline
+            os._exit(0)
+        alt_guard.cancel()
+        os.close(saved_stdout_fd)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and len(ks) == 1 and args.emulate_world is None:
             out["cpu_baseline"] = cpu_baseline(eng, args, dev)

@@ -56,3 +56,19 @@ def test_bench_one_gpu_line_carries_a_measured_clock_and_a_box_fingerprint():
     assert box["wall_clock_khz"] == 100000.0
     assert 1.0 < box["dominant_kernel_sclk_ghz"] <= box["effective_sclk_ghz"] * 1.03            # pass 2 clocks itself; denser than the calibration stream
     assert d["roofline"]["issue"] is None or d["roofline"]["issue"]["sclk_ghz"] == box["dominant_kernel_sclk_ghz"]
+
+
+@pytest.mark.gpu
+def test_bench_prints_its_headline_when_the_alternative_legs_run_out_of_time():
+    """A stuck or slow leg must not cost a multi-GPU run its headline: with a 1-second deadline for the legs rank 0 still prints ONE valid
+    line -- the headline, alt = null, alt_error saying why -- and the launcher exits 0."""
+    import bench
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--rows", "8000", "--snps", "40000",
+                        "--steps", "3", "--warmup", "1", "--ramp-ms", "0", "--alt-steps", "200", "--alt-deadline", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["alt"] is None and "did not complete within" in d["alt_error"] and d["value"] > 0 and d["n_gpus"] == 2
+    assert [p for p in bench.validate_line(d, 2) if not p.startswith(("alt.", "collectives."))] == []
