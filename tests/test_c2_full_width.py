@@ -176,3 +176,33 @@ def test_c4_width_one_epoch_against_the_reference():
     assert rel_loss.max() < 5e-5 and dq < 2e-3 and dp < 1e-2
     assert dq < float(d["med_dQ"]) and dp < float(d["med_dP"]) and dv <= float(d["med_dV"])
     assert np.allclose(Ps[0].astype(np.float64).sum(0), d["hi_P_colsum"], rtol=2e-5)
+
+
+def test_c2_cli_from_a_bed_file_against_the_reference(c2_matrix, tmp_path):
+    """The callers either side of the path at configs[1]'s size: `python -m neural_admixture_amd train` on the matrix as a PLINK .bed file
+    (.bed -> packed rows by the device transposition, RSVD from the packed matrix, mixture init, 5 epochs, `.Q` / `.P` writers) against the
+    reference's end-to-end run (c2_end_to_end.npz), held to the same bounds as the boundary call."""
+    from neural_admixture_amd import cli
+    _dev()
+    d = np.load(f"{GOLD}/c2_end_to_end.npz")
+    G = c2_matrix.numpy()
+    N, M, K = G.shape[0], G.shape[1], int(d["K"])
+    inv = np.array([3, 2, 0, 1], dtype=np.uint8)           # genotype code -> PLINK 2-bit code (inverse of utils.pyx:52's table [2, 3, 1, 0])
+    bed = np.zeros((M, (N + 3) // 4), dtype=np.uint8)
+    for i in range(N):
+        bed[:, i // 4] |= (inv[G[i]] << (2 * (i % 4))).astype(np.uint8)
+    with open(tmp_path / "c2.bed", "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x01]))
+        bed.tofile(f)
+    (tmp_path / "c2.fam").write_text("\n".join(["s"] * N) + "\n")
+    out = tmp_path / "out"
+    assert cli.main(["train", "--epochs", str(int(d["epochs"])), "--k", str(K), "--name", "run", "--data_path", str(tmp_path / "c2.bed"),
+                     "--save_dir", str(out), "--seed", str(int(d["run_seed"])), "--num_gpus", "1", "--threads", "4"]) == 0
+    Q = np.loadtxt(out / f"run.{K}.Q").astype(np.float32)
+    P = np.loadtxt(out / f"run.{K}.P", usecols=range(K), max_rows=None).astype(np.float32)
+    rows = SI.sample_rows(M, int(d["nrows"]), int(d["seed"]))
+    dq, dp = mx(Q, d["hi_Q"]), mx(P[rows], d["hi_P_rows"])
+    print(f"c2 CLI from .bed: dQ {dq:.2e} (mean {np.abs(Q - d['hi_Q']).mean():.2e}), dP {dp:.2e}")
+    assert Q.shape == (N, K) and P.shape == (M, K)
+    assert dq < mx(d["med_Q"], d["hi_Q"]) and float(np.abs(Q - d["hi_Q"]).mean()) < float(np.abs(d["med_Q"] - d["hi_Q"]).mean())
+    assert dp < 1e-2 and dp < mx(d["med_P_rows"], d["hi_P_rows"])
