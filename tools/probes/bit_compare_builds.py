@@ -4,7 +4,7 @@ sys.path.insert(0, "/root/repo")
 import neural_admixture_amd as na
 from oracle import nadm_oracle as O
 dev = torch.device("cuda:0")
-for (N, M, ks, b) in ((900, 70_001, [8], 800), (300, 5003, [3], 100), (500, 20_000, [2, 5, 8], 333), (900, 40_000, [7], 800)):
+for (N, M, ks, b) in ((900, 70_001, [8], 800), (300, 5003, [3], 100), (500, 20_000, [2, 5, 8], 333), (4500, 20_000, [7], 4301), (4400, 9_000, [2, 3, 9], 4099)):
     G = O.synth_genotypes(N, M, max(ks), seed=5, missing=0.02)
     rng = np.random.default_rng(1)
     V0 = (rng.standard_normal((M, 8)) / np.sqrt(M)).astype(np.float32)
