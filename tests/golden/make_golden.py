@@ -512,12 +512,13 @@ def case_c2_end_to_end_t4():
     np.savez_compressed(os.path.join(OUT, "c2_end_to_end_t4.npz"), **out)
 
 
-def case_c4_trajectory():
+def case_c4_trajectory(name="c4_trajectory", N=8000, M=500_000, K=8, seed=2027):
     """configs[3]'s MODEL at its width against the reference itself: K = 8, M = 500k, batch 800 -- the bench's step -- on 8000 seeded samples
     (the reference needs ~45 s per 10 steps here; the full 100k rows would take 9 minutes per epoch), one epoch = 10 steps from a seeded
-    V0 / P0.  'hi' outputs stored; of 'med' (the reference as it ships) only its distances from 'hi' -- the yardstick."""
+    V0 / P0.  'hi' outputs stored; of 'med' (the reference as it ships) only its distances from 'hi' -- the yardstick.
+    c5_trajectory: the same for configs[4]'s model -- K = 16 (pass 2's two-k-slot form), M = 1M -- on 2400 samples = 3 steps."""
     import seeded_inputs as SI
-    N, M, K, C, seed = 8000, 500_000, 8, 8, 2027
+    C = 8
     G = SI.genotypes(N, M, K, seed)
     V0, P0 = SI.init_v_p(M, C, K, seed)
     out = dict(sha_G=SI.sha(G), sha_V0=SI.sha(V0), sha_P0=SI.sha(P0), N=N, M=M, K=K, C=C, seed=seed, Hd=1024, b=800, lr=2e-3, epochs=1, run_seed=42, nrows=4096)
@@ -526,13 +527,13 @@ def case_c4_trajectory():
     for mode in ("hi", "med"):
         Qs, Ps, sd, sl = run_reference_training(G, V0, P0, K, None, None, 1024, 1, 800, 2e-3, 42, mode)
         res[mode] = (Qs[0], Ps[0][rows], sd["V"][rows], sl, Ps[0].astype(np.float64).sum(0))
-        print("c4 trajectory", mode, sl[:3], sl[-1], flush=True)
+        print(name, mode, sl[:3], sl[-1], flush=True)
     out["hi_Q"], out["hi_P_rows"], out["hi_V_rows"], out["hi_losses"], out["hi_P_colsum"] = res["hi"]
     out["med_dQ"] = np.abs(res["med"][0] - res["hi"][0]).max()
     out["med_dP"] = np.abs(res["med"][1] - res["hi"][1]).max()
     out["med_dV"] = np.abs(res["med"][2] - res["hi"][2]).max()
     out["med_losses"] = res["med"][3]
-    np.savez_compressed(os.path.join(OUT, "c4_trajectory.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
 
 
 def case_c2_multihead():
@@ -583,6 +584,7 @@ if __name__ == "__main__":
         "c2_end_to_end_t4": case_c2_end_to_end_t4,
         "c2_multihead": case_c2_multihead,
         "c4_trajectory": case_c4_trajectory,
+        "c5_trajectory": lambda: case_c4_trajectory("c5_trajectory", N=2400, M=1_000_000, K=16, seed=2028),
     }
     for name in (sys.argv[1:] or list(cases)):            # no arguments: every fixture; else only the named cases
         cases[name]()

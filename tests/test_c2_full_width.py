@@ -155,11 +155,13 @@ def test_c2_multihead_epoch_against_the_reference(c2_matrix):
         assert np.allclose(Ps[h].astype(np.float64).sum(0), d[f"hi_P{h}_colsum"], rtol=2e-5)
 
 
-def test_c4_width_one_epoch_against_the_reference():
+@pytest.mark.parametrize("name", ["c4_trajectory", "c5_trajectory"])
+def test_c4_c5_width_one_epoch_against_the_reference(name):
     """configs[3]'s MODEL at its width -- K = 8, M = 500k, batch 800: the bench's step -- against the reference itself on 8000 seeded samples:
     one epoch = 10 steps of the production trainer from a seeded V0 / P0 (the reference takes ~45 s for them; its full 100k rows 9 minutes
-    per epoch).  'med' (the reference as it ships) is kept as its distances from 'hi' only."""
-    d = np.load(f"{GOLD}/c4_trajectory.npz")
+    per epoch); and configs[4]'s -- K = 16 (pass 2's two-k-slot form), M = 1M -- on 2400 samples = 3 steps.  'med' (the reference as it
+    ships) is kept as its distances from 'hi' only."""
+    d = np.load(f"{GOLD}/{name}.npz")
     N, M, K, C = int(d["N"]), int(d["M"]), int(d["K"]), int(d["C"])
     G = SI.genotypes(N, M, K, int(d["seed"]), threads=min(32, os.cpu_count() or 8))
     assert SI.sha(G) == str(d["sha_G"])
@@ -171,7 +173,7 @@ def test_c4_width_one_epoch_against_the_reference():
     V = model.state_dict()["V"].numpy()
     rel_loss = np.abs(np.asarray(tr.step_losses) - d["hi_losses"]) / d["hi_losses"]
     dq, dp, dv = mx(Qs[0], d["hi_Q"]), mx(Ps[0][rows], d["hi_P_rows"]), mx(V[rows], d["hi_V_rows"])
-    print(f"c4 width: loss rel max {rel_loss.max():.2e}, dQ {dq:.2e} (ref hi-med {float(d['med_dQ']):.2e}), dP {dp:.2e} ({float(d['med_dP']):.2e}), "
+    print(f"{name}: loss rel max {rel_loss.max():.2e}, dQ {dq:.2e} (ref hi-med {float(d['med_dQ']):.2e}), dP {dp:.2e} ({float(d['med_dP']):.2e}), "
           f"dV {dv:.2e} ({float(d['med_dV']):.2e})")
     assert rel_loss.max() < 5e-5 and dq < 2e-3 and dp < 1e-2
     assert dq < float(d["med_dQ"]) and dp < float(d["med_dP"]) and dv <= float(d["med_dV"])
