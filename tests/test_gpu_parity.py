@@ -431,6 +431,20 @@ def test_pair_product_loss_and_its_exact_fallback(ks):
         torch.cuda.synchronize()
         out.append(e.read_loss()[1])
     assert np.isfinite(out[0]) and abs(out[0] - out[1]) <= 2e-6 * abs(out[1])
+    # ... and called heterozygous in EVERY sample: where the reconstruction rounds above 1 both factors of a pair are d (1 - d) < 0 and
+    # their product is positive -- the factor's saturation (clamp on the blend) must still send the pair to the exact form, whose
+    # term is 50 per genotype there (log 1 and the -100 floor, halved)
+    G2 = Gm.copy()
+    G2[:, 200:230] = 1
+    out = []
+    for form in ("fast", "exact"):
+        e = make_engine(G2, p1, N)
+        e.p_unit = form == "fast"
+        e.forward(idx, N)
+        e.backward(idx, N, True)
+        torch.cuda.synchronize()
+        out.append(e.read_loss()[1])
+    assert np.isfinite(out[0]) and abs(out[0] - out[1]) <= 2e-6 * abs(out[1]), out
 
 
 def test_snp_subrange_launches_give_identical_gradients():
