@@ -211,6 +211,14 @@ __device__ __forceinline__ void q_image_put(uint16_t* __restrict__ img, const in
         uint16_t* d2 = img + (512 + (pair * 2 + 1) * 64) * 8 + e;
         d1[(q8 * 16 + qk) * 8] = (uint16_t)h;                                             // column qk of Qh / Qm
         d2[(q8 * 16 + qk) * 8] = (uint16_t)md;
+    } else if (kp <= 4) {                                                                 // one R^T instruction: slots [Qh|Qm Qh|Qm Ql|Qh 0], four k each
+        uint16_t* r1 = img + ((st * 2 + 0) * 64) * 8 + qk;
+        r1[(i) * 8] = (uint16_t)h;        r1[(i) * 8 + 4] = (uint16_t)md;
+        r1[(i + 16) * 8] = (uint16_t)h;   r1[(i + 16) * 8 + 4] = (uint16_t)md;
+        r1[(i + 32) * 8] = (uint16_t)lo;  r1[(i + 32) * 8 + 4] = (uint16_t)h;
+        uint16_t* d1 = img + (512 + pair * 64) * 8 + e;
+        d1[(q8 * 16 + qk) * 8] = (uint16_t)h;                                             // columns 0..7: Qh
+        d1[(q8 * 16 + qk + 8) * 8] = (uint16_t)md;                                        // columns 8..15: Qm
     } else {
         uint16_t* r1 = img + ((st * 2 + 0) * 64) * 8 + qk;
         uint16_t* r2 = img + ((st * 2 + 1) * 64) * 8 + qk;

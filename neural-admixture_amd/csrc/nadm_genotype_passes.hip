@@ -804,6 +804,9 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
     // against float64 at b = 800, M = 500k, K = 16 the gradients err by 7.6e-7 of their maximum with them and 8.8e-7 without, for
     // 3 % of the kernel: profiles/r05_ablations.txt item 7.  K <= 8 carries them for free.)
     constexpr bool W = KP > 8;
+    // ONE (KP <= 4, r06): the six product terms of R^T are 6 x 4 = 24 of an MFMA's 32 K values -- every 8-wide slot carries TWO pieces of
+    // four k each and ONE instruction forms R^T:  [Ph|Ph  Pm|Pm  Ph|Pl  0].[Qh|Qm  Qh|Qm  Ql|Qh  0]   (3 MFMAs per tile instead of 4)
+    constexpr bool ONE = KP <= 4;
     constexpr int KW = W ? 16 : 8;                       // k columns of the operand images
     static_assert(BF_NTW == 4 || BF_NTW == 2, "tile bits are read as one 32- or 16-bit word");
     constexpr int NTW = BF_NTW, MF_WAVES = BF_WAVES, MF_TS = BF_TS;
@@ -891,6 +894,11 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
             pa_r2[t] = Md;                                                                       // slots [Pm Pm' Pm Pm']
             pa_r3[t] = make_uint4((H.x & m01) | (Lo.x & ~m01), (H.y & m01) | (Lo.y & ~m01), (H.z & m01) | (Lo.z & ~m01),
                                   (H.w & m01) | (Lo.w & ~m01));                              // slots [Ph Ph' Pl Pl']
+        } else if constexpr (ONE) {
+            const uint32_t m2 = lt_mask(a, 3) & ~m01;                                            // a == 2
+            pa_r1[t] = make_uint4((H.x & (m0 | m2)) | (Md.x & m1), (H.y & (m0 | m2)) | (Md.y & m1),
+                                  (H.x & m0) | (Md.x & m1) | (Lo.x & m2), (H.y & m0) | (Md.y & m1) | (Lo.y & m2));   // slots [Ph|Ph Pm|Pm Ph|Pl 0]
+            pa_r2[t] = make_uint4(0, 0, 0, 0);
         } else {
             pa_r1[t] = make_uint4((H.x & m01) | (Md.x & ~m01), (H.y & m01) | (Md.y & ~m01), (H.z & m01) | (Md.z & ~m01),
                                   (H.w & m01) | (Md.w & ~m01));                              // slots [Ph Ph Pm Pm]
@@ -1002,9 +1010,17 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
             } else {
                 uint16_t* r1 = reinterpret_cast<uint16_t*>(&s_qr[st][0][0]) + qk;       // + lane*8 (uint16 units)
                 uint16_t* r2 = reinterpret_cast<uint16_t*>(&s_qr[st][1][0]) + qk;
+                if constexpr (ONE) {
+                    if (qk < 4) {
+                        r1[(i) * 8] = (uint16_t)h;        r1[(i) * 8 + 4] = (uint16_t)md;        // slot 0: Qh | Qm
+                        r1[(i + 16) * 8] = (uint16_t)h;   r1[(i + 16) * 8 + 4] = (uint16_t)md;   // slot 1: Qh | Qm
+                        r1[(i + 32) * 8] = (uint16_t)lo;  r1[(i + 32) * 8 + 4] = (uint16_t)h;    // slot 2: Ql | Qh
+                    }
+                } else {
                 r1[(i) * 8] = (uint16_t)h;        r1[(i + 32) * 8] = (uint16_t)h;            // slots 0,2: Qh
                 r1[(i + 16) * 8] = (uint16_t)md;  r1[(i + 48) * 8] = (uint16_t)md;           // slots 1,3: Qm
                 r2[(i) * 8] = (uint16_t)lo;       r2[(i + 16) * 8] = (uint16_t)h;            // slots 0,1: Ql, Qh
+                }
                 uint16_t* d1 = reinterpret_cast<uint16_t*>(&s_qd[pair][0][0]) + e;
                 d1[(q8 * 16 + qk) * 8] = (uint16_t)h;                                        // columns 0..7: Qh
                 d1[(q8 * 16 + qk + 8) * 8] = (uint16_t)md;                                   // columns 8..15: Qm
@@ -1045,7 +1061,7 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
         if constexpr (W) {
             D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r2[t]), as_bf16x8(q1), D, 0, 0, 0);
             D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r3[t]), as_bf16x8(q2), D, 0, 0, 0);
-        } else {
+        } else if constexpr (!ONE) {
             D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(pa_r2[t]), as_bf16x8(q2), D, 0, 0, 0);
         }
         return D;
