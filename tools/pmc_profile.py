@@ -69,6 +69,7 @@ def calibrate():
     """counted / known bytes per access pattern -> <round>_pmc_calib.json"""
     exe = os.path.join(ROOT, "tools", "abl", "calib")
     if not os.path.exists(exe):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", os.path.join(ROOT, "tools", "calib_fetch.hip"), "-o", exe], check=True)
     out = {"round": RND, "unit_note": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; ratio = counted KiB * 1024 / known bytes of the launch"}
     known = {}
