@@ -666,21 +666,28 @@ __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast
 //              from per-class means of the raw codes, which reach 2 (train.py:82).
 //     fast     (r03, bce_loss_prod2; UNIT_P only) ONE logarithm per PAIR of genotypes instead of four.  With c = 2x in {0, 1, 2}
 //              twice the term of a genotype is c*log d + (2-c)*log(1-d) = log f, f = (1-d)^2, d(1-d), d^2.  With o = sat(1 - d)
-//              (a v_sub with the clamp bit) and q = o - x:  q^2 = o^2 for x = 0 and d^2 for x = 1 (q = -d), and the heterozygous
-//              value is den = d(1-d), which the gradient has already formed:  f = qq + h * (den - qq),  qq = q^2,  h = [c == 1]
-//              (one more v_cvt_scalef32_pk_f32_fp4 of the masked code word) -- four packed instructions per pair, and the two
-//              f of a pair are multiplied before the one v_log.  o is clamped: with d > 1 by a rounding error a homozygous-
-//              reference genotype gives f = 0 like the reference's log(1 - clamp(d)), the heterozygous one f <= den < 0, the
-//              homozygous-alternative one f = 1 (log 1).  The product is 0, negative or underflows exactly when a clamp of
-//              the reference could be active or d is tiny -- then, and only then, the logarithm is -inf / NaN and the wave
-//              recomputes the loss of that tile pair with the exact form (cold branch in the loop, decode_bce_bf16_kernel).
+//              (a v_sub with the clamp bit) and q = o - x:  q = 1-d | 1/2 - d | -d  for c = 0 | 1 | 2, so q^2 IS f for the two
+//              homozygous calls, and for the heterozygous one d(1-d) = 1/4 - (1/2 - d)^2 = 1/4 - q^2.  Since x(1-x) = 0 | 1/4 | 0,
+//                  f = | q^2 - x(1-x) | = | fma(q, q, fma(x, x, -x)) |
+//              for all three -- two packed fmas per pair behind q, no selector, nothing taken from the gradient's chain -- and
+//              the two f of a pair are multiplied (the |.| are source modifiers of that v_mul) before the one v_log.  (r03-r06:
+//              f = qq + h * (den - qq) with den = d - d^2 from the gradient and a selector h = [c == 1] converted from a masked
+//              code word: one packed instruction + one conversion + 3/4 mask instruction more per pair and a dependence on the
+//              gradient's den; the form above took pass 2 from 247-249 to 236-237 us, profiles/r06_abl_lossabs.txt.)
+//              o is clamped: with d > 1 by a rounding error a homozygous-reference genotype gives f = 0 like the reference's
+//              log(1 - clamp(d)), the heterozygous one q = -1/2 and f = 0 as well, the homozygous-alternative one f = 1 (log 1);
+//              d = 0 or 1 exactly gives f = 0 under a call whose reference term is a clamped logarithm.  The product is 0 or
+//              underflows exactly when a clamp of the reference could be active or d is tiny -- then, and only then, the
+//              logarithm is -inf and the wave recomputes the loss of that tile pair with the exact form (cold branch in the loop,
+//              decode_bce_bf16_kernel; a NaN among the inputs takes the same branch).
 //              Accuracy: the factor under a non-zero genotype carries the ABSOLUTE rounding error of 1 - d (3e-8 for d < 1/2),
-//              i.e. 3e-8 / d relative -- against the fp32 accumulation of ~4e8 terms this is invisible in the sum (tests: 2e-6
-//              against the exact form, 5e-6 against the oracle), but a single term under d = 1e-6 is only good to 3 %; the
-//              exact form has no such error.  (First r03 version: u = o + s1 * (d - o) with two selectors and the product
-//              u * v: three instructions more per pair and twice that error.  Multiplying the products of the lane's two pairs
-//              of a tile as well -- one logarithm per four genotypes -- measured 250 us against 246: the longer dependent chain
-//              in front of the logarithm costs what the logarithm saves.)
+//              i.e. 3e-8 / d relative (heterozygous: the same 3e-8 on d(1-d), where den had an ulp) -- against the fp32
+//              accumulation of ~4e8 terms this is invisible in the sum (tests: 2e-6 against the exact form, 5e-6 against the
+//              oracle), but a single term under d = 1e-6 is only good to 3 %; the exact form has no such error.  (First r03
+//              version: u = o + s1 * (d - o) with two selectors and the product u * v: three instructions more per pair and
+//              twice that error.  Multiplying the products of the lane's two pairs of a tile as well -- one logarithm per four
+//              genotypes -- measured 250 us against 246 in r03 and 233-237 against 236-237 on the form above: nothing for the
+//              narrower underflow margin of a four-factor product.)
 constexpr float LOSS_LOG_SHIFT = 20.f;                    // log2 of the scale of the exact form
 __device__ __forceinline__ f32x2_t two_max0(const f32x2_t v) {                 // 2 * max(v, 0), exact.  As asm: the compiler would pair
     f32x2_t r;                                                                 // the two adds into a v_pk_add_f32, which has no |abs|
@@ -688,13 +695,12 @@ __device__ __forceinline__ f32x2_t two_max0(const f32x2_t v) {                 /
     asm("v_add_f32_e64 %0, %1, |%1|" : "=v"(r.y) : "v"(v.y));
     return r;
 }
-// gradient w.r.t. the pre-clamp reconstruction for two genotypes, TIMES 1e-12 (eps; the caller multiplies the sums by rcp(1e-12));
-// den = (1 - d) d is handed back for the loss
+// gradient w.r.t. the pre-clamp reconstruction for two genotypes, TIMES 1e-12 (eps; the caller multiplies the sums by rcp(1e-12))
 // (r05, profiles/r05_abl_p2scalar.txt: the same algebra with scalar v_*_f32 instead of v_pk_*_f32 -- MI355X_MICROARCH.md prices packed f32
 // beside MFMAs at +22..26 cycles per instruction against two scalar ones -- is SLOWER here, 260 vs 239 us: twice the issue slots cost more
 // than the penalty saves at three waves per SIMD.  The arm is gone from the source.)
-__device__ __forceinline__ f32x2_t bce_grad2(const f32x2_t d, const f32x2_t x, const float eps, f32x2_t& den) {
-    den = __builtin_elementwise_fma(-d, d, d);                                                    // d - d^2 in one rounding; < 0 exactly when d is outside [0, 1]
+__device__ __forceinline__ f32x2_t bce_grad2(const f32x2_t d, const f32x2_t x, const float eps) {
+    const f32x2_t den = __builtin_elementwise_fma(-d, d, d);                                                    // d - d^2 in one rounding; < 0 exactly when d is outside [0, 1]
     // sat(1e-12 / den): 1 at den <= 1e-12 (and +0), 0 for den < 0.  Written per element so that the clamp folds into the multiply
     // (v_mul_f32_e64 ... clamp); as inline asm (v_pk_mul_f32 ... clamp) it would sit right behind the v_rcp without the wait state
     // the hardware needs between a transcendental and its consumer -- the hazard recognizer does not look into asm statements
@@ -718,14 +724,13 @@ __device__ __forceinline__ void bce_loss_exact2(const f32x2_t d, const f32x2_t o
     asm volatile("" : "+v"(lossacc));     // pin the accumulation here: otherwise LLVM sinks all the logs of a tile pair
                                           // to the end of the loop body and keeps their 32 inputs alive (+60 VGPRs)
 }
-// fast form: adds log2(f0 * f1) = 2 * (the two genotypes' terms in log2 units) to acc; -inf (or NaN) flags the pair.
-// h = [c == 1] per genotype
-__device__ __forceinline__ void bce_loss_prod2(const f32x2_t d, const f32x2_t den, const f32x2_t x, const f32x2_t h, float& acc) {
+// fast form: adds log2(f0 * f1) = 2 * (the two genotypes' terms in log2 units) to acc; -inf (or NaN) flags the pair
+__device__ __forceinline__ void bce_loss_prod2(const f32x2_t d, const f32x2_t x, float& acc) {
     const f32x2_t o = {__builtin_amdgcn_fmed3f(1.f - d.x, 0.f, 1.f), __builtin_amdgcn_fmed3f(1.f - d.y, 0.f, 1.f)};   // 1 - r: v_sub_f32 ... clamp
-    const f32x2_t q = o - x;                                                             // 1-r | . | -d  for c = 0 | 1 | 2
-    const f32x2_t qq = q * q;                                                            // (1-r)^2 | . | d^2
-    const f32x2_t f = __builtin_elementwise_fma(h, den - qq, qq);                        // c == 1: qq + (den - qq)
-    acc += __builtin_amdgcn_logf(f.x * f.y);
+    const f32x2_t q = o - x;                                                             // 1-r | 1/2 - r | -d  for c = 0 | 1 | 2
+    const f32x2_t mh = __builtin_elementwise_fma(x, x, -x);                              // x^2 - x = -[c == 1] / 4
+    const f32x2_t f = __builtin_elementwise_fma(q, q, mh);                               // (1-r)^2 | -r(1-r) | d^2
+    acc += __builtin_amdgcn_logf(__builtin_fabsf(f.x) * __builtin_fabsf(f.y));
     asm volatile("" : "+v"(acc));             // pin the accumulation here (see bce_loss_exact2)
 }
 
@@ -746,16 +751,6 @@ __device__ __forceinline__ f32x2_t fp4_pair(const uint32_t w, const int sel) {
         case 1: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 1);
         case 2: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 2);
         default: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 1.0f, 3);
-    }
-}
-
-// the same with the conversion's scale 2: a nibble 0001 (the subnormal 0.5) reads 1.0 -- a 0/1 selector without shifting the mask
-__device__ __forceinline__ f32x2_t fp4_pair_x2(const uint32_t w, const int sel) {
-    switch (sel) {
-        case 0: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 2.0f, 0);
-        case 1: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 2.0f, 1);
-        case 2: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 2.0f, 2);
-        default: return __builtin_amdgcn_cvt_scalef32_pk_f32_fp4(w, 2.0f, 3);
     }
 }
 
@@ -1105,10 +1100,9 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                             for (int h2 = 0; h2 < 2; ++h2) {
                                 const uint32_t cw = h2 ? odd[s2] : even[s2];
                                 const f32x2_t d = {D[2 * h2], D[2 * h2 + 1]}, x = fp4_pair(cw, t);
-                                f32x2_t den;
-                                const f32x2_t dR = bce_grad2(d, x, eps, den);
-                                if constexpr (FAST_LOSS)      // selector [c == 1]: the nibble 0001 read with the scale 2
-                                    bce_loss_prod2(d, den, x, fp4_pair_x2((cw & ~(cw >> 1)) & 0x11111111u, t), it_acc);
+                                const f32x2_t dR = bce_grad2(d, x, eps);
+                                if constexpr (FAST_LOSS)
+                                    bce_loss_prod2(d, x, it_acc);
                                 else if constexpr (LOSS)
                                     bce_loss_exact2<UNIT_P>(d, (f32x2_t){1.f, 1.f} - d, x, lossacc);
                                 const uint32_t hp = __builtin_bit_cast(uint32_t, __builtin_convertvector(dR, bf16x2_t));

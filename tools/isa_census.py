@@ -111,13 +111,11 @@ def main():
         ("gradient", "v_mul_f32_e64", 2, "sat(1e-12 * rcp): the floor and the clamp mask in one multiply"),
         ("gradient", "v_pk_add_f32", 1, "d - x"),
         ("gradient", "v_pk_mul_f32", 1, "(d - x) * inv"),
-        ("loss", "v_cvt_scalef32_pk_f32_fp4", 1, "h = [c == 1] (second FP4 read, scale 2)"),
         ("loss", "v_sub_f32_e64", 2, "o = sat(1 - d)"),
-        ("loss", "v_pk_add_f32", 2, "q = o - x;  den - qq"),
-        ("loss", "v_pk_mul_f32", 1, "qq = q^2"),
-        ("loss", "v_pk_fma_f32", 1, "f = qq + h (den - qq)"),
+        ("loss", "v_pk_add_f32", 1, "q = o - x"),
+        ("loss", "v_pk_fma_f32", 2, "x^2 - x = -[c == 1] / 4;  f = q^2 + that  (r06: | q^2 - x(1-x) | is f for all three calls)"),
         ("loss", "v_mul_f32_e32", 1, "f0 * f1"),
-        ("loss", "v_log_f32_e32", 1, "one logarithm per pair"),
+        ("loss", "v_log_f32_e64", 1, "one logarithm per pair, | . | as a source modifier"),
         ("loss", "v_add_f32_e32", 1, "accumulate"),
         ("bf16 split", "v_cvt_pk_bf16_f32", 2, "hi = bf16(dR), lo = bf16(dR - hi)"),
         ("bf16 split", "v_lshlrev_b32_e32", 1, "hi.x back to f32"),
