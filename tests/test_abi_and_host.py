@@ -853,3 +853,41 @@ def test_dz_image_hand_off_compiles_to_the_instructions_its_contract_names(tmp_p
         assert waits, name                                     # ... and is acknowledged before the block is counted
         assert any(s_.startswith("s_barrier") for s_ in before[waits[-1]:]), name      # every wave of the block has waited
         assert any(s_.startswith("global_load_dword ") and s_.endswith(" sc1") for s_ in after), name      # the last block reads past its L1 / L2 copies
+
+
+def test_pass2_pair_product_loss_is_one_formula_for_the_three_calls():
+    """The algebra of pass 2's fast loss (csrc/nadm_genotype_passes.hip, bce_loss_prod2), restated in numpy float32 and held against the
+    oracle's BCE (neural_admixture.py:288 with ATen's -100 clamp): with q = sat(1 - d) - x (x = call / 2) twice a genotype's term is
+    log f, f = | q^2 - x(1-x) | = (1-d)^2 | d(1-d) | d^2 for the calls 0 | 1 | 2.  And the fallback condition: f is EXACTLY 0 -- the wave
+    then recomputes the tile pair in the exact form -- for every (call, d) whose reference term is a clamped logarithm, d = 1 + a rounding
+    error included; never negative, so no product of two factors can hide one."""
+    from oracle import nadm_oracle as O
+    F = np.float32
+
+    def fast_f(d, x):
+        o = np.clip(F(1) - d, F(0), F(1)).astype(F)                                # v_sub_f32 ... clamp
+        q = (o - x).astype(F)
+        mh = (x.astype(np.float64) * x - x).astype(F)                              # v_pk_fma_f32 (one rounding; exact here)
+        return np.abs((q.astype(np.float64) * q + mh).astype(F))                   # v_pk_fma_f32, | . | in the v_log
+
+    rng = np.random.default_rng(5)
+    n = 1 << 16
+    d = np.exp(rng.uniform(np.log(1e-5), 0.0, n)).astype(F)
+    d[::2] = (F(1) - d[::2]).astype(F)                                             # both ends of (0, 1)
+    d = np.clip(d, F(1e-5), F(1) - F(1e-5)).astype(F)
+    x = (rng.integers(0, 3, n) / 2).astype(F)
+    f = fast_f(d, x)
+    want = np.where(x == 0, (1 - d.astype(np.float64)) ** 2, np.where(x == 1, d.astype(np.float64) ** 2, d.astype(np.float64) * (1 - d.astype(np.float64))))
+    assert np.all(f > 0)
+    assert np.abs(f / want - 1).max() < 1.3e-7 / 1e-5                              # the ABSOLUTE rounding error of 1 - d, 6e-8, under d >= 1e-5
+    fast = -0.5 * np.log(f.astype(np.float64)).sum()
+    assert abs(fast - O.bce_sum(d, x)) / O.bce_sum(d, x) < 2e-6                    # the tolerance the GPU test holds the kernel to
+    # the clamp cases: exact zeros, never a negative factor
+    one_up = np.nextafter(F(1), F(2))
+    for dv, calls_with_clamped_term in ((F(0), (0.5, 1.0)), (F(1), (0.0, 0.5)), (one_up, (0.0, 0.5)), (F(1.5), (0.0, 0.5))):
+        for xv in (0.0, 0.5, 1.0):
+            fv = fast_f(np.array([dv], F), np.array([xv], F))[0]
+            assert fv >= 0
+            assert (fv == 0) == (xv in calls_with_clamped_term), (dv, xv, fv)
+            if fv != 0:                                                            # the other call's term is log 1 = 0 in the reference too
+                assert fv == 1 and O.bce_sum(np.clip(np.array([dv], F), 0, 1), np.array([xv], F)) == 0
