@@ -140,10 +140,11 @@ __device__ __forceinline__ void fp6_piece(const float (&v)[32], int p, u32x6_t& 
     const bool dead = !(mx > 0.f) || !finite || sb < 1;     // (a piece below 2^-126 carries nothing an fp32 sum would see)
     if (dead) sb = finite ? 127 : 255;                      // inf / NaN in the block: the E8M0 scale NaN, so that what multiplies it becomes NaN
     f32x16_t fa, fb;
+    const uint32_t digit = dead ? 0u : 15u;                 // ONE select: per element it is a v_cndmask with its mask in VCC, 23 cycles x 32 on the tail of the MLP backward
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
         const uint32_t n = (uint32_t)__builtin_ldexpf(__builtin_fabsf(v[e]), 28 - E0);
-        const uint32_t h = dead ? 0u : ((n >> (28 - 4 * p)) & 15u);
+        const uint32_t h = (n >> (28 - 4 * p)) & digit;
         const float f = __builtin_copysignf((float)h, v[e]);
         if (e & 1) fb[e >> 1] = f; else fa[e >> 1] = f;      // the conversion interleaves its two sources: field 2i = a[i], 2i + 1 = b[i]
     }

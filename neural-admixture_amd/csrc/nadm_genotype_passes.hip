@@ -155,6 +155,8 @@ __device__ __forceinline__ uint32_t fp4_bf16_pair(const uint32_t w, const int se
 }
 
 __device__ __forceinline__ uint32_t bf16_trunc_bits(float v) { return __float_as_uint(v) & 0xFFFF0000u; }
+// (a >> 16) | (b & 0xFFFF0000): the bf16 truncations of a and b as one packed pair, a in the low half
+__device__ __forceinline__ uint32_t upper_halves(float a, float b) { return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u); }
 
 // The sum of the MLP weight-gradient partials of the PREVIOUS step + Adam on the small parameters (what nadm_small_grads does
 // as a launch of its own: 4.7 us + a launch gap at the end of every step) as side blocks of pass 1: pass 1 reads none of the
@@ -244,31 +246,30 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
 #pragma unroll
         for (int j = 0; j < CP; ++j) {
             const int e = 4 * (lane + 64 * j), ml = e / CP;
-            *reinterpret_cast<float4*>(sv + 8 * ml + 8 * (ml >> 6) + e % CP) = (slice0 + ml < M) ? vst[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint32_t in = lt_mask64(slice0 + ml, M);     // (a ?: here is four v_cndmask with the mask in VCC per row piece: 23 cycles each, nadm_common.h)
+            *reinterpret_cast<float4*>(sv + 8 * ml + 8 * (ml >> 6) + e % CP) = make_float4(keepf(vst[j].x, in), keepf(vst[j].y, in), keepf(vst[j].z, in), keepf(vst[j].w, in));
         }
         __builtin_amdgcn_wave_barrier();                      // the slice is written and read by this wave only (LDS operations of a wave complete in order)
         const int c = i & 7;
-        const bool upper = i >= 8;
+        const uint32_t upper = lt_mask(7, i);                 // lanes i >= 8 hold the mid pieces: blends, not selects
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) {
             uint32_t w1[4], w2[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                uint32_t p1[2], p2[2];
+                // two values -> their hi / mid / lo pieces (truncating split: every remainder exact), packed two by two with ONE v_perm_b32
+                // per piece (the upper halves of two registers side by side) instead of two shifts and an or
+                float v[2], r1[2], r2[2];
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int ml = 64 * q + 8 * s8 + 4 * (d & 1) + 2 * hh + (d >> 1);                // element order of the A operand
-                    const float v = c < CP ? sv[8 * ml + 8 * q + c] : 0.f;                           // (rows past M hold zeros)
-                    const uint32_t hi = bf16_trunc_bits(v);
-                    const float r1 = v - __uint_as_float(hi);
-                    const uint32_t mid = bf16_trunc_bits(r1);
-                    const float r2 = r1 - __uint_as_float(mid);
-                    const uint32_t lo = bf16_trunc_bits(r2);
-                    p1[hh] = (upper ? mid : hi) >> 16;
-                    p2[hh] = upper ? 0u : (lo >> 16);
+                    v[hh] = c < CP ? sv[8 * ml + 8 * q + c] : 0.f;                                   // (rows past M hold zeros)
+                    r1[hh] = v[hh] - __uint_as_float(bf16_trunc_bits(v[hh]));
+                    r2[hh] = r1[hh] - __uint_as_float(bf16_trunc_bits(r1[hh]));
                 }
-                w1[d] = p1[0] | (p1[1] << 16);
-                w2[d] = p2[0] | (p2[1] << 16);
+                const uint32_t hi = upper_halves(v[0], v[1]), mid = upper_halves(r1[0], r1[1]), lo = upper_halves(r2[0], r2[1]);
+                w1[d] = blend(mid, hi, upper);
+                w2[d] = lo & ~upper;
             }
             b1[s8] = __builtin_bit_cast(bf16x8, make_uint4(w1[0], w1[1], w1[2], w1[3]));
             b2[s8] = __builtin_bit_cast(bf16x8, make_uint4(w2[0], w2[1], w2[2], w2[3]));
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
                 rown[(u + 2 * EM_D - 2) % EM_D] = row_of(tile + 2 * EM_D - 2);
                 const bool ok = col_ok && (tile * 16 + i < b);
                 const uint4 cur = st[u];
-                const uint32_t raw[4] = {ok ? cur.x : 0u, ok ? cur.y : 0u, ok ? cur.z : 0u, ok ? cur.w : 0u};
+                const uint32_t raw[4] = {ok ? cur.x : 0u, ok ? cur.y : 0u, ok ? cur.z : 0u, ok ? cur.w : 0u};    // (wave-level mask in an SGPR pair: cheaper here than building a lane mask per tile, measured)
                 f32x4_t d1 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, d2 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
