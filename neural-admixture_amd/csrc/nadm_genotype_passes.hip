@@ -286,7 +286,10 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
         const int smp = tile * 16 + i;
         return idx[smp < b ? smp : b - 1];
     };
-    auto load_row = [&](int32_t row) -> uint4 { return *reinterpret_cast<const uint4*>(xp + (int64_t)row * ld + byte_off_c); };
+    // row index and row length as UNSIGNED 32-bit factors: one v_mad_u64_u32 per address (a signed 64 x 64 product is that + two quarter-rate
+    // v_mul_lo_u32 + a sign extension, per tile and lane; the launcher refuses rows of 4 GiB and more)
+    const uint32_t ld32 = (uint32_t)ld;
+    auto load_row = [&](int32_t row) -> uint4 { return *reinterpret_cast<const uint4*>(xp + ((uint64_t)(uint32_t)row * ld32 + (uint64_t)byte_off_c)); };
     // EM_D - 1 tiles of loads in flight ahead of the compute (a 16-sample tile is ~0.3 us of work per wave, much less
     // than the latency of the dependent idx -> row loads); the row index of the tile after those is fetched too.
     uint4 st[EM_D];
@@ -1736,6 +1739,7 @@ static int encode_fwd_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
     if (!xp || !idx || !V || !zpart) return fail("nadm_encode_fwd: null pointer");
     if (b <= 0 || M <= 0) return fail("nadm_encode_fwd: empty batch or M");
     if (ld % 16 != 0 || ld * 4 < M) return fail("nadm_encode_fwd: ld must be a multiple of 16 and >= ceil(M/4)");
+    if (ld >> 32) return fail("nadm_encode_fwd: rows of 4 GiB and more (ld >= 2^32) are not supported");      // the matrix pass forms row addresses from 32-bit factors
     const int rpb = enc_rows_per_block(b);
     dim3 grid((unsigned)nadm_encode_chunks(M), (unsigned)((b + rpb - 1) / rpb)), block(rpb);
     const size_t lds = (size_t)rpb * ENC_LDW * 4;
