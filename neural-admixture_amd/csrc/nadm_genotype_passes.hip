@@ -964,7 +964,9 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                 qstage[j] = Q[(int64_t)smp * SP + (qk < KP ? qk : 0)];
             }
         }
-        stage = *reinterpret_cast<const uint4*>(xp + (int64_t)row_pref * ld + poff_c);
+        // (unsigned 32-bit factors: one v_mad_u64_u32; the signed 64 x 64 product -- two quarter-rate v_mul_lo_u32 more per tile and thread, in front of
+        // the tile's first load -- cost the launch 1.2 %, profiles/r06_abl_p2addr.txt; the launcher refuses rows of 4 GiB and more)
+        stage = *reinterpret_cast<const uint4*>(xp + ((uint64_t)(uint32_t)row_pref * (uint32_t)ld + (uint64_t)poff_c));
         row_pref = row_index(i0 + MF_TS);
     };
     auto commit = [&](int i0) {
@@ -1857,6 +1859,7 @@ static int decode_bce_impl(const uint8_t* xp, int64_t ld, const int32_t* idx, in
                            float* losspart, int32_t with_loss, void* stream, uint8_t* xg, AdamFused ad, const uint4* qimg = nullptr,
                            int32_t n_slices = 1, float* slab = nullptr, int32_t* slice_cnt = nullptr) {
     if (!xp || !idx || !P || !Q || !dP || !dqpart) return fail("nadm_decode_bce: null pointer");
+    if (ld >> 32) return fail("nadm_decode_bce: rows of 4 GiB and more (ld >= 2^32) are not supported");      // the matrix pass forms row addresses from 32-bit factors
     if (n_slices < 1 || n_slices > NADM_MAX_P2_SLICES) return fail("nadm_decode_bce_sliced: n_slices must be in 1..8");
     if (n_slices > 1) {
         if (kp > 16) return fail("nadm_decode_bce_sliced: sample slices exist for padded K <= 16 only");
