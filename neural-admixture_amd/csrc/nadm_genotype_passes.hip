@@ -286,8 +286,8 @@ __global__ __launch_bounds__(512) void encode_fwd_mfma_kernel(const uint8_t* __r
         const int smp = tile * 16 + i;
         return idx[smp < b ? smp : b - 1];
     };
-    // row index and row length as UNSIGNED 32-bit factors: one v_mad_u64_u32 per address (a signed 64 x 64 product is that + two quarter-rate
-    // v_mul_lo_u32 + a sign extension, per tile and lane; the launcher refuses rows of 4 GiB and more)
+    // row index and row length as UNSIGNED 32-bit factors: one v_mad_u64_u32 per address (a signed 64 x 64 product is that + two
+    // v_mul_lo_u32 + a sign extension, per tile and lane, in the chain in front of the gather's load; the launcher refuses rows of 4 GiB and more)
     const uint32_t ld32 = (uint32_t)ld;
     auto load_row = [&](int32_t row) -> uint4 { return *reinterpret_cast<const uint4*>(xp + ((uint64_t)(uint32_t)row * ld32 + (uint64_t)byte_off_c)); };
     // EM_D - 1 tiles of loads in flight ahead of the compute (a 16-sample tile is ~0.3 us of work per wave, much less
@@ -964,8 +964,8 @@ __global__ __launch_bounds__(64 * BF_WAVES) __attribute__((amdgpu_waves_per_eu(b
                 qstage[j] = Q[(int64_t)smp * SP + (qk < KP ? qk : 0)];
             }
         }
-        // (unsigned 32-bit factors: one v_mad_u64_u32; the signed 64 x 64 product -- two quarter-rate v_mul_lo_u32 more per tile and thread, in front of
-        // the tile's first load -- cost the launch 1.2 %, profiles/r06_abl_p2addr.txt; the launcher refuses rows of 4 GiB and more)
+        // (unsigned 32-bit factors: one v_mad_u64_u32; the signed 64 x 64 product -- two v_mul_lo_u32 and a sign extension more per tile and thread, in the chain
+        // in front of the tile's gather load -- cost the launch 1.2 %, more than their 4.6 issue cycles each: profiles/r06_abl_p2addr.txt; the launcher refuses rows of 4 GiB and more)
         stage = *reinterpret_cast<const uint4*>(xp + ((uint64_t)(uint32_t)row_pref * (uint32_t)ld + (uint64_t)poff_c));
         row_pref = row_index(i0 + MF_TS);
     };

@@ -63,6 +63,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define B_LOGABS(j) asm volatile("v_log_f32_e64 %0, |%0|" : "+v"(a[j]));
 #define B_MULLEG(j) asm volatile("v_mul_legacy_f32 %0, %0, %1" : "+v"(a[j]) : "v"(c1));
 #define B_PKMOV(j) asm volatile("v_pk_mov_b32 %0, %0, %1" : "+v"(p[j]) : "v"(q));
+#define B_MULLO(j) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[j]) : "v"(c1));
+#define B_MULHI(j) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(u[j]) : "v"(c1));
+#define B_MAD64(j) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(p[j]) : "v"(u[j]), "v"(c1) : "vcc");
+#define B_LSHLADD64(j) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(p[j]) : "v"(q));
+#define B_LSHL64(j) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(p[j]));
+#define B_MULU24(j2) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[j2]) : "v"(c1));
+#define B_MADU24(j) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(u[j]) : "v"(c1), "v"(c2));
 #define B_SUBREV(j) asm volatile("v_sub_f32 %0, 1.0, %0" : "+v"(a[j]));
 
 KERNEL(k_add_vv, B_ADD_VV) KERNEL(k_add_sv, B_ADD_SV) KERNEL(k_mul_vv, B_MUL_VV) KERNEL(k_max_vv, B_MAX_VV) KERNEL(k_max_sv, B_MAX_SV)
@@ -71,6 +78,7 @@ KERNEL(k_shl, B_SHL) KERNEL(k_perm, B_PERM) KERNEL(k_cndmask, B_CNDMASK) KERNEL(
 KERNEL(k_pkmul, B_PKMUL) KERNEL(k_pkfma, B_PKFMA) KERNEL(k_cvtbf, B_CVTBF) KERNEL(k_fp4, B_FP4) KERNEL(k_log, B_LOG) KERNEL(k_rcp, B_RCP)
 KERNEL(k_mulu24, B_MULU24) KERNEL(k_addabs, B_ADDABS) KERNEL(k_lshladd, B_LSHLADD) KERNEL(k_andor, B_ANDOR) KERNEL(k_or, B_OR) KERNEL(k_bfi, B_BFI)
 KERNEL(k_alignbit, B_ALIGNBIT) KERNEL(k_min, B_MIN) KERNEL(k_cvti, B_CVTI) KERNEL(k_frexpm, B_FREXPM) KERNEL(k_logabs, B_LOGABS) KERNEL(k_mulleg, B_MULLEG) KERNEL(k_pkmov, B_PKMOV)
+KERNEL(k_mullo, B_MULLO) KERNEL(k_mulhi, B_MULHI) KERNEL(k_mad64, B_MAD64) KERNEL(k_lshladd64, B_LSHLADD64) KERNEL(k_lshl64, B_LSHL64) KERNEL(k_madu24, B_MADU24)
 KERNEL(k_mov, B_MOV) KERNEL(k_logmix, B_LOGMIX) KERNEL(k_bfe, B_BFE) KERNEL(k_addu, B_ADDU) KERNEL(k_subrev, B_SUBREV)
 
 static double g_ghz = 2.4;
@@ -111,6 +119,8 @@ int main() {
         run("v_mul_u32_u24 v, 0x10000, v", k_mulu24, out, wps, 1); run("v_add_f32_e64 v, v, |v|", k_addabs, out, wps, 1); run("v_lshl_add_u32", k_lshladd, out, wps, 1);
         run("v_and_or_b32", k_andor, out, wps, 1); run("v_or_b32", k_or, out, wps, 1); run("v_bfi_b32", k_bfi, out, wps, 1); run("v_alignbit_b32", k_alignbit, out, wps, 1);
         run("v_min_f32 v, 1.0, v", k_min, out, wps, 1); run("v_cvt_f32_i32", k_cvti, out, wps, 1); run("v_frexp_mant_f32", k_frexpm, out, wps, 1);
+        run("v_mul_lo_u32 v, v, v", k_mullo, out, wps, 1); run("v_mul_hi_u32 v, v, v", k_mulhi, out, wps, 1); run("v_mad_u64_u32 v[2], vcc, v, v, v[2]", k_mad64, out, wps, 1);
+        run("v_lshl_add_u64 v[2], v[2], 2, v[2]", k_lshladd64, out, wps, 1); run("v_lshlrev_b64 v[2], 3, v[2]", k_lshl64, out, wps, 1); run("v_mad_u32_u24 v, v, v, v", k_madu24, out, wps, 1);
         run("v_log_f32_e64 v, |v|", k_logabs, out, wps, 1); run("v_mul_legacy_f32", k_mulleg, out, wps, 1); run("v_pk_mov_b32", k_pkmov, out, wps, 1);
     }
     return 0;
