@@ -101,7 +101,7 @@ def main():
     for name, n, w in rows:
         tot += n * w
         print(f"{name:30s} {n:6d}   x {w:6.1f}   = {n * w:9.0f}    {n * w / geno:6.3f}")
-    print(f"{'static estimate':30s}                     {tot:9.0f}    {tot / geno:6.3f}   (SQ_INSTS_VALU of the profiled launch: profiles/r06_pmc_sq.json -- 13.98 per genotype; 15.35 with the r03-r06 loss form)")
+    print(f"{'static estimate':30s}                     {tot:9.0f}    {tot / geno:6.3f}   (SQ_INSTS_VALU of the profiled launch: profiles/r06_pmc_sq.json -- 13.91 per genotype; 15.35 with the r03-r06 loss form)")
     # ---- the hot loop itemised: 32 genotypes per lane = 16 PAIRS (packed f32 math handles two genotypes per instruction)
     pairs = per_lane // 2
     want = [  # bucket, opcode, count per pair, what it is
