@@ -17,7 +17,8 @@
  *
  * Device data layout (all float32 unless noted):
  *   xp     uint8 [rows, ld]   2-bit packed genotypes, sample-major, SNP 4c+i in bits [2i,2i+1] of
- *                             byte c (pack2bit.cu:26-31); ld >= ceil(M/4), ld % 16 == 0, pad bytes 0.
+ *                             byte c (pack2bit.cu:26-31); ld >= ceil(M/4), ld % 16 == 0, ld < 2^32 (the matrix-pipe passes form row addresses from
+ *                             32-bit factors and refuse longer rows), pad bytes 0.
  *   V      [M, CP]            encoder projection, CP = C rounded up to a multiple of 4, pad cols 0
  *                             (reference: Q_P.V [M,C], neural_admixture.py:129-130).
  *   P_h    [M, KP_h]          decoder head h, SNP-major, KP_h = padded K (nadm_pad_k), pad cols 0
