@@ -891,3 +891,13 @@ def test_pass2_pair_product_loss_is_one_formula_for_the_three_calls():
             assert (fv == 0) == (xv in calls_with_clamped_term), (dv, xv, fv)
             if fv != 0:                                                            # the other call's term is log 1 = 0 in the reference too
                 assert fv == 1 and O.bce_sum(np.clip(np.array([dv], F), 0, 1), np.array([xv], F)) == 0
+
+
+def test_matrix_passes_refuse_rows_of_4_gib():
+    """Passes 1 and 2 form a tile's row address as ONE v_mad_u64_u32 of unsigned 32-bit factors (row index x row length): the launchers
+    refuse ld >= 2^32 before anything is launched (include/nadm.h; no GPU needed: the check precedes the launch)."""
+    from neural_admixture_amd._lib import lib
+    fake = C.c_void_p(0x1000)                                   # never dereferenced: the call fails in the argument checks
+    ld = 1 << 32
+    assert lib.nadm_encode_fwd(fake, ld, fake, 16, 4 * ld, fake, 8, fake, None) != 0 and b"4 GiB" in lib.nadm_last_error()
+    assert lib.nadm_decode_bce(fake, ld, fake, 16, 4 * ld, fake, 8, fake, 8, fake, fake, fake, 1, None) != 0 and b"4 GiB" in lib.nadm_last_error()
