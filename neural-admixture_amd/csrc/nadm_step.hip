@@ -489,6 +489,7 @@ extern "C" int nadm_plan_create(const nadm_plan_desc_t* desc, nadm_plan_t** out)
     const nadm_plan_desc_t& d = *desc;
     if (d.mode != NADM_MODE_SINGLE && d.mode != NADM_MODE_DP && d.mode != NADM_MODE_SNP) return fail("nadm_plan_create: unknown mode");
     if (d.M <= 0 || d.bmax <= 0 || d.ld % 16 != 0 || d.ld * 4 < d.M) return fail("nadm_plan_create: M, bmax > 0; ld a multiple of 16 and >= ceil(M/4)");
+    if (d.ld >> 32) return fail("nadm_plan_create: rows of 4 GiB and more (ld >= 2^32) are not supported");      // the genotype passes form row addresses from 32-bit factors
     const nadm_heads_t& hd = d.heads;
     if (hd.n_heads < 1 || hd.n_heads > NADM_MAX_HEADS) return fail("nadm_plan_create: head table not initialised (nadm_heads_init)");
     if (!d.params || !d.grads || !d.m || !d.v || !d.zpart || !d.Z || !d.rinv || !d.Zn || !d.H || !d.Q || !d.dL || !d.dHpre || !d.dgp || !d.dZ ||
