@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void mlp_fwd_fast_kernel(nadm_heads_t hd, cons
     __shared__ float s_part[32 * BR_STRIDE];
     __shared__ float s_parts8[32 * 8];
     extern __shared__ __attribute__((aligned(16))) float s_logit[];      // [SB][SP]
-    const int C = hd.C, CP = hd.CP, Hd = hd.Hd, SP = hd.SP;
+    const int C = C8 ? 8 : hd.C, CP = C8 ? 8 : hd.CP, Hd = hd.Hd, SP = hd.SP;     // (C8: C == CP == 8 at compile time -- no run-time divisions by the row length)
     const int tid = threadIdx.x;
     const int i0 = blockIdx.x * SB;
     const int ns = min(SB, b - i0);
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
     __shared__ float s_part[32 * BR_STRIDE];
     __shared__ float s_parts8[32 * 8];
     extern __shared__ __attribute__((aligned(16))) float s_dl[];         // [SB][SP]
-    const int C = hd.C, CP = hd.CP, Hd = hd.Hd, SP = hd.SP;
+    const int C = C8 ? 8 : hd.C, CP = C8 ? 8 : hd.CP, Hd = hd.Hd, SP = hd.SP;     // (C8: C == CP == 8 at compile time)
     const int tid = threadIdx.x;
     // ---- loss: one EXTRA block (the launch has one more block than sample groups when n_loss > 0).  Inside a working block
     // the sum -- an HBM round trip, a float64 wave reduction -- was a tail every other block had already left behind.
@@ -650,6 +650,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_a_fast_kernel(nadm_heads_t hd, co
                     float4 v[DQD];
 #pragma unroll
                     for (int u = 0; u < DQD; ++u) { const int64_t ch = ch0 + (int64_t)u * G; v[u] = src[(ch < nch ? ch : nch - 1) * stride4]; }
+                    __builtin_amdgcn_sched_barrier(0);        // every load of the trip in flight before the first addition (left to itself the scheduler may interleave them six at a time: +3 us)
 #pragma unroll
                     for (int u = 0; u < DQD; ++u) {
                         const uint32_t ok = lt_mask64(ch0 + (int64_t)u * G, nch);
